@@ -1,0 +1,161 @@
+/* hjbdp.h - C ABI of libhjbdp: the Bellman-backup hot path of grid-based HJB
+ * dynamic programming on AMD MI355X (gfx950).
+ *
+ * The reference (abdolrezat/Optimal-Control-Dynamic-Programming, pure MATLAB) has
+ * no FFI seam; the seam this library replaces is the per-stage statement every
+ * solver repeats inside its stage loop
+ *
+ *     [F.Values, idx] = min( J_stage + F(x_next_1,...,x_next_D), [], ctrl_dim )
+ *
+ *   test/Dynamic_Solver.m:207-210           (J_state_M, called from run :86-102)
+ *   position-control/Solver_position.m:135-137   (simplified_run :132-141)
+ *   attitude-control/Solver_attitude.m:239-241   (simplified_run :236-247)
+ *   attitude-control/Solver_attitude.m:400-409   (calculate_J_U_opt_state_M, run :280-287)
+ *   pos-att/Solver_pos_att.m:272                 (calculate_one_channel_U_Opt :270-286)
+ *
+ * plus the loop around it (hjb_solve) including the pos-att early-stop monitor
+ * (Solver_pos_att.m:268-285).  F is griddedInterpolant(...,'linear'): N-linear
+ * interpolation with linear extrapolation; min returns the first minimal index.
+ *
+ * Conventions (MATLAB's): all arrays COLUMN-MAJOR, first index fastest; grid
+ * dims 0..D-1 are state axes, D..D+C-1 control axes; argmin labels enumerate the
+ * control dims column-major (ndgrid order) and are index_base-based.
+ *
+ * Plain C, caller-owned host pointers, no callbacks except the optional
+ * progress function; never throws.  A MATLAB host binds this header with
+ * loadlibrary/calllib; tests bind it with ctypes.
+ */
+#ifndef HJBDP_H
+#define HJBDP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HJB_MAX_D 6      /* state dims   (Solver_attitude.run: 6)            */
+#define HJB_MAX_C 3      /* control dims (Solver_attitude.run: U1,U2,U3)     */
+#define HJB_MAX_G 9      /* D + C        (reshape_states: dims 1..9)         */
+#define HJB_MAX_TERMS 8  /* broadcast terms per quantity                     */
+
+/* status codes */
+#define HJB_OK 0
+#define HJB_E_INVALID 1      /* bad argument / inconsistent problem           */
+#define HJB_E_UNSUPPORTED 2  /* valid but not supported (D, C, dtype)         */
+#define HJB_E_DEVICE 3       /* HIP error; text via hjb_last_error            */
+#define HJB_E_NOMEM 4
+#define HJB_E_HALO 5         /* a query left the slab's halo (multi-GPU)      */
+
+#define HJB_F32 0
+#define HJB_F64 1
+
+/* One broadcast term of an ordered sum  q = ((t0 + t1) + t2) + ...
+ * This is MATLAB implicit expansion of vectors/arrays reshaped onto the
+ * D+C grid dims (Solver_attitude.m:717-742 reshape_states; Solver_pos_att.m
+ * :307-314, :791-801): bit d of mask set <=> the term varies along grid dim d.
+ * data: host array of the problem's dtype, column-major over the masked dims
+ * in increasing dim order. */
+typedef struct hjb_term {
+    uint32_t mask;
+    uint32_t reserved;
+    const void *data;
+} hjb_term;
+
+typedef struct hjb_problem {
+    int32_t D;                      /* number of state axes, 1..HJB_MAX_D      */
+    int32_t C;                      /* number of control axes, 1..HJB_MAX_C    */
+    int32_t n[HJB_MAX_D];           /* state grid sizes (>= 2)                 */
+    int32_t m[HJB_MAX_C];           /* control grid sizes (>= 1)               */
+    int32_t dtype;                  /* HJB_F32 / HJB_F64: arithmetic type of J,
+                                       tables, knots and weights               */
+    int32_t index_base;             /* 0 or 1 (MATLAB) for argmin labels       */
+    const double *knots[HJB_MAX_D]; /* grid vectors, strictly increasing, may be
+                                       non-uniform (Solver_pos_att.m:906-918);
+                                       rounded to dtype inside                 */
+    /* x_next_a = ordered sum of terms (a_D_M Dynamic_Solver.m:184-188;
+       next_stage_states_simplified Solver_pos_att.m:299-328; ...)             */
+    int32_t n_next_terms[HJB_MAX_D];
+    hjb_term next_terms[HJB_MAX_D][HJB_MAX_TERMS];
+    /* stage cost g = ordered sum of terms (g_D Dynamic_Solver.m:196-200;
+       J_current_reshaped Solver_pos_att.m:784-802; ...)                       */
+    int32_t n_cost_terms;
+    int32_t reserved0;
+    hjb_term cost_terms[HJB_MAX_TERMS];
+    /* Slab decomposition along the LAST state axis (multi-GPU; all four zero =
+       whole grid).  The handle owns planes [slab_begin, slab_end) and every J
+       buffer it is given covers planes [slab_begin-halo_lo, slab_end+halo_hi). */
+    int32_t slab_begin, slab_end, halo_lo, halo_hi;
+} hjb_problem;
+
+typedef struct hjb_handle_s *hjb_handle;
+
+/* optional progress callback, replaces fprintf/waitbar in the stage loops
+ * (Dynamic_Solver.m:101, Solver_pos_att.m:278): called at monitor points with
+ * the reference's k_s, e = d(sum J), e2 = d(sum idx), elapsed seconds. */
+typedef void (*hjb_progress_fn)(void *user, int32_t k_s, double e, double e2, double seconds);
+
+typedef struct hjb_solve_opts {
+    int32_t n_stages;        /* number of backups: N-1 (Dynamic_Solver.m:86), N_stage-1 */
+    int32_t monitor_period;  /* 0 = off; 50 in Solver_pos_att.m:273                     */
+    double monitor_tol;      /* 1e-2 in Solver_pos_att.m:269                            */
+    const void *terminal;    /* J_N [nS] dtype, NULL = zeros (Dynamic_Solver.m:83-84)   */
+    void *J_final;           /* out [nS] dtype: J of the last computed stage (may be NULL) */
+    int32_t *idx_final;      /* out [nS]: argmin labels of the last computed stage      */
+    void *J_stages;          /* out [nS * n_stages] or NULL: stage with reference index
+                                k_s (1-based, counting down from n_stages) is written
+                                to plane k_s-1  (test_coder.m:32 J_star(:,:,k_s))       */
+    int32_t *idx_stages;     /* out [nS * n_stages] or NULL (Dynamic_Solver.m:100)      */
+    hjb_progress_fn progress;
+    void *progress_user;
+} hjb_solve_opts;
+
+typedef struct hjb_result {
+    int32_t stages_done;     /* < n_stages if the monitor stopped the sweep             */
+    int32_t stopped_early;
+    double sweep_ms;         /* device time of the stage loop (HIP events)              */
+    double last_e, last_e2;  /* monitor deltas at the last monitor point                */
+} hjb_result;
+
+typedef struct hjb_info {
+    int64_t n_states;        /* states this handle owns                                 */
+    int64_t n_controls;
+    int64_t j_elems;         /* elements of a J buffer (owned + halo planes)            */
+    int32_t kernel_variant;  /* which stage kernel hjb_create selected                  */
+    int32_t lds_bytes;
+    int32_t block, grid;
+    int32_t halo_needed_lo;  /* conservative halo the tables imply (planes)             */
+    int32_t halo_needed_hi;
+} hjb_info;
+
+const char *hjb_version(void);
+const char *hjb_status_string(int32_t status);
+/* number of visible HIP devices, or 0 */
+int32_t hjb_device_count(void);
+
+/* Validate the problem, copy tables and knots to `device`, pick a kernel. */
+int32_t hjb_create(const hjb_problem *problem, int32_t device, hjb_handle *out);
+int32_t hjb_destroy(hjb_handle h);
+/* text of the last error on this handle (h may be NULL: last create error) */
+const char *hjb_last_error(hjb_handle h);
+int32_t hjb_get_info(hjb_handle h, hjb_info *info);
+/* tuning/testing knobs: "variant" (force a stage kernel), "block" */
+int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
+
+/* ONE backup, host buffers (exactly the MATLAB statement above):
+ * J_next [j_elems] -> J_out [j_elems] (owned planes written), idx_out [n_states]. */
+int32_t hjb_backup_stage(hjb_handle h, const void *J_next, void *J_out, int32_t *idx_out);
+/* ONE backup on device buffers, asynchronous on `stream` (a hipStream_t; NULL =
+ * default stream).  For host-driven loops and multi-GPU halo exchange. */
+int32_t hjb_backup_stage_device(hjb_handle h, const void *dJ_next, void *dJ_out,
+                                int32_t *d_idx_out, void *stream);
+/* Non-zero if a previous device-side backup hit HJB_E_HALO (synchronises). */
+int32_t hjb_check_device_status(hjb_handle h, void *stream);
+
+/* The whole backward sweep (the `for k` loops of the reference). */
+int32_t hjb_solve(hjb_handle h, const hjb_solve_opts *opts, hjb_result *result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HJBDP_H */

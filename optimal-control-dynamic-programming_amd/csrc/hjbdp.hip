@@ -1,0 +1,601 @@
+// hjbdp.hip - C ABI of libhjbdp (include/hjbdp.h): problem upload, stage-kernel
+// dispatch, the backward sweep loop and the early-stop monitor.
+// gfx950 (MI355X) only; no CPU fallback - without a HIP device every compute
+// entry point returns HJB_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hjbdp.h"
+#include "hjbdp_dev.h"
+#include "kernels_generic.h"
+#include "kernels_reduce.h"
+
+using namespace hjb;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Handle {
+    hjb_problem prob{};  // scalar fields only (pointers are not kept)
+    int device = 0;
+    int dtype = HJB_F32;
+    size_t esz = 4;
+    int64_t n_owned = 0, nU = 0, j_elems = 0, inner = 0;
+    int nplanes = 0, plane0 = 0;
+    DParams hp{};                 // host copy of the device params
+    DParams *dp = nullptr;        // device params
+    std::vector<void *> allocs;   // every device allocation (freed in destroy)
+    int32_t *d_status = nullptr;
+    // work buffers (lazy)
+    void *dJ[2] = {nullptr, nullptr};
+    int32_t *d_idx = nullptr;
+    double *d_partials = nullptr;  // monitor reduction scratch
+    double *d_sums = nullptr;      // [2]: sum J, sum idx
+    int variant = 0;
+    int forced_variant = -1;
+    int block = 256, grid = 0;
+    int halo_need_lo = 0, halo_need_hi = 0;
+    std::string err;
+};
+
+int fail(Handle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, HJB_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+template <typename T>
+int upload(Handle *h, const std::vector<T> &v, void **out) {
+    void *d = nullptr;
+    HIP_TRY(h, hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    h->allocs.push_back(d);
+    if (!v.empty()) HIP_TRY(h, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return HJB_OK;
+}
+
+int dev_alloc(Handle *h, size_t bytes, void **out) {
+    void *d = nullptr;
+    HIP_TRY(h, hipMalloc(&d, std::max<size_t>(bytes, 16)));
+    h->allocs.push_back(d);
+    *out = d;
+    return HJB_OK;
+}
+
+int64_t term_elems(const hjb_problem *p, uint32_t mask) {
+    int64_t s = 1;
+    for (int d = 0; d < p->D + p->C; ++d)
+        if (mask & (1u << d)) s *= (d < p->D) ? p->n[d] : p->m[d - p->D];
+    return s;
+}
+
+// upload one term, fill strides
+template <typename T>
+int make_term(Handle *h, const hjb_problem *p, const hjb_term &t, DTerm *out) {
+    const int G = p->D + p->C;
+    int64_t s = 1;
+    for (int d = 0; d < HJB_MAX_G; ++d) out->stride[d] = 0;
+    for (int d = 0; d < G; ++d) {
+        if (t.mask & (1u << d)) {
+            out->stride[d] = (int32_t)s;
+            s *= (d < p->D) ? p->n[d] : p->m[d - p->D];
+        }
+    }
+    std::vector<T> host((const T *)t.data, (const T *)t.data + s);
+    void *d = nullptr;
+    int st = upload(h, host, &d);
+    if (st) return st;
+    out->data = d;
+    out->pad = 0;
+    return HJB_OK;
+}
+
+// conservative range of an ordered term sum for a fixed index along `dim`
+// (used for the halo the last axis needs)
+template <typename T>
+void term_minmax_along(const hjb_problem *p, const hjb_term &t, int dim, std::vector<double> &lo,
+                       std::vector<double> &hi) {
+    const int G = p->D + p->C;
+    const int nd = p->n[dim];
+    std::vector<double> tlo(nd, INFINITY), thi(nd, -INFINITY);
+    int64_t total = term_elems(p, t.mask);
+    int64_t stride_dim = 0, s = 1;
+    for (int d = 0; d < G; ++d) {
+        if (t.mask & (1u << d)) {
+            if (d == dim) stride_dim = s;
+            s *= (d < p->D) ? p->n[d] : p->m[d - p->D];
+        }
+    }
+    const T *data = (const T *)t.data;
+    if (!(t.mask & (1u << dim))) {
+        double mn = INFINITY, mx = -INFINITY;
+        for (int64_t i = 0; i < total; ++i) { mn = std::min(mn, (double)data[i]); mx = std::max(mx, (double)data[i]); }
+        for (int i = 0; i < nd; ++i) { tlo[i] = mn; thi[i] = mx; }
+    } else {
+        for (int64_t i = 0; i < total; ++i) {
+            int id = (int)((i / stride_dim) % nd);
+            tlo[id] = std::min(tlo[id], (double)data[i]);
+            thi[id] = std::max(thi[id], (double)data[i]);
+        }
+    }
+    for (int i = 0; i < nd; ++i) { lo[i] += tlo[i]; hi[i] += thi[i]; }
+}
+
+template <typename T>
+int build(Handle *h, const hjb_problem *p) {
+    const int D = p->D, C = p->C;
+    DParams &P = h->hp;
+    memset(&P, 0, sizeof P);
+    P.D = D;
+    P.C = C;
+    int sb = p->slab_begin, se = p->slab_end, hlo = p->halo_lo, hhi = p->halo_hi;
+    if (sb == 0 && se == 0) { se = p->n[D - 1]; hlo = hhi = 0; }
+    h->plane0 = sb - hlo;
+    h->nplanes = (se + hhi) - h->plane0;
+    int64_t s = 1, inner = 1;
+    for (int a = 0; a < D; ++a) {
+        P.n[a] = (a == D - 1) ? (se - sb) : p->n[a];
+        P.jstride[a] = s;
+        s *= (a == D - 1) ? h->nplanes : p->n[a];
+        if (a < D - 1) inner *= p->n[a];
+    }
+    h->j_elems = s;
+    h->inner = inner;
+    h->n_owned = inner * (se - sb);
+    h->nU = 1;
+    for (int c = 0; c < C; ++c) { P.m[c] = p->m[c]; h->nU *= p->m[c]; }
+    for (int c = C; c < HJB_MAX_C; ++c) P.m[c] = 1;
+    P.n_owned = h->n_owned;
+    P.nU = h->nU;
+    P.inner = inner;
+    P.plane0 = h->plane0;
+    P.nplanes = h->nplanes;
+    P.slab_begin = sb;
+    P.halo_lo = hlo;
+    P.index_base = p->index_base;
+
+    const uint32_t state_mask = (1u << D) - 1u;
+    for (int a = 0; a < D; ++a) {
+        DAxis &ax = P.axis[a];
+        const int n = p->n[a];
+        std::vector<T> kk(n), rdx(n);
+        for (int i = 0; i < n; ++i) kk[i] = (T)p->knots[a][i];
+        for (int i = 0; i + 1 < n; ++i) {
+            if (!(kk[i + 1] > kk[i]))
+                return fail(h, HJB_E_INVALID, "knots of axis %d are not strictly increasing in the working dtype at %d", a, i);
+            rdx[i] = (T)1 / (T)(kk[i + 1] - kk[i]);
+        }
+        rdx[n - 1] = (T)0;
+        void *dk = nullptr, *dr = nullptr;
+        int st = upload(h, kk, &dk);
+        if (st) return st;
+        st = upload(h, rdx, &dr);
+        if (st) return st;
+        ax.knots = dk;
+        ax.rdx = dr;
+        ax.n = n;
+        const double hstep = ((double)kk[n - 1] - (double)kk[0]) / (n - 1);
+        double dev = 0;
+        for (int i = 0; i < n; ++i) dev = std::max(dev, std::fabs((double)kk[i] - ((double)kk[0] + i * hstep)));
+        ax.uniform = dev <= 1.5 * hstep ? 1 : 0;
+        ax.x0 = (double)kk[0];
+        ax.inv_h = 1.0 / hstep;
+        ax.n_terms = p->n_next_terms[a];
+        int npre = 0;
+        while (npre < ax.n_terms && (p->next_terms[a][npre].mask & ~state_mask) == 0) ++npre;
+        ax.n_prefix = npre;
+        for (int k = 0; k < ax.n_terms; ++k) {
+            st = make_term<T>(h, p, p->next_terms[a][k], &ax.t[k]);
+            if (st) return st;
+        }
+    }
+    P.n_cost = p->n_cost_terms;
+    {
+        int npre = 0;
+        while (npre < P.n_cost && (p->cost_terms[npre].mask & ~state_mask) == 0) ++npre;
+        P.n_cost_prefix = npre;
+        for (int k = 0; k < P.n_cost; ++k) {
+            int st = make_term<T>(h, p, p->cost_terms[k], &P.cost[k]);
+            if (st) return st;
+        }
+    }
+    // conservative halo implied by the tables of the last axis
+    {
+        const int a = D - 1, n = p->n[a];
+        std::vector<double> lo(n, 0.0), hi(n, 0.0);
+        for (int k = 0; k < p->n_next_terms[a]; ++k) term_minmax_along<T>(p, p->next_terms[a][k], a, lo, hi);
+        std::vector<T> kk(n);
+        for (int i = 0; i < n; ++i) kk[i] = (T)p->knots[a][i];
+        auto cell_of = [&](double q) {
+            int c = (int)(std::upper_bound(kk.begin(), kk.end(), (T)q) - kk.begin()) - 1;
+            return std::min(std::max(c, 0), n - 2);
+        };
+        int need_lo = 0, need_hi = 0;
+        for (int i = 0; i < n; ++i) {
+            // small relative slack: the sum of per-term extrema is formed in double
+            double span = std::fabs(hi[i]) + std::fabs(lo[i]);
+            int clo = cell_of(lo[i] - 1e-6 * span), chi = cell_of(hi[i] + 1e-6 * span);
+            need_lo = std::max(need_lo, i - clo);
+            need_hi = std::max(need_hi, chi + 1 - i);
+        }
+        h->halo_need_lo = need_lo;
+        h->halo_need_hi = need_hi;
+    }
+    void *dst = nullptr;
+    int st = dev_alloc(h, sizeof(int32_t), &dst);
+    if (st) return st;
+    h->d_status = (int32_t *)dst;
+    HIP_TRY(h, hipMemset(h->d_status, 0, sizeof(int32_t)));
+    P.status = h->d_status;
+    void *dpp = nullptr;
+    st = dev_alloc(h, sizeof(DParams), &dpp);
+    if (st) return st;
+    h->dp = (DParams *)dpp;
+    HIP_TRY(h, hipMemcpy(h->dp, &P, sizeof(DParams), hipMemcpyHostToDevice));
+    return HJB_OK;
+}
+
+void choose_launch(Handle *h) {
+    h->variant = h->forced_variant >= 0 ? h->forced_variant : 0;
+    h->block = 256;
+    int64_t blocks = (h->n_owned + h->block - 1) / h->block;
+    h->grid = (int)std::min<int64_t>(blocks, 256 * 16);
+    if (h->grid < 1) h->grid = 1;
+}
+
+template <typename T>
+int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t st) {
+    const int D = h->hp.D;
+    dim3 g(h->grid), b(h->block);
+    switch (D) {
+        case 1: hipLaunchKernelGGL((k_backup_generic<T, 1>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 2: hipLaunchKernelGGL((k_backup_generic<T, 2>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 3: hipLaunchKernelGGL((k_backup_generic<T, 3>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 4: hipLaunchKernelGGL((k_backup_generic<T, 4>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 5: hipLaunchKernelGGL((k_backup_generic<T, 5>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 6: hipLaunchKernelGGL((k_backup_generic<T, 6>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return HJB_OK;
+}
+
+int launch_stage(Handle *h, const void *dJn, void *dJo, int32_t *didx, hipStream_t st) {
+    if (h->dtype == HJB_F32) return launch_stage_t<float>(h, (const float *)dJn, (float *)dJo, didx, st);
+    return launch_stage_t<double>(h, (const double *)dJn, (double *)dJo, didx, st);
+}
+
+int ensure_work(Handle *h) {
+    if (h->dJ[0]) return HJB_OK;
+    for (int i = 0; i < 2; ++i) {
+        int st = dev_alloc(h, (size_t)h->j_elems * h->esz, &h->dJ[i]);
+        if (st) return st;
+        HIP_TRY(h, hipMemset(h->dJ[i], 0, (size_t)h->j_elems * h->esz));
+    }
+    void *d = nullptr;
+    int st = dev_alloc(h, (size_t)h->n_owned * sizeof(int32_t), &d);
+    if (st) return st;
+    h->d_idx = (int32_t *)d;
+    st = dev_alloc(h, sizeof(double) * 2 * kReduceBlocks, &d);
+    if (st) return st;
+    h->d_partials = (double *)d;
+    st = dev_alloc(h, sizeof(double) * 2, &d);
+    if (st) return st;
+    h->d_sums = (double *)d;
+    return HJB_OK;
+}
+
+int check_status(Handle *h, hipStream_t st) {
+    int32_t flag = 0;
+    HIP_TRY(h, hipMemcpyAsync(&flag, h->d_status, sizeof flag, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if (flag) {
+        HIP_TRY(h, hipMemsetAsync(h->d_status, 0, sizeof(int32_t), st));
+        return fail(h, HJB_E_HALO, "a next-state query left the slab's halo (halo_lo=%d halo_hi=%d; tables imply lo=%d hi=%d)",
+                    h->hp.halo_lo, h->nplanes - h->hp.n[h->hp.D - 1] - h->hp.halo_lo, h->halo_need_lo, h->halo_need_hi);
+    }
+    return HJB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hjb_version(void) { return "hjbdp 0.1.0 (gfx950)"; }
+
+const char *hjb_status_string(int32_t s) {
+    switch (s) {
+        case HJB_OK: return "ok";
+        case HJB_E_INVALID: return "invalid argument";
+        case HJB_E_UNSUPPORTED: return "unsupported";
+        case HJB_E_DEVICE: return "device error";
+        case HJB_E_NOMEM: return "out of memory";
+        case HJB_E_HALO: return "query outside slab halo";
+        default: return "unknown status";
+    }
+}
+
+int32_t hjb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *hjb_last_error(hjb_handle hh) {
+    Handle *h = (Handle *)hh;
+    return h ? h->err.c_str() : g_last_error.c_str();
+}
+
+int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
+    if (!p || !out) return fail(nullptr, HJB_E_INVALID, "null argument");
+    *out = nullptr;
+    if (p->D < 1 || p->D > HJB_MAX_D) return fail(nullptr, HJB_E_UNSUPPORTED, "D=%d not in 1..%d", p->D, HJB_MAX_D);
+    if (p->C < 1 || p->C > HJB_MAX_C) return fail(nullptr, HJB_E_UNSUPPORTED, "C=%d not in 1..%d", p->C, HJB_MAX_C);
+    if (p->dtype != HJB_F32 && p->dtype != HJB_F64) return fail(nullptr, HJB_E_UNSUPPORTED, "dtype %d", p->dtype);
+    if (p->index_base != 0 && p->index_base != 1) return fail(nullptr, HJB_E_INVALID, "index_base must be 0 or 1");
+    const int G = p->D + p->C;
+    int64_t nS = 1, nU = 1;
+    for (int a = 0; a < p->D; ++a) {
+        if (p->n[a] < 2) return fail(nullptr, HJB_E_INVALID, "n[%d]=%d < 2", a, p->n[a]);
+        if (!p->knots[a]) return fail(nullptr, HJB_E_INVALID, "knots[%d] is null", a);
+        for (int i = 0; i + 1 < p->n[a]; ++i)
+            if (!(p->knots[a][i + 1] > p->knots[a][i]))
+                return fail(nullptr, HJB_E_INVALID, "knots[%d] not strictly increasing at %d", a, i);
+        if (p->n_next_terms[a] < 1 || p->n_next_terms[a] > HJB_MAX_TERMS)
+            return fail(nullptr, HJB_E_INVALID, "n_next_terms[%d]=%d", a, p->n_next_terms[a]);
+        for (int k = 0; k < p->n_next_terms[a]; ++k) {
+            const hjb_term &t = p->next_terms[a][k];
+            if (!t.data || (t.mask >> G)) return fail(nullptr, HJB_E_INVALID, "next term %d of axis %d: bad mask/data", k, a);
+        }
+        nS *= p->n[a];
+    }
+    for (int c = 0; c < p->C; ++c) {
+        if (p->m[c] < 1) return fail(nullptr, HJB_E_INVALID, "m[%d]=%d < 1", c, p->m[c]);
+        nU *= p->m[c];
+    }
+    if (nU >= (int64_t)1 << 31) return fail(nullptr, HJB_E_UNSUPPORTED, "too many controls");
+    if (p->n_cost_terms < 1 || p->n_cost_terms > HJB_MAX_TERMS) return fail(nullptr, HJB_E_INVALID, "n_cost_terms=%d", p->n_cost_terms);
+    for (int k = 0; k < p->n_cost_terms; ++k)
+        if (!p->cost_terms[k].data || (p->cost_terms[k].mask >> G)) return fail(nullptr, HJB_E_INVALID, "cost term %d: bad mask/data", k);
+    if (p->slab_begin || p->slab_end || p->halo_lo || p->halo_hi) {
+        const int nl = p->n[p->D - 1];
+        if (p->slab_begin < 0 || p->slab_end > nl || p->slab_begin >= p->slab_end || p->halo_lo < 0 || p->halo_hi < 0 ||
+            p->slab_begin - p->halo_lo < 0 || p->slab_end + p->halo_hi > nl)
+            return fail(nullptr, HJB_E_INVALID, "bad slab [%d,%d) halo %d/%d on axis of %d planes", p->slab_begin,
+                        p->slab_end, p->halo_lo, p->halo_hi, nl);
+        if ((p->slab_end + p->halo_hi) - (p->slab_begin - p->halo_lo) < 2)
+            return fail(nullptr, HJB_E_INVALID, "slab + halo must span at least 2 planes");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, HJB_E_DEVICE, "no HIP device visible (libhjbdp has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, HJB_E_INVALID, "device %d not in 0..%d", device, ndev - 1);
+    Handle *h = new Handle();
+    h->device = device;
+    h->dtype = p->dtype;
+    h->esz = p->dtype == HJB_F32 ? 4 : 8;
+    h->prob = *p;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        int st = fail(nullptr, HJB_E_DEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        delete h;
+        return st;
+    }
+    int st = p->dtype == HJB_F32 ? build<float>(h, p) : build<double>(h, p);
+    if (st) {
+        g_last_error = h->err;
+        for (void *d : h->allocs) (void)hipFree(d);
+        delete h;
+        return st;
+    }
+    // pointers in the kept copy must not be dereferenced later
+    for (int a = 0; a < HJB_MAX_D; ++a) {
+        h->prob.knots[a] = nullptr;
+        for (int k = 0; k < HJB_MAX_TERMS; ++k) h->prob.next_terms[a][k].data = nullptr;
+    }
+    for (int k = 0; k < HJB_MAX_TERMS; ++k) h->prob.cost_terms[k].data = nullptr;
+    choose_launch(h);
+    *out = (hjb_handle)h;
+    return HJB_OK;
+}
+
+int32_t hjb_destroy(hjb_handle hh) {
+    Handle *h = (Handle *)hh;
+    if (!h) return HJB_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (void *d : h->allocs) (void)hipFree(d);
+    delete h;
+    return HJB_OK;
+}
+
+int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
+    Handle *h = (Handle *)hh;
+    if (!h || !info) return fail(h, HJB_E_INVALID, "null argument");
+    info->n_states = h->n_owned;
+    info->n_controls = h->nU;
+    info->j_elems = h->j_elems;
+    info->kernel_variant = h->variant;
+    info->lds_bytes = 0;
+    info->block = h->block;
+    info->grid = h->grid;
+    info->halo_needed_lo = h->halo_need_lo;
+    info->halo_needed_hi = h->halo_need_hi;
+    return HJB_OK;
+}
+
+int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
+    Handle *h = (Handle *)hh;
+    if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
+    if (!strcmp(key, "variant")) {
+        if (value < -1 || value > 0) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        h->forced_variant = (int)value;
+        choose_launch(h);
+        return HJB_OK;
+    }
+    return fail(h, HJB_E_INVALID, "unknown option '%s'", key);
+}
+
+int32_t hjb_backup_stage_device(hjb_handle hh, const void *dJ_next, void *dJ_out, int32_t *d_idx_out, void *stream) {
+    Handle *h = (Handle *)hh;
+    if (!h || !dJ_next || !dJ_out) return fail(h, HJB_E_INVALID, "null argument");
+    if (dJ_next == dJ_out) return fail(h, HJB_E_INVALID, "J_next and J_out must not alias");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_stage(h, dJ_next, dJ_out, d_idx_out, (hipStream_t)stream);
+}
+
+int32_t hjb_check_device_status(hjb_handle hh, void *stream) {
+    Handle *h = (Handle *)hh;
+    if (!h) return fail(h, HJB_E_INVALID, "null handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return check_status(h, (hipStream_t)stream);
+}
+
+int32_t hjb_backup_stage(hjb_handle hh, const void *J_next, void *J_out, int32_t *idx_out) {
+    Handle *h = (Handle *)hh;
+    if (!h || !J_next || !J_out) return fail(h, HJB_E_INVALID, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int st = ensure_work(h);
+    if (st) return st;
+    const size_t jb = (size_t)h->j_elems * h->esz;
+    HIP_TRY(h, hipMemcpy(h->dJ[0], J_next, jb, hipMemcpyHostToDevice));
+    // keep halo planes of the output defined: start from the input
+    HIP_TRY(h, hipMemcpy(h->dJ[1], h->dJ[0], jb, hipMemcpyDeviceToDevice));
+    st = launch_stage(h, h->dJ[0], h->dJ[1], h->d_idx, nullptr);
+    if (st) return st;
+    st = check_status(h, nullptr);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpy(J_out, h->dJ[1], jb, hipMemcpyDeviceToHost));
+    if (idx_out) HIP_TRY(h, hipMemcpy(idx_out, h->d_idx, (size_t)h->n_owned * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return HJB_OK;
+}
+
+int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
+    Handle *h = (Handle *)hh;
+    if (!h || !o) return fail(h, HJB_E_INVALID, "null argument");
+    if (o->n_stages < 1) return fail(h, HJB_E_INVALID, "n_stages=%d", o->n_stages);
+    if (h->j_elems != h->n_owned)
+        return fail(h, HJB_E_UNSUPPORTED, "hjb_solve runs whole grids; drive slabs with hjb_backup_stage_device + a halo exchange");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int st = ensure_work(h);
+    if (st) return st;
+    const int64_t nS = h->n_owned;
+    const size_t jb = (size_t)nS * h->esz;
+    hipStream_t stream = nullptr;
+    // optional per-stage capture: kernels write straight into the stage planes
+    char *dJst = nullptr;
+    int32_t *dIst = nullptr;
+    if (o->J_stages) {
+        void *d = nullptr;
+        if (hipMalloc(&d, jb * o->n_stages) != hipSuccess) return fail(h, HJB_E_NOMEM, "cannot hold %d J stages on the device", o->n_stages);
+        dJst = (char *)d;
+        (void)hipMemset(dJst, 0, jb * o->n_stages);
+    }
+    if (o->idx_stages) {
+        void *d = nullptr;
+        if (hipMalloc(&d, (size_t)nS * 4 * o->n_stages) != hipSuccess) {
+            if (dJst) (void)hipFree(dJst);
+            return fail(h, HJB_E_NOMEM, "cannot hold %d idx stages on the device", o->n_stages);
+        }
+        dIst = (int32_t *)d;
+        (void)hipMemset(dIst, 0, (size_t)nS * 4 * o->n_stages);
+    }
+    auto cleanup = [&]() {
+        if (dJst) (void)hipFree(dJst);
+        if (dIst) (void)hipFree(dIst);
+    };
+#define SOLVE_TRY(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            cleanup();                                                                             \
+            return fail(h, HJB_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));           \
+        }                                                                                          \
+    } while (0)
+    if (o->terminal) SOLVE_TRY(hipMemcpy(h->dJ[0], o->terminal, jb, hipMemcpyHostToDevice));
+    else SOLVE_TRY(hipMemset(h->dJ[0], 0, jb));
+    hipEvent_t ev0, ev1;
+    SOLVE_TRY(hipEventCreate(&ev0));
+    SOLVE_TRY(hipEventCreate(&ev1));
+    SOLVE_TRY(hipEventRecord(ev0, stream));
+    const void *cur = h->dJ[0];
+    int pp = 1;  // next ping-pong target
+    int32_t *cur_idx = h->d_idx;
+    int done = 0, early = 0;
+    double fprev = 0, iprev = 0, e = 0, e2 = 0;
+    for (int k_s = o->n_stages; k_s >= 1; --k_s) {
+        void *outJ = dJst ? (void *)(dJst + (size_t)(k_s - 1) * jb) : h->dJ[pp];
+        int32_t *outI = dIst ? dIst + (size_t)(k_s - 1) * nS : h->d_idx;
+        st = launch_stage(h, cur, outJ, outI, stream);
+        if (st) { cleanup(); return st; }
+        cur = outJ;
+        cur_idx = outI;
+        if (!dJst) pp ^= 1;
+        ++done;
+        if (o->monitor_period > 0 && (k_s % o->monitor_period) == 0) {
+            // Solver_pos_att.m:273-285: fsum50 = sum(F.Values(:)), idsum50 = sum(U_Optimal_id(:))
+            st = launch_monitor_sums(h->dtype, cur, cur_idx, nS, h->d_partials, h->d_sums, stream);
+            if (st != HJB_OK) { cleanup(); return fail(h, HJB_E_DEVICE, "monitor reduction launch failed"); }
+            double sums[2];
+            SOLVE_TRY(hipMemcpyAsync(sums, h->d_sums, sizeof sums, hipMemcpyDeviceToHost, stream));
+            SOLVE_TRY(hipStreamSynchronize(stream));
+            e = sums[0] - fprev;
+            e2 = sums[1] - iprev;
+            fprev = sums[0];
+            iprev = sums[1];
+            if (o->progress) {
+                float ms = 0;
+                (void)hipEventRecord(ev1, stream);
+                (void)hipEventSynchronize(ev1);
+                (void)hipEventElapsedTime(&ms, ev0, ev1);
+                o->progress(o->progress_user, k_s, e, e2, ms * 1e-3);
+            }
+            if (std::fabs(e) < o->monitor_tol) { early = 1; break; }
+        }
+    }
+    SOLVE_TRY(hipEventRecord(ev1, stream));
+    SOLVE_TRY(hipEventSynchronize(ev1));
+    float ms = 0;
+    SOLVE_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    st = check_status(h, stream);
+    if (st) { cleanup(); return st; }
+    if (o->J_final) SOLVE_TRY(hipMemcpy(o->J_final, cur, jb, hipMemcpyDeviceToHost));
+    if (o->idx_final) SOLVE_TRY(hipMemcpy(o->idx_final, cur_idx, (size_t)nS * 4, hipMemcpyDeviceToHost));
+    if (o->J_stages) SOLVE_TRY(hipMemcpy(o->J_stages, dJst, jb * o->n_stages, hipMemcpyDeviceToHost));
+    if (o->idx_stages) SOLVE_TRY(hipMemcpy(o->idx_stages, dIst, (size_t)nS * 4 * o->n_stages, hipMemcpyDeviceToHost));
+    cleanup();
+    if (res) {
+        res->stages_done = done;
+        res->stopped_early = early;
+        res->sweep_ms = ms;
+        res->last_e = e;
+        res->last_e2 = e2;
+    }
+    return HJB_OK;
+#undef SOLVE_TRY
+}
+
+}  // extern "C"

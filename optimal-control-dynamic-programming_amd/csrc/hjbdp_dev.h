@@ -1,0 +1,50 @@
+// hjbdp_dev.h - device-side problem description shared by all stage kernels.
+// gfx950 only.  See DESIGN.md for the data layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hjbdp.h"
+
+namespace hjb {
+
+// one broadcast term on the device: element strides per grid dim (0 = broadcast)
+struct DTerm {
+    const void *data;
+    int32_t stride[HJB_MAX_G];
+    int32_t pad;
+};
+
+// a state axis: knots, reciprocal spacings, the ordered terms of x_next_a.
+// Terms [0, n_prefix) depend on state dims only and are summed once per state;
+// terms [n_prefix, n_terms) are evaluated per control (same left-to-right order).
+struct DAxis {
+    const void *knots;  // [n]   dtype
+    const void *rdx;    // [n]   dtype, rdx[i] = 1/(k[i+1]-k[i]), rdx[n-1] = 0
+    int32_t n;
+    int32_t uniform;    // knots are (numerically) uniform: arithmetic first guess
+    double x0, inv_h;   // first-guess map cell ~ (q - x0) * inv_h
+    int32_t n_terms, n_prefix;
+    DTerm t[HJB_MAX_TERMS];
+};
+
+struct DParams {
+    int32_t D, C;
+    int32_t n[HJB_MAX_D];     // n[D-1] = number of OWNED planes of the last axis
+    int32_t m[HJB_MAX_C];
+    int64_t n_owned;          // owned states
+    int64_t nU;
+    int64_t inner;            // states per plane of the last axis
+    int64_t jstride[HJB_MAX_D];
+    int32_t plane0;           // global plane index of local plane 0 of a J buffer
+    int32_t nplanes;          // planes in a J buffer (owned + halo)
+    int32_t slab_begin;       // first owned global plane
+    int32_t halo_lo;
+    int32_t index_base;
+    int32_t n_cost, n_cost_prefix;
+    int32_t pad0;
+    int32_t *status;          // device word, set to 1 when a query leaves the slab
+    DAxis axis[HJB_MAX_D];
+    DTerm cost[HJB_MAX_TERMS];
+};
+
+}  // namespace hjb

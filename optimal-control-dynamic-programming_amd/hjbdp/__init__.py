@@ -1,0 +1,17 @@
+"""hjbdp - host side of libhjbdp, the MI355X-native Bellman-backup path of
+abdolrezat/Optimal-Control-Dynamic-Programming.
+
+The classes keep the reference's names and methods so its scripts read the same:
+
+    from hjbdp import Dynamic_Solver
+    objA = Dynamic_Solver(); objA.run(); objA.get_optimal_path()
+
+All sweeps run in the HIP library (hjbdp/libhjbdp.so, C ABI in include/hjbdp.h);
+there is no CPU fallback.
+"""
+from . import _abi
+from .core import Backup, HjbError, device_count, load_library
+from .problem import ProblemSpec, Term
+from .dynamic_solver import Dynamic_Solver
+
+__all__ = ["Backup", "HjbError", "ProblemSpec", "Term", "Dynamic_Solver", "device_count", "load_library", "_abi"]

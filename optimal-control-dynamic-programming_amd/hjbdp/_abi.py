@@ -1,0 +1,116 @@
+"""ctypes mirror of include/hjbdp.h (the C ABI of libhjbdp).
+
+Field order and types must match the header exactly; tests/test_abi.py checks the
+struct sizes against the compiled library's view and that every declared symbol
+is exported.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+HJB_MAX_D = 6
+HJB_MAX_C = 3
+HJB_MAX_G = 9
+HJB_MAX_TERMS = 8
+
+HJB_OK = 0
+HJB_E_INVALID = 1
+HJB_E_UNSUPPORTED = 2
+HJB_E_DEVICE = 3
+HJB_E_NOMEM = 4
+HJB_E_HALO = 5
+
+HJB_F32 = 0
+HJB_F64 = 1
+
+
+class hjb_term(C.Structure):
+    _fields_ = [("mask", C.c_uint32), ("reserved", C.c_uint32), ("data", C.c_void_p)]
+
+
+class hjb_problem(C.Structure):
+    _fields_ = [
+        ("D", C.c_int32),
+        ("C", C.c_int32),
+        ("n", C.c_int32 * HJB_MAX_D),
+        ("m", C.c_int32 * HJB_MAX_C),
+        ("dtype", C.c_int32),
+        ("index_base", C.c_int32),
+        ("knots", C.POINTER(C.c_double) * HJB_MAX_D),
+        ("n_next_terms", C.c_int32 * HJB_MAX_D),
+        ("next_terms", (hjb_term * HJB_MAX_TERMS) * HJB_MAX_D),
+        ("n_cost_terms", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("cost_terms", hjb_term * HJB_MAX_TERMS),
+        ("slab_begin", C.c_int32),
+        ("slab_end", C.c_int32),
+        ("halo_lo", C.c_int32),
+        ("halo_hi", C.c_int32),
+    ]
+
+
+hjb_progress_fn = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double)
+
+
+class hjb_solve_opts(C.Structure):
+    _fields_ = [
+        ("n_stages", C.c_int32),
+        ("monitor_period", C.c_int32),
+        ("monitor_tol", C.c_double),
+        ("terminal", C.c_void_p),
+        ("J_final", C.c_void_p),
+        ("idx_final", C.c_void_p),
+        ("J_stages", C.c_void_p),
+        ("idx_stages", C.c_void_p),
+        ("progress", hjb_progress_fn),
+        ("progress_user", C.c_void_p),
+    ]
+
+
+class hjb_result(C.Structure):
+    _fields_ = [
+        ("stages_done", C.c_int32),
+        ("stopped_early", C.c_int32),
+        ("sweep_ms", C.c_double),
+        ("last_e", C.c_double),
+        ("last_e2", C.c_double),
+    ]
+
+
+class hjb_info(C.Structure):
+    _fields_ = [
+        ("n_states", C.c_int64),
+        ("n_controls", C.c_int64),
+        ("j_elems", C.c_int64),
+        ("kernel_variant", C.c_int32),
+        ("lds_bytes", C.c_int32),
+        ("block", C.c_int32),
+        ("grid", C.c_int32),
+        ("halo_needed_lo", C.c_int32),
+        ("halo_needed_hi", C.c_int32),
+    ]
+
+
+# every symbol include/hjbdp.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "hjb_version": (C.c_char_p, []),
+    "hjb_status_string": (C.c_char_p, [C.c_int32]),
+    "hjb_device_count": (C.c_int32, []),
+    "hjb_create": (C.c_int32, [C.POINTER(hjb_problem), C.c_int32, C.POINTER(C.c_void_p)]),
+    "hjb_destroy": (C.c_int32, [C.c_void_p]),
+    "hjb_last_error": (C.c_char_p, [C.c_void_p]),
+    "hjb_get_info": (C.c_int32, [C.c_void_p, C.POINTER(hjb_info)]),
+    "hjb_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "hjb_backup_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_backup_stage_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_check_device_status": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "hjb_solve": (C.c_int32, [C.c_void_p, C.POINTER(hjb_solve_opts), C.POINTER(hjb_result)]),
+}
+
+
+def bind(lib, symbols=SYMBOLS):
+    for name, (res, args) in symbols.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib

@@ -1,0 +1,160 @@
+"""Thin host binding of libhjbdp (include/hjbdp.h) - the only way the host
+classes reach the GPU.  There is NO CPU fallback: if the shared library is
+missing, or no HIP device is visible, every compute call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import _abi
+from .problem import ProblemSpec
+
+_LIB = None
+LIB_PATH = Path(__file__).resolve().parent / "libhjbdp.so"
+
+
+class HjbError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("libhjbdp: %s (status %d)" % (text, status))
+        self.status = status
+
+
+def load_library(path=None):
+    """Load libhjbdp.so (built in-tree by __graft_entry__.build()).  Loading needs
+    no GPU; raises if the file is missing - the product never falls back."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = Path(path) if path else Path(os.environ.get("HJBDP_LIB", LIB_PATH))
+    if not p.exists():
+        raise FileNotFoundError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). libhjbdp has no CPU fallback." % p)
+    lib = _abi.bind(C.CDLL(str(p)))
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def device_count():
+    return int(load_library().hjb_device_count())
+
+
+def _check(lib, handle, st):
+    if st != _abi.HJB_OK:
+        msg = lib.hjb_last_error(handle)
+        raise HjbError(st, (msg or b"").decode() or lib.hjb_status_string(st).decode())
+
+
+class Backup:
+    """A problem resident on one GPU.  Mirrors the C handle one to one."""
+
+    def __init__(self, spec: ProblemSpec, device=0, slab=None, variant=None):
+        self.lib = load_library()
+        self.spec = spec
+        self._cprob, self._keep = spec.to_c(slab)
+        self._h = C.c_void_p()
+        st = self.lib.hjb_create(C.byref(self._cprob), int(device), C.byref(self._h))
+        if st != _abi.HJB_OK:
+            self._h = C.c_void_p()
+            _check(self.lib, None, st)
+        self.device = int(device)
+        if variant is not None:
+            self.set_option("variant", variant)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.hjb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- queries ----------------------------------------------------------
+    def info(self):
+        inf = _abi.hjb_info()
+        _check(self.lib, self._h, self.lib.hjb_get_info(self._h, C.byref(inf)))
+        return {k: getattr(inf, k) for k, _ in inf._fields_}
+
+    def set_option(self, key, value):
+        _check(self.lib, self._h, self.lib.hjb_set_option(self._h, key.encode(), int(value)))
+
+    # -- one stage, host buffers -------------------------------------------
+    def backup_stage(self, J_next):
+        """[J_k, idx] = min(g + F(x_next), [], ctrl): J_next/J_k in the (haloed)
+        column-major J layout, idx int32 labels of the owned states."""
+        inf = self.info()
+        dt = self.spec.dtype
+        Jn = np.ascontiguousarray(np.asarray(J_next, dtype=dt).reshape(-1, order="F"))
+        if Jn.size != inf["j_elems"]:
+            raise ValueError("J_next has %d elements, the handle's J layout has %d" % (Jn.size, inf["j_elems"]))
+        Jo = np.empty_like(Jn)
+        idx = np.empty(inf["n_states"], dtype=np.int32)
+        st = self.lib.hjb_backup_stage(self._h, Jn.ctypes.data, Jo.ctypes.data, idx.ctypes.data)
+        _check(self.lib, self._h, st)
+        return Jo, idx
+
+    # -- one stage, device buffers (torch tensors or raw pointers) -----------
+    def backup_stage_device(self, dJ_next, dJ_out, d_idx=None, stream=0):
+        def ptr(x):
+            if x is None:
+                return None
+            return int(x.data_ptr()) if hasattr(x, "data_ptr") else int(x)
+        st = self.lib.hjb_backup_stage_device(self._h, ptr(dJ_next), ptr(dJ_out), ptr(d_idx), int(stream) or None)
+        _check(self.lib, self._h, st)
+
+    def check_device_status(self, stream=0):
+        _check(self.lib, self._h, self.lib.hjb_check_device_status(self._h, int(stream) or None))
+
+    # -- the whole sweep -----------------------------------------------------
+    def solve(self, n_stages, terminal=None, keep_J=False, keep_idx=False, monitor_period=0, monitor_tol=0.0,
+              progress=None):
+        """Backward sweep of n_stages backups.  Returns a dict with J (final), idx
+        (final), optional J_stages/idx_stages [nS, n_stages] with reference stage
+        k_s at column k_s-1, stages_done, stopped_early, sweep_ms."""
+        nS, dt = self.spec.nS, self.spec.dtype
+        o = _abi.hjb_solve_opts()
+        o.n_stages = int(n_stages)
+        o.monitor_period = int(monitor_period)
+        o.monitor_tol = float(monitor_tol)
+        keep = []
+        if terminal is not None:
+            t = np.ascontiguousarray(np.asarray(terminal, dtype=dt).reshape(-1, order="F"))
+            if t.size != nS:
+                raise ValueError("terminal cost must have nS elements")
+            keep.append(t)
+            o.terminal = t.ctypes.data
+        J = np.empty(nS, dtype=dt)
+        idx = np.empty(nS, dtype=np.int32)
+        o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
+        Js = Is = None
+        if keep_J:
+            Js = np.zeros((nS, n_stages), dtype=dt, order="F")
+            o.J_stages = Js.ctypes.data
+        if keep_idx:
+            Is = np.zeros((nS, n_stages), dtype=np.int32, order="F")
+            o.idx_stages = Is.ctypes.data
+        if progress is not None:
+            cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
+            keep.append(cb)
+            o.progress = cb
+        res = _abi.hjb_result()
+        st = self.lib.hjb_solve(self._h, C.byref(o), C.byref(res))
+        _check(self.lib, self._h, st)
+        return {"J": J, "idx": idx, "J_stages": Js, "idx_stages": Is, "stages_done": res.stages_done,
+                "stopped_early": bool(res.stopped_early), "sweep_ms": res.sweep_ms, "last_e": res.last_e,
+                "last_e2": res.last_e2}

@@ -1,0 +1,103 @@
+"""Problem description handed to libhjbdp: grid vectors + ordered broadcast terms.
+
+The reference builds its next-state and stage-cost tables by MATLAB implicit
+expansion of vectors reshaped onto dims 1..D (states) and D+1..D+C (controls)
+(attitude-control/Solver_attitude.m:717-742 `reshape_states`,
+pos-att/Solver_pos_att.m:307-314 and :791-801).  A `Term` is one such reshaped
+operand; a quantity is the left-to-right sum of its terms, which is how MATLAB
+evaluates `A(1)*X1 + A(3)*X2 + B(1)*U` (test/Dynamic_Solver.m:186) element by
+element - so nothing of size nS x nU is ever materialised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+class Term:
+    """`data` varies along the grid dims listed in `dims` (0-based, increasing:
+    state dims 0..D-1, then control dims D..D+C-1); data.shape follows dims."""
+
+    def __init__(self, dims, data):
+        self.dims = tuple(int(d) for d in dims)
+        if list(self.dims) != sorted(set(self.dims)):
+            raise ValueError("Term dims must be strictly increasing")
+        self.data = np.asarray(data)
+        if self.data.ndim != len(self.dims):
+            raise ValueError("Term data rank %d != number of dims %d" % (self.data.ndim, len(self.dims)))
+
+    @property
+    def mask(self):
+        m = 0
+        for d in self.dims:
+            m |= 1 << d
+        return m
+
+
+class ProblemSpec:
+    """knots[D] grid vectors (float64 values, rounded to `dtype` by the library -
+    pass `single(linspace(..))`-rounded values to mirror test/Dynamic_Solver.m:69),
+    m[C] control grid sizes, next_terms[D][*], cost_terms[*]."""
+
+    def __init__(self, knots, m, next_terms, cost_terms, dtype=np.float64, index_base=0):
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        self.knots = [np.ascontiguousarray(k, dtype=np.float64) for k in knots]
+        self.D = len(self.knots)
+        self.n = tuple(len(k) for k in self.knots)
+        self.m = tuple(int(x) for x in m)
+        self.C = len(self.m)
+        self.G = self.D + self.C
+        if not (1 <= self.D <= _abi.HJB_MAX_D):
+            raise ValueError("D=%d not in 1..%d" % (self.D, _abi.HJB_MAX_D))
+        if not (1 <= self.C <= _abi.HJB_MAX_C):
+            raise ValueError("C=%d not in 1..%d" % (self.C, _abi.HJB_MAX_C))
+        g = self.n + self.m
+        self.next_terms = [[self._check(t, g) for t in ts] for ts in next_terms]
+        self.cost_terms = [self._check(t, g) for t in cost_terms]
+        if len(self.next_terms) != self.D:
+            raise ValueError("need one term list per state axis")
+        for ts in self.next_terms + [self.cost_terms]:
+            if not (1 <= len(ts) <= _abi.HJB_MAX_TERMS):
+                raise ValueError("1..%d terms per quantity" % _abi.HJB_MAX_TERMS)
+        self.index_base = int(index_base)
+        self.nS = int(np.prod(self.n))
+        self.nU = int(np.prod(self.m))
+
+    def _check(self, t, g):
+        for ax, d in enumerate(t.dims):
+            if not (0 <= d < self.G) or t.data.shape[ax] != g[d]:
+                raise ValueError("term over dims %s has shape %s, grid is %s" % (t.dims, t.data.shape, g))
+        # column-major bytes in the working dtype
+        return Term(t.dims, np.asfortranarray(t.data, dtype=self.dtype))
+
+    def to_c(self, slab=None):
+        """-> (hjb_problem, keepalive list).  slab = (begin, end, halo_lo, halo_hi)."""
+        p = _abi.hjb_problem()
+        keep = []
+        p.D, p.C = self.D, self.C
+        for a in range(self.D):
+            p.n[a] = self.n[a]
+            p.knots[a] = self.knots[a].ctypes.data_as(C.POINTER(C.c_double))
+            p.n_next_terms[a] = len(self.next_terms[a])
+            for k, t in enumerate(self.next_terms[a]):
+                p.next_terms[a][k].mask = t.mask
+                p.next_terms[a][k].data = t.data.ctypes.data
+                keep.append(t.data)
+        for c in range(self.C):
+            p.m[c] = self.m[c]
+        p.dtype = _abi.HJB_F32 if self.dtype == np.float32 else _abi.HJB_F64
+        p.index_base = self.index_base
+        p.n_cost_terms = len(self.cost_terms)
+        for k, t in enumerate(self.cost_terms):
+            p.cost_terms[k].mask = t.mask
+            p.cost_terms[k].data = t.data.ctypes.data
+            keep.append(t.data)
+        if slab is not None:
+            p.slab_begin, p.slab_end, p.halo_lo, p.halo_hi = (int(x) for x in slab)
+        keep.append(self.knots)
+        return p, keep

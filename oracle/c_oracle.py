@@ -1,0 +1,88 @@
+"""ctypes wrapper of oracle/libhjb_oracle.so (the C twin, oracle/hjb_oracle.c).
+TEST INFRASTRUCTURE ONLY - imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package.
+
+It takes the same `hjb_problem` struct the HIP library takes (built by
+hjbdp.problem.ProblemSpec.to_c), so both sides see byte-identical tables.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+SO = HERE / "libhjb_oracle.so"
+_lib = None
+
+
+def build(force=False):
+    if force or not SO.exists() or SO.stat().st_mtime < (HERE / "hjb_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(HERE), "-B" if force else "-s"], check=True, capture_output=True)
+    return SO
+
+
+def lib(abi):
+    """abi = the hjbdp._abi module (struct definitions)."""
+    global _lib
+    if _lib is None:
+        if not SO.exists():
+            build()
+        l = C.CDLL(str(SO))
+        l.orc_backup_stage.restype = C.c_int
+        l.orc_backup_stage.argtypes = [C.POINTER(abi.hjb_problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        l.orc_sweep.restype = C.c_int
+        l.orc_sweep.argtypes = [C.POINTER(abi.hjb_problem), C.POINTER(abi.hjb_solve_opts), C.POINTER(abi.hjb_result), C.c_int]
+        l.orc_max_threads.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def backup_stage(abi, spec, J_next, slab=None, nthreads=0):
+    """One canonical-arithmetic backup on the CPU.  Returns (J_out flat, idx)."""
+    l = lib(abi)
+    p, keep = spec.to_c(slab)
+    Jn = np.ascontiguousarray(np.asarray(J_next, dtype=spec.dtype).reshape(-1, order="F"))
+    Jo = Jn.copy()
+    if slab is None:
+        n_owned = spec.nS
+    else:
+        n_owned = spec.nS // spec.n[-1] * (slab[1] - slab[0])
+    idx = np.empty(n_owned, dtype=np.int32)
+    nt = nthreads or l.orc_max_threads()
+    st = l.orc_backup_stage(C.byref(p), Jn.ctypes.data, Jo.ctypes.data, idx.ctypes.data, nt)
+    if st not in (0,):
+        raise RuntimeError("orc_backup_stage status %d" % st)
+    return Jo, idx
+
+
+def sweep(abi, spec, n_stages, terminal=None, keep_J=False, keep_idx=False, monitor_period=0, monitor_tol=0.0,
+          nthreads=0):
+    l = lib(abi)
+    p, keep = spec.to_c()
+    nS, dt = spec.nS, spec.dtype
+    o = abi.hjb_solve_opts()
+    o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
+    if terminal is not None:
+        t = np.ascontiguousarray(np.asarray(terminal, dtype=dt).reshape(-1, order="F"))
+        keep.append(t)
+        o.terminal = t.ctypes.data
+    J = np.empty(nS, dtype=dt)
+    idx = np.empty(nS, dtype=np.int32)
+    o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
+    Js = Is = None
+    if keep_J:
+        Js = np.zeros((nS, n_stages), dtype=dt, order="F")
+        o.J_stages = Js.ctypes.data
+    if keep_idx:
+        Is = np.zeros((nS, n_stages), dtype=np.int32, order="F")
+        o.idx_stages = Is.ctypes.data
+    res = abi.hjb_result()
+    nt = nthreads or l.orc_max_threads()
+    st = l.orc_sweep(C.byref(p), C.byref(o), C.byref(res), nt)
+    if st != 0:
+        raise RuntimeError("orc_sweep status %d" % st)
+    return {"J": J, "idx": idx, "J_stages": Js, "idx_stages": Is, "stages_done": res.stages_done,
+            "stopped_early": bool(res.stopped_early), "last_e": res.last_e, "last_e2": res.last_e2}

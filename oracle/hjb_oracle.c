@@ -1,0 +1,245 @@
+/* hjb_oracle.c - CPU restatement (plain C + OpenMP) of the reference's Bellman
+ * backup.  TEST INFRASTRUCTURE ONLY: it is the checker for the HIP path and the
+ * timed "cpu_baseline" of bench.py; the product (libhjbdp) never links or calls it.
+ *
+ * Follows, per stage,
+ *     [F.Values, idx] = min( J_stage + F(x_next_1,...,x_next_D), [], ctrl_dim )
+ *   test/Dynamic_Solver.m:207-210, test/test_coder.m:28-36,109-117,
+ *   position-control/Solver_position.m:135-137,
+ *   attitude-control/Solver_attitude.m:239-241,400-409,
+ *   pos-att/Solver_pos_att.m:272 (+ early-stop monitor :268-285)
+ * with F = griddedInterpolant(...,'linear') (N-linear, linear extrapolation) and
+ * `min` returning the first minimal index (cascade order for C > 1).
+ *
+ * Parity pin: oracle/hjb_oracle.py (same algorithm, numpy) reproduces
+ * test/obj_1.mat to 7.4e-14; tests/test_oracle_golden.py checks this C twin
+ * against the same fixture and against the numpy version.
+ *
+ * This twin fixes the floating-point evaluation order ("canonical arithmetic")
+ * so that the HIP kernels can be compared BIT-FOR-BIT:
+ *   q_a   = ((t0 + t1) + t2) ...                 plain adds, left to right
+ *   cell  = clamp(upper_bound(knots,q) - 1, 0, n-2)          exact search
+ *   t     = (q - k[cell]) * rdx[cell],  rdx = 1/(k[i+1]-k[i]) rounded to dtype
+ *   lerp  = fma(t, v1 - v0, v0), axis 0 first ... axis D-1 last
+ *   total = g + interp,  g = ((c0 + c1) + c2) ...
+ *   argmin: strict '<' while visiting controls with control dim 0 SLOWEST
+ *           (= cascade min over dims D+C-1, ..., D of Solver_attitude.m:400-409)
+ * Compile with -ffp-contract=off so only the explicit fma() contracts.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/hjbdp.h"
+
+typedef struct {
+    const void *data;
+    int64_t stride[HJB_MAX_G];
+    int has_ctrl;
+} term_t;
+
+static void build_term(const hjb_problem *p, const hjb_term *t, term_t *out) {
+    int G = p->D + p->C;
+    int64_t s = 1;
+    out->data = t->data;
+    out->has_ctrl = 0;
+    for (int d = 0; d < HJB_MAX_G; ++d) out->stride[d] = 0;
+    for (int d = 0; d < G; ++d) {
+        if (t->mask & (1u << d)) {
+            out->stride[d] = s;
+            s *= (d < p->D) ? p->n[d] : p->m[d - p->D];
+            if (d >= p->D) out->has_ctrl = 1;
+        }
+    }
+}
+
+static int validate(const hjb_problem *p) {
+    if (!p || p->D < 1 || p->D > HJB_MAX_D || p->C < 1 || p->C > HJB_MAX_C) return HJB_E_INVALID;
+    if (p->dtype != HJB_F32 && p->dtype != HJB_F64) return HJB_E_UNSUPPORTED;
+    for (int a = 0; a < p->D; ++a) {
+        if (p->n[a] < 2 || !p->knots[a]) return HJB_E_INVALID;
+        if (p->n_next_terms[a] < 1 || p->n_next_terms[a] > HJB_MAX_TERMS) return HJB_E_INVALID;
+    }
+    for (int c = 0; c < p->C; ++c)
+        if (p->m[c] < 1) return HJB_E_INVALID;
+    if (p->n_cost_terms < 1 || p->n_cost_terms > HJB_MAX_TERMS) return HJB_E_INVALID;
+    return HJB_OK;
+}
+
+#define DEFINE_BACKUP(T, NAME, FMA)                                                                   \
+    static int NAME(const hjb_problem *p, const T *Jn, T *Jout, int32_t *idx_out, int nthreads) {      \
+        const int D = p->D, C = p->C;                                                                  \
+        T *knots[HJB_MAX_D], *rdx[HJB_MAX_D];                                                          \
+        term_t nt[HJB_MAX_D][HJB_MAX_TERMS], ct[HJB_MAX_TERMS];                                        \
+        int64_t jstride[HJB_MAX_D];                                                                    \
+        for (int a = 0; a < D; ++a) {                                                                  \
+            int n = p->n[a];                                                                           \
+            knots[a] = (T *)malloc(sizeof(T) * n);                                                     \
+            rdx[a] = (T *)malloc(sizeof(T) * n);                                                       \
+            for (int i = 0; i < n; ++i) knots[a][i] = (T)p->knots[a][i];                               \
+            for (int i = 0; i + 1 < n; ++i) rdx[a][i] = (T)1 / (knots[a][i + 1] - knots[a][i]);        \
+            rdx[a][n - 1] = 0;                                                                         \
+            for (int k = 0; k < p->n_next_terms[a]; ++k) build_term(p, &p->next_terms[a][k], &nt[a][k]); \
+        }                                                                                              \
+        for (int k = 0; k < p->n_cost_terms; ++k) build_term(p, &p->cost_terms[k], &ct[k]);            \
+        /* slab geometry along the last axis */                                                        \
+        int sb = p->slab_begin, se = p->slab_end, hlo = p->halo_lo, hhi = p->halo_hi;                  \
+        if (sb == 0 && se == 0) { se = p->n[D - 1]; hlo = hhi = 0; }                                   \
+        const int plane0 = sb - hlo;                  /* global plane of local plane 0 */              \
+        const int nplanes = (se + hhi) - plane0;                                                       \
+        int64_t s = 1, inner = 1;                                                                      \
+        for (int a = 0; a < D; ++a) { jstride[a] = s; s *= (a == D - 1) ? nplanes : p->n[a]; }         \
+        for (int a = 0; a + 1 < D; ++a) inner *= p->n[a];                                              \
+        const int64_t n_owned = inner * (se - sb);                                                     \
+        int64_t nU = 1;                                                                                \
+        for (int c = 0; c < C; ++c) nU *= p->m[c];                                                     \
+        int err = 0;                                                                                   \
+        (void)nthreads;                                                                                \
+        _Pragma("omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)")         \
+        for (int64_t ls = 0; ls < n_owned; ++ls) {                                                     \
+            int gi[HJB_MAX_G];                                                                         \
+            int64_t r = ls;                                                                            \
+            for (int a = 0; a < D; ++a) {                                                              \
+                int na = (a == D - 1) ? (se - sb) : p->n[a];                                           \
+                gi[a] = (int)(r % na);                                                                 \
+                r /= na;                                                                               \
+            }                                                                                          \
+            gi[D - 1] += sb;                                                                           \
+            T best = 0;                                                                                \
+            int64_t best_label = 0;                                                                    \
+            int first = 1;                                                                             \
+            for (int c = 0; c < C; ++c) gi[D + c] = 0;                                                 \
+            for (int64_t u = 0; u < nU; ++u) {                                                         \
+                T v[1 << HJB_MAX_D];                                                                   \
+                T tw[HJB_MAX_D];                                                                       \
+                int64_t base = 0;                                                                      \
+                for (int a = 0; a < D; ++a) {                                                          \
+                    T q = 0;                                                                           \
+                    for (int k = 0; k < p->n_next_terms[a]; ++k) {                                     \
+                        int64_t off = 0;                                                               \
+                        for (int d = 0; d < D + C; ++d) off += nt[a][k].stride[d] * gi[d];             \
+                        T x = ((const T *)nt[a][k].data)[off];                                         \
+                        q = (k == 0) ? x : (T)(q + x);                                                 \
+                    }                                                                                  \
+                    const T *kk = knots[a];                                                            \
+                    int n = p->n[a];                                                                   \
+                    /* upper_bound(q) - 1, clamped to [0, n-2] */                                      \
+                    int lo = 0, hi = n - 1; /* invariant: answer in [lo, hi-1] */                      \
+                    while (hi - lo > 1) {                                                              \
+                        int mid = (lo + hi) >> 1;                                                      \
+                        if (kk[mid] <= q) lo = mid; else hi = mid;                                     \
+                    }                                                                                  \
+                    tw[a] = (T)((T)(q - kk[lo]) * rdx[a][lo]);                                         \
+                    int cell = lo;                                                                     \
+                    if (a == D - 1) {                                                                  \
+                        cell -= plane0;                                                                \
+                        if (cell < 0 || cell + 1 >= nplanes) {                                         \
+                            err = 1;                                                                   \
+                            cell = cell < 0 ? 0 : nplanes - 2;                                         \
+                        }                                                                              \
+                    }                                                                                  \
+                    base += jstride[a] * cell;                                                         \
+                }                                                                                      \
+                for (int c = 0; c < (1 << D); ++c) {                                                   \
+                    int64_t off = base;                                                                \
+                    for (int a = 0; a < D; ++a)                                                        \
+                        if (c & (1 << a)) off += jstride[a];                                           \
+                    v[c] = Jn[off];                                                                    \
+                }                                                                                      \
+                for (int a = 0; a < D; ++a) {                                                          \
+                    int half = 1 << (D - 1 - a);                                                       \
+                    for (int j = 0; j < half; ++j) v[j] = FMA(tw[a], (T)(v[2 * j + 1] - v[2 * j]), v[2 * j]); \
+                }                                                                                      \
+                T g = 0;                                                                               \
+                for (int k = 0; k < p->n_cost_terms; ++k) {                                            \
+                    int64_t off = 0;                                                                   \
+                    for (int d = 0; d < D + C; ++d) off += ct[k].stride[d] * gi[d];                    \
+                    T x = ((const T *)ct[k].data)[off];                                                \
+                    g = (k == 0) ? x : (T)(g + x);                                                     \
+                }                                                                                      \
+                T tot = (T)(g + v[0]);                                                                 \
+                if (first || tot < best) {                                                             \
+                    first = 0;                                                                         \
+                    best = tot;                                                                        \
+                    int64_t lab = 0, mul = 1;                                                          \
+                    for (int c = 0; c < C; ++c) { lab += mul * gi[D + c]; mul *= p->m[c]; }            \
+                    best_label = lab;                                                                  \
+                }                                                                                      \
+                /* next control: last control dim fastest (control dim 0 slowest) */                   \
+                for (int c = C - 1; c >= 0; --c) {                                                     \
+                    if (++gi[D + c] < p->m[c]) break;                                                  \
+                    gi[D + c] = 0;                                                                     \
+                }                                                                                      \
+            }                                                                                          \
+            /* owned state -> position in the haloed J layout */                                       \
+            int64_t in_plane = ls % inner, pl = ls / inner;                                            \
+            Jout[in_plane + inner * (pl + hlo)] = best;                                                \
+            if (idx_out) idx_out[ls] = (int32_t)(best_label + p->index_base);                          \
+        }                                                                                              \
+        for (int a = 0; a < D; ++a) { free(knots[a]); free(rdx[a]); }                                  \
+        return err ? HJB_E_HALO : HJB_OK;                                                              \
+    }
+
+DEFINE_BACKUP(float, backup_f32, fmaf)
+DEFINE_BACKUP(double, backup_f64, fma)
+
+/* one backup.  J buffers are in the haloed slab layout of hjb_problem (whole
+ * grid when the slab fields are zero); idx_out covers owned states only. */
+int orc_backup_stage(const hjb_problem *p, const void *J_next, void *J_out, int32_t *idx_out, int nthreads) {
+    int st = validate(p);
+    if (st) return st;
+    if (p->dtype == HJB_F32) return backup_f32(p, (const float *)J_next, (float *)J_out, idx_out, nthreads);
+    return backup_f64(p, (const double *)J_next, (double *)J_out, idx_out, nthreads);
+}
+
+/* whole-grid backward sweep with the same outputs as hjb_solve. */
+int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, int nthreads) {
+    int st = validate(p);
+    if (st) return st;
+    if (p->slab_begin || p->slab_end) return HJB_E_UNSUPPORTED;
+    int64_t nS = 1;
+    for (int a = 0; a < p->D; ++a) nS *= p->n[a];
+    size_t es = p->dtype == HJB_F32 ? 4 : 8;
+    char *A = (char *)calloc(nS, es), *B = (char *)calloc(nS, es);
+    int32_t *idx = (int32_t *)calloc(nS, sizeof(int32_t));
+    if (!A || !B || !idx) return HJB_E_NOMEM;
+    if (o->terminal) memcpy(A, o->terminal, nS * es);
+    double fprev = 0, iprev = 0;
+    int done = 0, early = 0;
+    double e = 0, e2 = 0;
+    for (int k_s = o->n_stages; k_s >= 1; --k_s) {
+        st = orc_backup_stage(p, A, B, idx, nthreads);
+        if (st) break;
+        char *t = A; A = B; B = t;
+        ++done;
+        if (o->J_stages) memcpy((char *)o->J_stages + (size_t)(k_s - 1) * nS * es, A, nS * es);
+        if (o->idx_stages) memcpy(o->idx_stages + (size_t)(k_s - 1) * nS, idx, nS * sizeof(int32_t));
+        if (o->monitor_period > 0 && (k_s % o->monitor_period) == 0) {
+            double fs = 0, is = 0;
+            for (int64_t i = 0; i < nS; ++i) {
+                fs += p->dtype == HJB_F32 ? (double)((float *)A)[i] : ((double *)A)[i];
+                is += (double)idx[i];
+            }
+            e = fs - fprev; e2 = is - iprev;
+            fprev = fs; iprev = is;
+            if (o->progress) o->progress(o->progress_user, k_s, e, e2, 0.0);
+            if (fabs(e) < o->monitor_tol) { early = 1; break; }
+        }
+    }
+    if (o->J_final) memcpy(o->J_final, A, nS * es);
+    if (o->idx_final) memcpy(o->idx_final, idx, nS * sizeof(int32_t));
+    if (res) { res->stages_done = done; res->stopped_early = early; res->sweep_ms = 0; res->last_e = e; res->last_e2 = e2; }
+    free(A); free(B); free(idx);
+    return st;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
