@@ -15,6 +15,7 @@
 #include "../../include/hjbdp.h"
 #include "hjbdp_dev.h"
 #include "kernels_generic.h"
+#include "kernels_nested.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -39,6 +40,10 @@ struct Handle {
     int32_t *d_idx = nullptr;
     double *d_partials = nullptr;  // monitor reduction scratch
     double *d_sums = nullptr;      // [2]: sum J, sum idx
+    DNested hn{};                 // variant 1 (control-nested) parameters
+    DNested *dn = nullptr;
+    bool nested_ok = false;
+    size_t nested_lds = 0;
     int variant = 0;
     int forced_variant = -1;
     int block = 256, grid = 0;
@@ -242,6 +247,58 @@ int build(Handle *h, const hjb_problem *p) {
         h->halo_need_lo = need_lo;
         h->halo_need_hi = need_hi;
     }
+    // ---- variant 1 (control-nested) eligibility --------------------------------
+    {
+        DNested &N = h->hn;
+        memset(&N, 0, sizeof N);
+        const uint32_t in_bit = 1u << (D + C - 1);
+        bool ok = true;
+        for (int a = 0; a < D - 1 && ok; ++a)
+            for (int k = 0; k < p->n_next_terms[a]; ++k)
+                if (p->next_terms[a][k].mask & in_bit) ok = false;
+        const DAxis &axl = P.axis[D - 1];
+        int ax_kin = axl.n_terms, cost_kin = P.n_cost;
+        for (int k = axl.n_terms - 1; k >= 0; --k)
+            if (p->next_terms[D - 1][k].mask & in_bit) ax_kin = k;
+        for (int k = P.n_cost - 1; k >= 0; --k)
+            if (p->cost_terms[k].mask & in_bit) cost_kin = k;
+        ax_kin = std::max(ax_kin, axl.n_prefix);       // prefix terms are summed per state anyway
+        cost_kin = std::max(cost_kin, P.n_cost_prefix);
+        N.m_in = p->m[C - 1];
+        N.nUo = (int32_t)(h->nU / p->m[C - 1]);
+        N.ax_kin = ax_kin;
+        N.cost_kin = cost_kin;
+        N.n_ax_in = axl.n_terms - ax_kin;
+        N.n_cost_in = P.n_cost - cost_kin;
+        if (N.n_ax_in > kMaxInAx || N.n_cost_in > kMaxInCost) ok = false;
+        int slots = 0;
+        for (int s = 0; s < kMaxInner; ++s) { N.in[s].data = nullptr; N.in[s].stride_in = 0; N.in[s].lds_slot = -1; }
+        if (ok) {
+            for (int s = 0; s < N.n_ax_in; ++s) {
+                const DTerm &t = axl.t[ax_kin + s];
+                N.in[s].data = t.data;
+                N.in[s].stride_in = t.stride[D + C - 1];
+                if (p->next_terms[D - 1][ax_kin + s].mask == in_bit) N.in[s].lds_slot = slots++;
+            }
+            for (int s = 0; s < N.n_cost_in; ++s) {
+                const DTerm &t = P.cost[cost_kin + s];
+                N.in[kMaxInAx + s].data = t.data;
+                N.in[kMaxInAx + s].stride_in = t.stride[D + C - 1];
+                if (p->cost_terms[cost_kin + s].mask == in_bit) N.in[kMaxInAx + s].lds_slot = slots++;
+            }
+        }
+        N.n_slots = slots;
+        h->nested_lds = ((size_t)2 * p->n[D - 1] + (size_t)slots * N.m_in) * sizeof(T);
+        if (h->nested_lds > 64 * 1024) ok = false;
+        h->nested_ok = ok;
+        if (ok) {
+            void *dnn = nullptr;
+            int st2 = dev_alloc(h, sizeof(DNested), &dnn);
+            if (st2) return st2;
+            h->dn = (DNested *)dnn;
+            HIP_TRY(h, hipMemcpy(h->dn, &N, sizeof(DNested), hipMemcpyHostToDevice));
+        }
+    }
     void *dst = nullptr;
     int st = dev_alloc(h, sizeof(int32_t), &dst);
     if (st) return st;
@@ -257,7 +314,7 @@ int build(Handle *h, const hjb_problem *p) {
 }
 
 void choose_launch(Handle *h) {
-    h->variant = h->forced_variant >= 0 ? h->forced_variant : 0;
+    h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->nested_ok ? 1 : 0);
     h->block = 256;
     int64_t blocks = (h->n_owned + h->block - 1) / h->block;
     h->grid = (int)std::min<int64_t>(blocks, 256 * 16);
@@ -268,6 +325,20 @@ template <typename T>
 int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t st) {
     const int D = h->hp.D;
     dim3 g(h->grid), b(h->block);
+    if (h->variant == 1) {
+        const size_t lds = h->nested_lds;
+        switch (D) {
+            case 1: hipLaunchKernelGGL((k_backup_nested<T, 1>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
+            case 2: hipLaunchKernelGGL((k_backup_nested<T, 2>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
+            case 3: hipLaunchKernelGGL((k_backup_nested<T, 3>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
+            case 4: hipLaunchKernelGGL((k_backup_nested<T, 4>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
+            case 5: hipLaunchKernelGGL((k_backup_nested<T, 5>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
+            case 6: hipLaunchKernelGGL((k_backup_nested<T, 6>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
+            default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return HJB_OK;
+    }
     switch (D) {
         case 1: hipLaunchKernelGGL((k_backup_generic<T, 1>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
         case 2: hipLaunchKernelGGL((k_backup_generic<T, 2>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
@@ -437,7 +508,7 @@ int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
     info->n_controls = h->nU;
     info->j_elems = h->j_elems;
     info->kernel_variant = h->variant;
-    info->lds_bytes = 0;
+    info->lds_bytes = h->variant == 1 ? (int32_t)h->nested_lds : 0;
     info->block = h->block;
     info->grid = h->grid;
     info->halo_needed_lo = h->halo_need_lo;
@@ -449,7 +520,9 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     Handle *h = (Handle *)hh;
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) {
-        if (value < -1 || value > 0) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value < -1 || value > 1) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value == 1 && !h->nested_ok)
+            return fail(h, HJB_E_UNSUPPORTED, "variant 1 (control-nested) needs: only the last state axis depends on the innermost control dim");
         h->forced_variant = (int)value;
         choose_launch(h);
         return HJB_OK;

@@ -23,6 +23,27 @@ class HjbError(RuntimeError):
         self.status = status
 
 
+def _share_torch_hip_runtime():
+    """If PyTorch-ROCm is installed, map ITS bundled libamdhip64 (same soname,
+    libamdhip64.so.7) before libhjbdp so the process has one HIP runtime: torch
+    tensors, torch streams and RCCL then share a context with our kernels.  With
+    ROCm's copy loaded first, a later `import torch` finds no GPU.  No torch
+    installed -> the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+        if cand.exists():
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def load_library(path=None):
     """Load libhjbdp.so (built in-tree by __graft_entry__.build()).  Loading needs
     no GPU; raises if the file is missing - the product never falls back."""
@@ -34,6 +55,7 @@ def load_library(path=None):
         raise FileNotFoundError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). libhjbdp has no CPU fallback." % p)
+    _share_torch_hip_runtime()
     lib = _abi.bind(C.CDLL(str(p)))
     if path is None:
         _LIB = lib

@@ -55,3 +55,40 @@ def random_problem(seed, n, m, dtype=np.float64, nonuniform=False, spread=0.35, 
 def random_terminal(spec, seed=0):
     rng = np.random.default_rng(seed)
     return rng.random(spec.nS).astype(spec.dtype)
+
+
+def nested_problem(seed, n, m, dtype=np.float32, nonuniform=False, spread=0.2, mixed_inner=False):
+    """Structure of the spacecraft solvers: control dim c drives state axis
+    D-C+c only (the innermost control dim drives the LAST axis); every axis also
+    couples to other state dims.  mixed_inner adds an inner term that also
+    depends on a state dim (a 'general' inner term for the nested kernel)."""
+    rng = np.random.default_rng(seed)
+    D, C = len(n), len(m)
+    g = tuple(n) + tuple(m)
+    knots = []
+    for a in range(D):
+        if nonuniform:
+            k = np.cumsum(rng.uniform(0.5, 1.5, n[a]))
+            k = (k - k[0]) / (k[-1] - k[0]) * 2.0 - 1.0
+        else:
+            k = np.linspace(-1.0, 1.0, n[a])
+        knots.append(k.astype(dtype).astype(np.float64))
+    nxt = []
+    for a in range(D):
+        terms = [Term((a,), knots[a].copy())]
+        others = [d for d in range(D) if d != a]
+        if others:
+            pick = sorted(rng.choice(others, size=min(len(others), 2), replace=False).tolist())
+            terms.append(Term(pick, spread * 0.5 * rng.standard_normal(tuple(g[d] for d in pick))))
+        c = a - (D - C)
+        if c >= 0:
+            if mixed_inner and others:
+                d = int(others[0])
+                dims = tuple(sorted((d, D + c)))
+                terms.append(Term(dims, spread * rng.standard_normal(tuple(g[x] for x in dims))))
+            terms.append(Term((D + c,), spread * rng.standard_normal(g[D + c])))
+        nxt.append(terms)
+    cost = [Term((a,), (1.0 + a) * knots[a] ** 2) for a in range(D)]
+    for c in range(C):
+        cost.append(Term((D + c,), 0.3 * rng.standard_normal(m[c]) ** 2))
+    return ProblemSpec(knots, m, nxt, cost[:8], dtype=dtype, index_base=1)

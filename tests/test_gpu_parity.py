@@ -81,13 +81,14 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [None, 0])
 @pytest.mark.parametrize("n,m,dtype,nonuniform", SHAPES)
-def test_random_problems_bit_exact(env, n, m, dtype, nonuniform):
+def test_random_problems_bit_exact(env, n, m, dtype, nonuniform, variant):
     hjbdp, _abi, c_oracle = env
     from problems import random_problem, random_terminal
     spec = random_problem(1234 + len(n) * 10 + len(m), n, m, dtype=dtype, nonuniform=nonuniform, index_base=1)
     term = random_terminal(spec, 7)
-    with hjbdp.Backup(spec) as bk:
+    with hjbdp.Backup(spec, variant=variant) as bk:
         out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
         J1, i1 = bk.backup_stage(term)
     ref = c_oracle.sweep(_abi, spec, 3, terminal=term, keep_J=True, keep_idx=True)
@@ -97,6 +98,60 @@ def test_random_problems_bit_exact(env, n, m, dtype, nonuniform):
     # single-stage entry point = first computed stage (k_s = 3 -> column 2)
     assert np.array_equal(J1, ref["J_stages"][:, 2]) and np.array_equal(i1, ref["idx_stages"][:, 2])
     assert out["idx"].min() >= 1 and out["idx"].max() <= spec.nU
+
+
+NESTED = [
+    ((9, 8), (3,), np.float64, False, False),              # Solver_position / attitude-simplified shape
+    ((13, 11), (7,), np.float32, True, True),
+    ((9, 8, 7), (5, 4, 3), np.float32, False, False),      # C2 shape
+    ((9, 8, 7), (4, 5), np.float64, True, True),
+    ((6, 5, 4, 5), (3, 4), np.float32, False, False),
+    ((4, 3, 4, 3, 3, 5), (3, 3, 3), np.float32, False, False),  # C3 shape
+    ((4, 3, 4, 3, 3, 5), (2, 3, 2), np.float64, True, True),
+]
+
+
+@pytest.mark.parametrize("n,m,dtype,nonuniform,mixed", NESTED)
+def test_nested_variant_bit_exact(env, n, m, dtype, nonuniform, mixed):
+    """Variant 1 (control-nested) must be selected for spacecraft-shaped problems
+    and agree bit for bit with the oracle and with the generic kernel."""
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    spec = nested_problem(4321 + len(n), n, m, dtype=dtype, nonuniform=nonuniform, mixed_inner=mixed)
+    term = random_terminal(spec, 9)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 1
+        out = bk.solve(4, terminal=term, keep_J=True, keep_idx=True)
+    with hjbdp.Backup(spec, variant=0) as bk:
+        assert bk.info()["kernel_variant"] == 0
+        out0 = bk.solve(4, terminal=term, keep_J=True, keep_idx=True)
+    ref = c_oracle.sweep(_abi, spec, 4, terminal=term, keep_J=True, keep_idx=True)
+    for o in (out, out0):
+        assert np.array_equal(o["J_stages"], ref["J_stages"])
+        assert np.array_equal(o["idx_stages"], ref["idx_stages"])
+
+
+def test_c2_workload_small_bit_exact(env):
+    """BASELINE configs[1] (Solver_position 3-DOF) at a size the oracle finishes in seconds."""
+    hjbdp, _abi, c_oracle = env
+    from hjbdp.synthetic import position3d_spec
+    spec = position3d_spec(n=15, mu=7)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 1
+        out = bk.solve(6, keep_J=True, keep_idx=True)
+    ref = c_oracle.sweep(_abi, spec, 6, keep_J=True, keep_idx=True)
+    assert np.array_equal(out["J_stages"], ref["J_stages"])
+    assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+
+
+def test_variant_1_refused_when_not_applicable(env):
+    hjbdp, _abi, c_oracle = env
+    spec = _kirk(hjbdp, "double", 5, 8, 9).build_spec()   # both axes depend on u
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 0
+        with pytest.raises(hjbdp.HjbError) as ei:
+            bk.set_option("variant", 1)
+        assert ei.value.status == _abi.HJB_E_UNSUPPORTED
 
 
 def test_exact_ties_first_index_wins(env):
