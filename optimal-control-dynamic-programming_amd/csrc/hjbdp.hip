@@ -43,6 +43,7 @@ struct Handle {
     DNested hn{};                 // variant 1 (control-nested) parameters
     DNested *dn = nullptr;
     bool nested_ok = false;
+    bool nested_fast = false;
     size_t nested_lds = 0;
     int variant = 0;
     int forced_variant = -1;
@@ -278,17 +279,19 @@ int build(Handle *h, const hjb_problem *p) {
                 const DTerm &t = axl.t[ax_kin + s];
                 N.in[s].data = t.data;
                 N.in[s].stride_in = t.stride[D + C - 1];
-                if (p->next_terms[D - 1][ax_kin + s].mask == in_bit) N.in[s].lds_slot = slots++;
+                if (p->next_terms[D - 1][ax_kin + s].mask == in_bit) { N.in[s].lds_slot = s; ++slots; }
             }
             for (int s = 0; s < N.n_cost_in; ++s) {
                 const DTerm &t = P.cost[cost_kin + s];
                 N.in[kMaxInAx + s].data = t.data;
                 N.in[kMaxInAx + s].stride_in = t.stride[D + C - 1];
-                if (p->cost_terms[cost_kin + s].mask == in_bit) N.in[kMaxInAx + s].lds_slot = slots++;
+                if (p->cost_terms[cost_kin + s].mask == in_bit) { N.in[kMaxInAx + s].lds_slot = kMaxInAx + s; ++slots; }
             }
         }
         N.n_slots = slots;
-        h->nested_lds = ((size_t)2 * p->n[D - 1] + (size_t)slots * N.m_in) * sizeof(T);
+        h->nested_lds = ((size_t)2 * p->n[D - 1] + (size_t)kMaxInner * (N.m_in + 1)) * sizeof(T);
+        h->nested_fast = ok && N.n_ax_in == 1 && N.n_cost_in == 1 && N.in[0].lds_slot >= 0 &&
+                         N.in[kMaxInAx].lds_slot >= 0 && ax_kin > 0 && cost_kin > 0;
         if (h->nested_lds > 64 * 1024) ok = false;
         h->nested_ok = ok;
         if (ok) {
@@ -328,12 +331,24 @@ int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t s
     if (h->variant == 1) {
         const size_t lds = h->nested_lds;
         switch (D) {
-            case 1: hipLaunchKernelGGL((k_backup_nested<T, 1>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
-            case 2: hipLaunchKernelGGL((k_backup_nested<T, 2>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
-            case 3: hipLaunchKernelGGL((k_backup_nested<T, 3>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
-            case 4: hipLaunchKernelGGL((k_backup_nested<T, 4>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
-            case 5: hipLaunchKernelGGL((k_backup_nested<T, 5>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
-            case 6: hipLaunchKernelGGL((k_backup_nested<T, 6>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); break;
+            case 1: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 1, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    else hipLaunchKernelGGL((k_backup_nested<T, 1, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    break;
+            case 2: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 2, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    else hipLaunchKernelGGL((k_backup_nested<T, 2, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    break;
+            case 3: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 3, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    else hipLaunchKernelGGL((k_backup_nested<T, 3, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    break;
+            case 4: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 4, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    else hipLaunchKernelGGL((k_backup_nested<T, 4, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    break;
+            case 5: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 5, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    else hipLaunchKernelGGL((k_backup_nested<T, 5, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    break;
+            case 6: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 6, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    else hipLaunchKernelGGL((k_backup_nested<T, 6, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
+                    break;
             default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
         }
         HIP_TRY(h, hipGetLastError());
@@ -438,6 +453,7 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
         for (int k = 0; k < p->n_next_terms[a]; ++k) {
             const hjb_term &t = p->next_terms[a][k];
             if (!t.data || (t.mask >> G)) return fail(nullptr, HJB_E_INVALID, "next term %d of axis %d: bad mask/data", k, a);
+            if (term_elems(p, t.mask) >= ((int64_t)1 << 31)) return fail(nullptr, HJB_E_UNSUPPORTED, "next term %d of axis %d has >= 2^31 elements", k, a);
         }
         nS *= p->n[a];
     }
@@ -449,6 +465,8 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
     if (p->n_cost_terms < 1 || p->n_cost_terms > HJB_MAX_TERMS) return fail(nullptr, HJB_E_INVALID, "n_cost_terms=%d", p->n_cost_terms);
     for (int k = 0; k < p->n_cost_terms; ++k)
         if (!p->cost_terms[k].data || (p->cost_terms[k].mask >> G)) return fail(nullptr, HJB_E_INVALID, "cost term %d: bad mask/data", k);
+    for (int k = 0; k < p->n_cost_terms; ++k)
+        if (term_elems(p, p->cost_terms[k].mask) >= ((int64_t)1 << 31)) return fail(nullptr, HJB_E_UNSUPPORTED, "cost term %d has >= 2^31 elements", k);
     if (p->slab_begin || p->slab_end || p->halo_lo || p->halo_hi) {
         const int nl = p->n[p->D - 1];
         if (p->slab_begin < 0 || p->slab_end > nl || p->slab_begin >= p->slab_end || p->halo_lo < 0 || p->halo_hi < 0 ||

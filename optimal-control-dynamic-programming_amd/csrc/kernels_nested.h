@@ -1,4 +1,4 @@
-// kernels_nested.h - variant 1: control-nested stage kernel.
+// kernels_nested.h - variant 1: control-nested stage kernel with cell tracking.
 //
 // Applies when only the LAST state axis depends on the innermost control dim
 // (every spacecraft solver of the reference: Solver_position.m:152-186 v+ = v +
@@ -7,22 +7,25 @@
 //   * everything that does not depend on the innermost control dim - the cells
 //     and weights of axes 0..D-2, the partial cost sum - is computed once per
 //     OUTER control step instead of once per control;
+//   * every axis TRACKS its current cell: the cell's bounds [lo,hi), knot and
+//     reciprocal spacing live in registers, so a query that stays inside its cell
+//     costs two compares; the exact search runs only on a boundary crossing;
 //   * the 2^D-corner gather + the lerps of axes 0..D-2 collapse into a cached
-//     pair (E0, dE) tagged with the last-axis cell; the inner loop is one fma
-//     per control unless the query crosses a cell boundary;
+//     pair (E0, dE) per last-axis cell: the inner loop is
+//         q = qo + b[j]; t = (q-kc)*rc; val = fma(t,dE,E0); tot = (go+r[j]) + val
+//     plus the strict-< min update;
 //   * the last axis' knots / reciprocal spacings and the control-only inner
-//     tables (b*u, r*u^2) are staged in LDS once per workgroup.
-// Per control: 1 LDS table read + cell search on LDS knots + fma + 2 adds +
-// compare/select, instead of D searches + 2^D global loads + (2^D-1) lerps.
+//     tables (b*u, r*u^2), interleaved per control, are staged in LDS once per
+//     workgroup (one ds_read_b128 per control brings every inner table value).
 #pragma once
 #include "hjbdp_dev.h"
 #include "kernels_generic.h"
 
 namespace hjb {
 
-constexpr int kMaxInAx = 2;    // inner terms of the last axis kept in registers
-constexpr int kMaxInCost = 3;  // inner terms of the cost
-constexpr int kMaxInner = kMaxInAx + kMaxInCost;
+constexpr int kMaxInAx = 2;    // inner terms of the last axis
+constexpr int kMaxInCost = 2;  // inner terms of the cost
+constexpr int kMaxInner = kMaxInAx + kMaxInCost;  // = LDS slots per control (one 16-B row for f32)
 
 struct DInnerTerm {
     const void *data;     // global table
@@ -40,12 +43,52 @@ struct DNested {
     DInnerTerm in[kMaxInner];  // [0,n_ax_in): last-axis terms, [kMaxInAx, kMaxInAx+n_cost_in): cost
 };
 
+// per-axis tracked cell
 template <typename T>
-__device__ __forceinline__ int find_cell_lds(const T *k, int n, T q, int uniform, T x0, T inv_h) {
-    return find_cell<T>(k, n, q, uniform, x0, inv_h);
+struct CellTrack {
+    T lo, hi;   // q in [lo, hi) <=> same cell (lo = -inf for cell 0, hi = +inf for cell n-2)
+    T kc, rc;   // knot and reciprocal spacing of the cell
+    int cell;
+};
+
+template <typename T>
+__device__ __forceinline__ void track_reset(CellTrack<T> &c) {
+    c.lo = (T)INFINITY;
+    c.hi = -(T)INFINITY;
+    c.kc = (T)0;
+    c.rc = (T)0;
+    c.cell = 0;
+}
+
+// exact: returns true when the cell changed (or on first use)
+template <typename T>
+__device__ __forceinline__ bool track_update(CellTrack<T> &c, const T *k, const T *r, int n, T q, int uniform, T x0,
+                                             T inv_h) {
+    if (q >= c.lo && q < c.hi) return false;
+    const int i = find_cell<T>(k, n, q, uniform, x0, inv_h);
+    c.cell = i;
+    c.kc = k[i];
+    c.rc = r[i];
+    c.lo = (i == 0) ? -(T)INFINITY : c.kc;
+    c.hi = (i == n - 2) ? (T)INFINITY : k[i + 1];
+    return true;
 }
 
 template <typename T, int D>
+__device__ __forceinline__ int term_offset(const DTerm &t, const int (&si)[D], const int (&cj)[HJB_MAX_C]) {
+    int off = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) off += t.stride[a] * si[a];
+#pragma unroll
+    for (int c = 0; c < HJB_MAX_C; ++c) off += t.stride[D + c] * cj[c];
+    return off;
+}
+
+// FAST = the canonical spacecraft shape: exactly one control-only inner term for
+// the last axis and one for the cost, each preceded by at least one other term
+// (x+ = [state part] + b*u_in, g = [state/outer part] + r*u_in^2).  All the
+// runtime structure flags fold away and the inner loop is ~11 VALU per control.
+template <typename T, int D, bool FAST>
 __global__ void __launch_bounds__(256)
 k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, const T *__restrict__ Jn,
                 T *__restrict__ Jout, int32_t *__restrict__ idx_out) {
@@ -53,9 +96,10 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
     const DAxis &axl = P->axis[D - 1];
     const int nl = axl.n;
     const int m_in = N->m_in;
-    T *s_k = reinterpret_cast<T *>(smem_raw);
+    // LDS: [m_in][kMaxInner] interleaved inner tables (16-B aligned rows), then knots, rdx of the last axis
+    T *s_tab = reinterpret_cast<T *>(smem_raw);
+    T *s_k = s_tab + (size_t)(m_in + 1) * kMaxInner;  // one padding row (prefetch)
     T *s_r = s_k + nl;
-    T *s_tab = s_r + nl;
     for (int i = threadIdx.x; i < nl; i += blockDim.x) {
         s_k[i] = static_cast<const T *>(axl.knots)[i];
         s_r[i] = static_cast<const T *>(axl.rdx)[i];
@@ -63,9 +107,9 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
 #pragma unroll
     for (int s = 0; s < kMaxInner; ++s) {
         const DInnerTerm &it = N->in[s];
-        if (it.lds_slot >= 0)
-            for (int i = threadIdx.x; i < m_in; i += blockDim.x)
-                s_tab[it.lds_slot * m_in + i] = static_cast<const T *>(it.data)[(int64_t)i * it.stride_in];
+        for (int i = threadIdx.x; i <= m_in; i += blockDim.x)
+            s_tab[i * kMaxInner + s] =
+                (it.lds_slot >= 0 && i < m_in) ? static_cast<const T *>(it.data)[(int64_t)i * it.stride_in] : (T)0;
     }
     __syncthreads();
 
@@ -73,10 +117,23 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
     const int64_t n_owned = P->n_owned;
     const int nUo = N->nUo;
     const int n_ax_in = N->n_ax_in, n_cost_in = N->n_cost_in;
+    const int ax_kin = N->ax_kin, cost_kin = N->cost_kin;
     const int l_uniform = axl.uniform;
     const T l_x0 = (T)axl.x0, l_invh = (T)axl.inv_h;
     const int plane0 = P->plane0, nplanes = P->nplanes;
     const int64_t js_last = P->jstride[D - 1];
+    // which inner slots are general (need a per-lane global load)?
+    bool gen[kMaxInner];
+    const T *gdata[kMaxInner];
+    int gstride[kMaxInner];
+#pragma unroll
+    for (int s = 0; s < kMaxInner; ++s) {
+        const bool used = (s < kMaxInAx) ? (s < n_ax_in) : (s - kMaxInAx < n_cost_in);
+        gen[s] = used && N->in[s].lds_slot < 0;
+        gdata[s] = static_cast<const T *>(N->in[s].data);
+        gstride[s] = N->in[s].stride_in;
+    }
+    const bool any_gen = gen[0] || gen[1] || gen[2] || gen[3];
 
     for (int64_t ls = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ls < n_owned;
          ls += (int64_t)gridDim.x * blockDim.x) {
@@ -108,9 +165,13 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
             T x = term_value<T, D>(P->cost[k], si, cj);
             gpre = (k == 0) ? x : (T)(gpre + x);
         }
+        CellTrack<T> trk[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) track_reset(trk[a]);
+        int lc = 0;  // local plane of the tracked last-axis cell
 
         T best = (T)0;
-        int64_t best_u = 0;
+        int best_uo = 0, best_j = 0;
         for (int uo = 0; uo < nUo; ++uo) {
             // ---- once per outer control step -------------------------------
             T tw[D > 1 ? D - 1 : 1];
@@ -123,109 +184,138 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                     T x = term_value<T, D>(ax.t[k], si, cj);
                     q = (k == 0) ? x : (T)(q + x);
                 }
-                const T *kk = static_cast<const T *>(ax.knots);
-                int cell = find_cell<T>(kk, ax.n, q, ax.uniform, (T)ax.x0, (T)ax.inv_h);
-                tw[a] = (T)((T)(q - kk[cell]) * static_cast<const T *>(ax.rdx)[cell]);
-                base += P->jstride[a] * cell;
+                track_update<T>(trk[a], static_cast<const T *>(ax.knots), static_cast<const T *>(ax.rdx), ax.n, q,
+                                ax.uniform, (T)ax.x0, (T)ax.inv_h);
+                tw[a] = (T)((T)(q - trk[a].kc) * trk[a].rc);
+                base += P->jstride[a] * trk[a].cell;
             }
             T qo = qpre[D - 1];
-            for (int k = axl.n_prefix; k < N->ax_kin; ++k) {
+            for (int k = axl.n_prefix; k < ax_kin; ++k) {
                 T x = term_value<T, D>(axl.t[k], si, cj);
                 qo = (k == 0) ? x : (T)(qo + x);
             }
             T go = gpre;
-            for (int k = P->n_cost_prefix; k < N->cost_kin; ++k) {
+            for (int k = P->n_cost_prefix; k < cost_kin; ++k) {
                 T x = term_value<T, D>(P->cost[k], si, cj);
                 go = (k == 0) ? x : (T)(go + x);
             }
-            // base offsets of the general (non control-only) inner terms
-            int64_t ib[kMaxInner];
+            int ib[kMaxInner] = {0, 0, 0, 0};
+            if (any_gen) {
 #pragma unroll
-            for (int s = 0; s < kMaxInAx; ++s) {
-                ib[s] = 0;
-                if (s < n_ax_in && N->in[s].lds_slot < 0) {
-                    const DTerm &t = axl.t[N->ax_kin + s];
-                    int64_t off = 0;
-#pragma unroll
-                    for (int a = 0; a < D; ++a) off += (int64_t)t.stride[a] * si[a];
-#pragma unroll
-                    for (int c = 0; c < HJB_MAX_C; ++c) off += (int64_t)t.stride[D + c] * cj[c];
-                    ib[s] = off;
-                }
+                for (int s = 0; s < kMaxInner; ++s)
+                    if (gen[s])
+                        ib[s] = term_offset<T, D>(s < kMaxInAx ? axl.t[ax_kin + s] : P->cost[cost_kin + s - kMaxInAx],
+                                                  si, cj);
             }
-#pragma unroll
-            for (int s = 0; s < kMaxInCost; ++s) {
-                ib[kMaxInAx + s] = 0;
-                if (s < n_cost_in && N->in[kMaxInAx + s].lds_slot < 0) {
-                    const DTerm &t = P->cost[N->cost_kin + s];
-                    int64_t off = 0;
-#pragma unroll
-                    for (int a = 0; a < D; ++a) off += (int64_t)t.stride[a] * si[a];
-#pragma unroll
-                    for (int c = 0; c < HJB_MAX_C; ++c) off += (int64_t)t.stride[D + c] * cj[c];
-                    ib[kMaxInAx + s] = off;
-                }
-            }
-            int tag = -0x7fffffff;
+            bool need_gather = true;
             T E0 = (T)0, dE = (T)0;
             // ---- per control of the innermost dim ----------------------------
-            for (int j = 0; j < m_in; ++j) {
-                T q = qo;
+            if constexpr (FAST) {
+                // slot 0 = last-axis table b[j], slot kMaxInAx = cost table r[j]
+                T xb = s_tab[0], xr = s_tab[kMaxInAx];
+                T ibest = (T)INFINITY;
+                int ij = 0;
+                for (int j = 0; j < m_in; ++j) {
+                    const T q = (T)(qo + xb);
+                    const T gr = (T)(go + xr);
+                    // prefetch the next control's row (row m_in is padding)
+                    xb = s_tab[(j + 1) * kMaxInner];
+                    xr = s_tab[(j + 1) * kMaxInner + kMaxInAx];
+                    if (track_update<T>(trk[D - 1], s_k, s_r, nl, q, l_uniform, l_x0, l_invh)) {
+                        lc = trk[D - 1].cell - plane0;
+                        if (lc < 0 || lc + 1 >= nplanes) {
+                            *P->status = 1;
+                            lc = lc < 0 ? 0 : nplanes - 2;
+                        }
+                        need_gather = true;
+                    }
+                    if (need_gather) {
+                        need_gather = false;
+                        T v[1 << D];
+                        const int64_t b2 = base + js_last * lc;
 #pragma unroll
-                for (int s = 0; s < kMaxInAx; ++s) {
-                    if (s < n_ax_in) {
-                        const DInnerTerm &it = N->in[s];
-                        T x = it.lds_slot >= 0
-                                  ? s_tab[it.lds_slot * m_in + j]
-                                  : static_cast<const T *>(it.data)[ib[s] + (int64_t)j * it.stride_in];
-                        q = (N->ax_kin + s == 0) ? x : (T)(q + x);
+                        for (int c = 0; c < (1 << D); ++c) {
+                            int64_t off = b2;
+#pragma unroll
+                            for (int a = 0; a < D; ++a)
+                                if (c & (1 << a)) off += P->jstride[a];
+                            v[c] = Jn[off];
+                        }
+#pragma unroll
+                        for (int a = 0; a < D - 1; ++a) {
+#pragma unroll
+                            for (int jj = 0; jj < (1 << (D - 1 - a)); ++jj)
+                                v[jj] = fma_t<T>(tw[a], (T)(v[2 * jj + 1] - v[2 * jj]), v[2 * jj]);
+                        }
+                        E0 = v[0];
+                        dE = (T)(v[1] - v[0]);
+                    }
+                    const T t = (T)((T)(q - trk[D - 1].kc) * trk[D - 1].rc);
+                    const T tot = (T)(gr + fma_t<T>(t, dE, E0));
+                    if (tot < ibest) {
+                        ibest = tot;
+                        ij = j;
                     }
                 }
-                int cell = find_cell_lds<T>(s_k, nl, q, l_uniform, l_x0, l_invh);
-                const T t = (T)((T)(q - s_k[cell]) * s_r[cell]);
-                int lc = cell - plane0;
-                if (lc < 0 || lc + 1 >= nplanes) {
-                    *P->status = 1;
-                    lc = lc < 0 ? 0 : nplanes - 2;
+                // strict '<' across outer steps keeps the first minimiser in visiting order
+                if (uo == 0 || ibest < best) {
+                    best = ibest;
+                    best_uo = uo;
+                    best_j = ij;
                 }
-                if (lc != tag) {
-                    tag = lc;
-                    T v[1 << D];
-                    const int64_t b2 = base + js_last * lc;
-#pragma unroll
-                    for (int c = 0; c < (1 << D); ++c) {
-                        int64_t off = b2;
-#pragma unroll
-                        for (int a = 0; a < D; ++a)
-                            if (c & (1 << a)) off += P->jstride[a];
-                        v[c] = Jn[off];
+            } else {
+                for (int j = 0; j < m_in; ++j) {
+                    T x[kMaxInner];
+    #pragma unroll
+                    for (int s = 0; s < kMaxInner; ++s) x[s] = s_tab[j * kMaxInner + s];
+                    if (any_gen) {
+    #pragma unroll
+                        for (int s = 0; s < kMaxInner; ++s)
+                            if (gen[s]) x[s] = gdata[s][ib[s] + j * gstride[s]];
                     }
-#pragma unroll
-                    for (int a = 0; a < D - 1; ++a) {
-#pragma unroll
-                        for (int jj = 0; jj < (1 << (D - 1 - a)); ++jj)
-                            v[jj] = fma_t<T>(tw[a], (T)(v[2 * jj + 1] - v[2 * jj]), v[2 * jj]);
+                    T q = qo;
+                    if (n_ax_in > 0) q = (ax_kin == 0) ? x[0] : (T)(q + x[0]);
+                    if (n_ax_in > 1) q = (T)(q + x[1]);
+                    if (track_update<T>(trk[D - 1], s_k, s_r, nl, q, l_uniform, l_x0, l_invh)) {
+                        lc = trk[D - 1].cell - plane0;
+                        if (lc < 0 || lc + 1 >= nplanes) {
+                            *P->status = 1;
+                            lc = lc < 0 ? 0 : nplanes - 2;
+                        }
+                        need_gather = true;
                     }
-                    E0 = v[0];
-                    dE = (T)(v[1] - v[0]);
-                }
-                const T val = fma_t<T>(t, dE, E0);
-                T g = go;
-#pragma unroll
-                for (int s = 0; s < kMaxInCost; ++s) {
-                    if (s < n_cost_in) {
-                        const DInnerTerm &it = N->in[kMaxInAx + s];
-                        T x = it.lds_slot >= 0
-                                  ? s_tab[it.lds_slot * m_in + j]
-                                  : static_cast<const T *>(it.data)[ib[kMaxInAx + s] + (int64_t)j * it.stride_in];
-                        g = (N->cost_kin + s == 0) ? x : (T)(g + x);
+                    if (need_gather) {
+                        need_gather = false;
+                        T v[1 << D];
+                        const int64_t b2 = base + js_last * lc;
+    #pragma unroll
+                        for (int c = 0; c < (1 << D); ++c) {
+                            int64_t off = b2;
+    #pragma unroll
+                            for (int a = 0; a < D; ++a)
+                                if (c & (1 << a)) off += P->jstride[a];
+                            v[c] = Jn[off];
+                        }
+    #pragma unroll
+                        for (int a = 0; a < D - 1; ++a) {
+    #pragma unroll
+                            for (int jj = 0; jj < (1 << (D - 1 - a)); ++jj)
+                                v[jj] = fma_t<T>(tw[a], (T)(v[2 * jj + 1] - v[2 * jj]), v[2 * jj]);
+                        }
+                        E0 = v[0];
+                        dE = (T)(v[1] - v[0]);
                     }
-                }
-                const T tot = (T)(g + val);
-                const int64_t u = (int64_t)uo * m_in + j;
-                if (u == 0 || tot < best) {
-                    best = tot;
-                    best_u = u;
+                    const T t = (T)((T)(q - trk[D - 1].kc) * trk[D - 1].rc);
+                    const T val = fma_t<T>(t, dE, E0);
+                    T g = go;
+                    if (n_cost_in > 0) g = (cost_kin == 0) ? x[kMaxInAx] : (T)(g + x[kMaxInAx]);
+                    if (n_cost_in > 1) g = (T)(g + x[kMaxInAx + 1]);
+                    const T tot = (T)(g + val);
+                    if ((uo == 0 && j == 0) || tot < best) {
+                        best = tot;
+                        best_uo = uo;
+                        best_j = j;
+                    }
                 }
             }
             // next outer control: dims 0..C-2, dim C-2 fastest
@@ -235,17 +325,15 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                 ++cj[0];
             }
         }
+        // visiting order (dim 0 slowest) -> column-major label (dim 0 fastest)
         int64_t label;
         if (C == 1) {
-            label = best_u;
+            label = best_j;
         } else if (C == 2) {
-            int64_t j1 = best_u % P->m[1], j0 = best_u / P->m[1];
-            label = j0 + (int64_t)P->m[0] * j1;
+            label = best_uo + (int64_t)P->m[0] * best_j;
         } else {
-            int64_t j2 = best_u % P->m[2];
-            int64_t rr = best_u / P->m[2];
-            int64_t j1 = rr % P->m[1], j0 = rr / P->m[1];
-            label = j0 + (int64_t)P->m[0] * (j1 + (int64_t)P->m[1] * j2);
+            const int j1 = best_uo % P->m[1], j0 = best_uo / P->m[1];
+            label = j0 + (int64_t)P->m[0] * (j1 + (int64_t)P->m[1] * best_j);
         }
         const int64_t in_plane = ls % P->inner, pl = ls / P->inner;
         Jout[in_plane + P->inner * (pl + P->halo_lo)] = best;
