@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py - the reference's headline metric on its named config, on MI355X.
+
+Metric  : Bellman backups/s (state x control x stage)       [BASELINE.json `metric`]
+Workload: configs[1] "Solver_position 3-DOF, 101^3 state x 21^3 control grid,
+          100 stages, 1x MI355X" (SURVEY.md 8(d) C2), float32, synthetic/deterministic.
+Step    : ONE stage of the backward sweep = one fused backup kernel over the whole
+          grid (1,030,301 states x 9,261 controls = 9.54e9 backups).  Default
+          K=100 steps = the config's 100 stages.
+N GPUs  : one process per GPU (torchrun); the grid is sharded along its last state
+          axis, WEAK scaling: every rank owns 101 planes (global last axis 101*N),
+          with a per-stage neighbour halo exchange over RCCL (torch.distributed P2P).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the stage kernel with the
+ALGORITHMIC work of SURVEY.md 8(d): F_alg(3) = 41 flop/backup against the fp32
+vector peak (the binding roofline: every BASELINE config is VALU-bound) and
+(2*4+4) B/state/stage against HBM.  `cpu_baseline` times the oracle's C twin
+(oracle/hjb_oracle.c, OpenMP) on a bounded slab sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "optimal-control-dynamic-programming_amd"))
+sys.path.insert(0, str(ROOT))
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (= f32-input MFMA rate)
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def f_alg(D):
+    return 3 * (2 ** D - 1) + 6 * D + 2   # SURVEY.md 8(d) "Algorithmic flops per backup"
+
+
+def cpu_baseline(spec, budget_s=15.0):
+    """Oracle C twin on this host's cores, on a slab sample (whole planes of the
+    last axis, mid-grid, with halos) of the SAME workload."""
+    import numpy as np
+    from hjbdp import _abi
+    from oracle import c_oracle
+    c_oracle.build()
+    lib = c_oracle.lib(_abi)
+    cores = int(lib.orc_max_threads())
+    inner = spec.nS // spec.n[-1]
+    mid = spec.n[-1] // 2
+    rng = np.random.default_rng(0)
+
+    def run(planes):
+        b, e = mid, mid + planes
+        J = rng.random(inner * (planes + 2)).astype(spec.dtype)
+        t0 = time.perf_counter()
+        c_oracle.backup_stage(_abi, spec, J, slab=(b, e, 1, 1), nthreads=cores)
+        return time.perf_counter() - t0
+    t1 = run(1)
+    planes = int(max(1, min(spec.n[-1] // 2 - 2, budget_s / max(t1, 1e-3))))
+    t = run(planes) if planes > 1 else t1
+    backups = inner * planes * spec.nU
+    return {"value": backups / t, "unit": "backups/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d planes of the last state axis (%d states x %d controls, 1 stage) in %.1f s; "
+                      "oracle/hjb_oracle.c, OpenMP" % (planes, spec.n[-1], inner * planes, spec.nU, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=101, help="state grid points per axis (config: 101)")
+    ap.add_argument("--mu", type=int, default=21, help="control grid points per axis (config: 21)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=None, help="force a stage-kernel variant (testing)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import hjbdp
+    from hjbdp.sharded import ShardedSweep
+    from hjbdp.synthetic import position3d_spec
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # weak scaling: every rank owns args.n planes of the last axis
+    spec = position3d_spec(n=args.n, mu=args.mu, n_last=args.n * world)
+    sw = ShardedSweep(spec, rank, world, dev)
+    if args.variant is not None:
+        sw._handle.set_option("variant", args.variant)
+    info = sw._handle.info()
+    sw.set_terminal(None)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        sw.step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                      # same stream the kernels are launched on
+    for _ in range(args.steps):
+        sw.step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    sw._handle.check_device_status()
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt[0])
+
+    states_per_rank = info["n_states"]
+    backups_per_launch = states_per_rank * spec.nU
+    total_backups = backups_per_launch * world * args.steps
+    value = total_backups / wall
+    launch_ms = dev_ms / args.steps                                 # one kernel per step
+    D = spec.D
+    alg_flops = f_alg(D) * backups_per_launch
+    alg_bytes = (2 * spec.dtype.itemsize + 4) * states_per_rank     # read J_{k+1}, write J_k + int32 argmin
+    tflops = alg_flops / (launch_ms * 1e-3) / 1e12
+    gbs = alg_bytes / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_traffic.json"                    # written from rocprofv3 --pmc passes
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    J_final = sw.owned_J()
+    checksum = float(J_final.double().sum())
+    out = {
+        "metric": "bellman_backups_per_s", "value": value, "unit": "backups/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2 Solver_position 3-DOF: %d^2 x %d states x %d^3 controls, 1 stage per step"
+                               % (args.n, args.n * world, args.mu),
+                   "states_per_gpu": states_per_rank, "controls": spec.nU, "stages": args.steps,
+                   "sharding": "last state axis, %d planes per GPU, halo %d/%d planes exchanged per stage"
+                               % (args.n, sw.halo_lo, sw.halo_hi) if world > 1 else "none",
+                   "kernel_variant": info["kernel_variant"]},
+        "roofline": {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
+                     "kernel": "k_backup_nested<float,3,true>" if info["kernel_variant"] == 1 else "k_backup_generic<float,3>",
+                     "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(D),
+                     "note": "fp32 vector (VALU) roofline binds (SURVEY 8d); peak = MI355X fp32 vector = f32-MFMA rate",
+                     "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                             "alg_bytes_per_state": 2 * spec.dtype.itemsize + 4}},
+        "checksum_sum_J": checksum,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spec)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sw.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

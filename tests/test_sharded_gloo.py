@@ -1,0 +1,111 @@
+"""CPU tests of the multi-GPU path's host logic: world_size-2 (and 3) gloo process
+groups; the per-slab backup is the oracle (injected), so what is tested is the
+partitioning, halo sizing and the halo exchange, against a whole-grid sweep."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_stage_fn(spec, sw):
+    import torch
+    from hjbdp import _abi
+    from oracle import c_oracle
+
+    def fn(J_in, J_out, idx):
+        slab = sw.slab if sw.world > 1 else None
+        Jo, io = c_oracle.backup_stage(_abi, spec, J_in.numpy().reshape(-1), slab=slab, nthreads=2)
+        J_out.copy_(torch.from_numpy(Jo.reshape(J_out.shape)))
+        idx.copy_(torch.from_numpy(io.reshape(idx.shape)))
+    return fn
+
+
+def _worker(rank, world, port, n, m, stages, q):
+    sys.path.insert(0, str(ROOT / "optimal-control-dynamic-programming_amd"))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch
+    import torch.distributed as dist
+    from problems import nested_problem, random_terminal
+    from hjbdp.sharded import ShardedSweep
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = nested_problem(31, n, m, dtype=np.float32, spread=0.12)
+    term = random_terminal(spec, 2)
+    sw = ShardedSweep(spec, rank, world, "cpu", stage_fn=lambda *a: None)
+    sw.stage_fn = _oracle_stage_fn(spec, sw)
+    sw.set_terminal(term)
+    done = sw.sweep(stages, monitor_period=2, monitor_tol=0.0)
+    fs, isum = sw.monitor_sums()
+    J, idx = sw.gather()
+    if rank == 0:
+        q.put((done, fs, isum, J, idx, sw.halo_lo, sw.halo_hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sweep_matches_whole_grid(built, world):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT / "tests"))
+    from problems import nested_problem, random_terminal
+    from hjbdp import _abi
+    from oracle import c_oracle
+    n, m, stages = (7, 6, 13), (3, 4), 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, m, stages, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    done, fs, isum, J, idx, hlo, hhi = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    spec = nested_problem(31, n, m, dtype=np.float32, spread=0.12)
+    ref = c_oracle.sweep(_abi, spec, stages, terminal=random_terminal(spec, 2))
+    assert done == stages
+    assert np.array_equal(J, ref["J"]) and np.array_equal(idx, ref["idx"])
+    assert abs(fs - float(ref["J"].astype(np.float64).sum())) < 1e-6 * abs(fs)
+    assert isum == float(ref["idx"].astype(np.float64).sum())
+
+
+def test_partition_and_halo():
+    from hjbdp.sharded import partition, required_halo
+    from hjbdp.synthetic import position3d_spec
+    assert partition(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert partition(101, 8)[-1][1] == 101 and all(e - b in (12, 13) for b, e in partition(101, 8))
+    lo, hi = required_halo(position3d_spec(n=21, mu=5))
+    assert (lo, hi) == (1, 1)      # x3+ = x3 + (h/M) u3 moves a fraction of a cell
+
+
+def test_single_rank_needs_no_process_group(built):
+    """world=1 path of ShardedSweep (what bench.py runs at --gpus 1), oracle injected."""
+    import torch  # noqa: F401
+    sys.path.insert(0, str(ROOT / "tests"))
+    from problems import nested_problem
+    from hjbdp import _abi
+    from hjbdp.sharded import ShardedSweep
+    from oracle import c_oracle
+    spec = nested_problem(3, (6, 5, 7), (3, 3), dtype=np.float64)
+    sw = ShardedSweep(spec, 0, 1, "cpu", stage_fn=lambda *a: None)
+    sw.stage_fn = _oracle_stage_fn(spec, sw)
+    sw.set_terminal(None)
+    sw.sweep(3)
+    J, idx = sw.gather()
+    ref = c_oracle.sweep(_abi, spec, 3)
+    assert np.array_equal(J, ref["J"]) and np.array_equal(idx, ref["idx"])
