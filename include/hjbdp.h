@@ -37,7 +37,7 @@ extern "C" {
 #define HJB_MAX_D 6      /* state dims   (Solver_attitude.run: 6)            */
 #define HJB_MAX_C 3      /* control dims (Solver_attitude.run: U1,U2,U3)     */
 #define HJB_MAX_G 9      /* D + C        (reshape_states: dims 1..9)         */
-#define HJB_MAX_TERMS 8  /* broadcast terms per quantity                     */
+#define HJB_MAX_TERMS 12 /* broadcast terms per quantity (attitude cost: 9)      */
 
 /* status codes */
 #define HJB_OK 0

@@ -11,7 +11,7 @@ import ctypes as C
 HJB_MAX_D = 6
 HJB_MAX_C = 3
 HJB_MAX_G = 9
-HJB_MAX_TERMS = 8
+HJB_MAX_TERMS = 12
 
 HJB_OK = 0
 HJB_E_INVALID = 1

@@ -1,0 +1,144 @@
+"""Solver_pos_att - host mirror of pos-att/Solver_pos_att.m (the sweep part).
+
+simplified_run (:197-242) -> four calls of calculate_one_channel_U_Opt (:244-297):
+per channel a 4-D state (x, v, theta, w) x 9 thruster combinations (6 for the
+thruster-failure channel), `sym_linspace` grids (:906-918, non-uniform for even n),
+first-order ("RK4_*" are Euler, :330-402) next states, cost of J_current_reshaped
+(:784-802), 1999 stages with the early-stop monitor every 50 stages (:268-285,
+restated as intended: idsum50_prev is read before assignment in the reference).
+The reference saves each controller to a .mat file (:289); here the same four
+variables are kept in `self.controllers[file_name]`.
+
+Typing: the reference keeps J single (`zeros(...,'single')`, :265) with double
+query tables; libhjbdp computes a problem in ONE dtype, so the sweep runs in
+float32 end to end (coordinates and weights included) - the choice SURVEY 8a
+note 6 documents as unpinned by any reference artefact.  The stage cost is by
+default passed as ONE full-mask term holding single(double sum), which is exactly
+`J_current_M = single(...)` (:800-801); cost_mode='terms' passes the five
+separable operands instead (float32 sums, ~1 ulp different, no nS*nU table).
+Policy use / forward simulation (:404-730) is out of scope.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .core import Backup
+from .matlab_compat import deg2rad, sym_linspace_pos_att
+from .problem import ProblemSpec, Term
+
+
+def vectors_allcomb(f1, f2, f3, f4):
+    """Solver_pos_att.m:886-904: ndgrid of the four thruster level vectors in
+    column-major order, minus combinations firing opposing thrusters
+    (f1>0 & f3<0) or (f2>0 & f4<0)."""
+    f1, f2, f3, f4 = (np.atleast_1d(np.asarray(f, dtype=np.float64)) for f in (f1, f2, f3, f4))
+    G = np.meshgrid(f1, f2, f3, f4, indexing="ij")
+    F1, F2, F3, F4 = (g.reshape(-1, order="F") for g in G)
+    rm = ((F1 > 0) & (F3 < 0)) | ((F2 > 0) & (F4 < 0))
+    keep = ~rm
+    return F1[keep], F2[keep], F3[keep], F4[keep]
+
+
+class Solver_pos_att:
+    def __init__(self):
+        # Solver_pos_att.m:96-195
+        self.v_min, self.v_max, self.n_mesh_v = -0.1, 0.1, 30
+        self.x_min, self.x_max, self.n_mesh_x = -0.2, 0.2, 30
+        self.w_min, self.w_max, self.n_mesh_w = float(deg2rad(-2)), float(deg2rad(2)), 15
+        self.theta1_min, self.theta1_max = -5.0, 5.0
+        self.theta2_min, self.theta2_max = -6.0, 6.0
+        self.theta3_min, self.theta3_max = -7.0, 7.0
+        self.n_mesh_t = 20
+        self.Mass = 4.16
+        i1, i2, i3 = 0.02836 + 0.00016, 0.026817 + 0.00150, 0.023 + 0.00150
+        i4, i5, i6 = -0.0000837, 0.000014, -0.00029
+        self.InertiaM = np.array([[i1, i4, i5], [i4, i2, i6], [i5, i6, i3]])
+        self.J1, self.J2, self.J3 = self.InertiaM[0, 0], self.InertiaM[1, 1], self.InertiaM[2, 2]
+        self.Qx1 = self.Qx2 = self.Qx3 = 6.0
+        self.Qv1 = self.Qv2 = self.Qv3 = 6.0
+        self.Qt1 = self.Qt2 = self.Qt3 = 0.5
+        self.Qw1 = self.Qw2 = self.Qw3 = 0.5
+        self.R1 = self.R2 = self.R3 = 0.1
+        self.T_final = 10.0
+        self.h = 0.005
+        self.N_stage = int(math.ceil(self.T_final / self.h))
+        self.T_final = self.h * self.N_stage
+        T = 0.13
+        self.T_dist = 9.65e-2
+        self.F_Thr0 = self.F_Thr1 = self.F_Thr2 = self.F_Thr3 = self.F_Thr4 = self.F_Thr5 = np.array([0.0, T])
+        self.F_Thr6 = self.F_Thr7 = self.F_Thr8 = self.F_Thr9 = self.F_Thr10 = self.F_Thr11 = -np.array([0.0, T])
+        self.monitor_period = 50      # :273
+        self.monitor_tol = 1e-2       # :269
+        self.cost_mode = "exact"
+        self.device = 0
+        self.controllers = {}
+
+    # ------------------------------------------------------------------
+    def grids(self):
+        sx = sym_linspace_pos_att(self.x_min, self.x_max, self.n_mesh_x)
+        sv = sym_linspace_pos_att(self.v_min, self.v_max, self.n_mesh_v)
+        st = [sym_linspace_pos_att(float(deg2rad(a)), float(deg2rad(b)), self.n_mesh_t)
+              for a, b in ((self.theta1_min, self.theta1_max), (self.theta2_min, self.theta2_max),
+                           (self.theta3_min, self.theta3_max))]
+        sw = sym_linspace_pos_att(self.w_min, self.w_max, self.n_mesh_w)
+        return sx, sv, st, sw
+
+    def build_channel_spec(self, s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw, R, J):
+        """One calculate_one_channel_U_Opt problem (:244-265)."""
+        fa, fb, fc, fd = vectors_allcomb(f0, f1, f6, f7)                  # :253
+        h, d = self.h, self.T_dist
+        # next_stage_states_simplified :299-328 with the Euler steps :330-402 (double)
+        dv = h * ((fa + fb + fc + fd) / self.Mass)
+        dw = h * ((fa * d + fb * (-d) + fc * d + fd * (-d)) / J)
+        f32 = np.float32
+        nxt = [[Term((0,), s_x), Term((1,), h * s_v)],
+               [Term((1,), s_v), Term((4,), dv)],
+               [Term((2,), s_t), Term((3,), h * s_w)],
+               [Term((3,), s_w), Term((4,), dw)]]
+        # J_current_reshaped :784-802 (argument order x,v,t,w; sum order Qx,Qv,Qw,Qt,R)
+        cu = R * fa ** 2 + R * fb ** 2 + R * fc ** 2 + R * fd ** 2
+        if self.cost_mode == "exact":
+            X = s_x[:, None, None, None, None]
+            V = s_v[None, :, None, None, None]
+            Tt = s_t[None, None, :, None, None]
+            W = s_w[None, None, None, :, None]
+            full = (Qx * X ** 2 + Qv * V ** 2 + Qw * W ** 2 + Qt * Tt ** 2 + cu[None, None, None, None, :]).astype(f32)
+            cost = [Term((0, 1, 2, 3, 4), full)]
+        elif self.cost_mode == "terms":
+            cost = [Term((0,), Qx * s_x ** 2), Term((1,), Qv * s_v ** 2), Term((3,), Qw * s_w ** 2),
+                    Term((2,), Qt * s_t ** 2), Term((4,), cu)]
+        else:
+            raise ValueError("cost_mode must be 'exact' or 'terms'")
+        spec = ProblemSpec([s_x, s_v, s_t, s_w], [len(fa)], nxt, cost, dtype=np.float32, index_base=1)
+        return spec, (fa, fb, fc, fd)
+
+    def calculate_one_channel_U_Opt(self, s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw, R, J, file_name,
+                                    n_stages=None, progress=None):
+        spec, combos = self.build_channel_spec(s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw, R, J)
+        n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
+        with Backup(spec, device=self.device) as bk:
+            out = bk.solve(n_st, monitor_period=self.monitor_period, monitor_tol=self.monitor_tol, progress=progress)
+        shape = spec.n
+        self.controllers[file_name] = {                                  # save(file_name, ...) :289
+            "GridVectors": [s_x, s_v, s_t, s_w],
+            "F_gI_Values": out["J"].reshape(shape, order="F"),
+            "U_Optimal_id": out["idx"].reshape(shape, order="F"),
+            "f0_allcomb": combos[0], "f1_allcomb": combos[1], "f6_allcomb": combos[2], "f7_allcomb": combos[3],
+            "stages_done": out["stages_done"], "stopped_early": out["stopped_early"], "sweep_ms": out["sweep_ms"],
+        }
+        return self.controllers[file_name]
+
+    def simplified_run(self, n_stages=None, progress=None):
+        sx, sv, st, sw = self.grids()
+        ch = self.calculate_one_channel_U_Opt
+        ch(sx, sv, st[0], sw, self.F_Thr0, self.F_Thr1, self.F_Thr6, self.F_Thr7,
+           self.Qx1, self.Qv1, self.Qt1, self.Qw1, self.R1, self.J2, "channel_x_controller_1", n_stages, progress)     # :217-221
+        ch(sx, sv, st[1], sw, self.F_Thr2, self.F_Thr3, self.F_Thr8, self.F_Thr9,
+           self.Qx2, self.Qv2, self.Qt2, self.Qw2, self.R2, self.J3, "channel_y_controller_1", n_stages, progress)     # :223-227
+        ch(sx, sv, st[2], sw, self.F_Thr4, self.F_Thr5, self.F_Thr10, self.F_Thr11,
+           self.Qx3, self.Qv3, self.Qt3, self.Qw3, self.R3, self.J1, "channel_z_controller_1", n_stages, progress)     # :229-233
+        ch(sx, sv, st[0], sw, [0.0], self.F_Thr1, self.F_Thr6, self.F_Thr7,
+           self.Qx1, self.Qv1, self.Qt1, self.Qw1, self.R1, self.J2, "channel_x_controller_1_failure", n_stages, progress)  # :236-240
+        return self

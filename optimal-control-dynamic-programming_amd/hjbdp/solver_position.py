@@ -1,0 +1,101 @@
+"""Solver_position - host mirror of position-control/Solver_position.m.
+
+`simplified_run` (:94-150): three independent 2-D (x_i, v_i) sweeps with the three
+thrust levels U_vector = [-0.26 0 0.26]; the `for k_s = N_stage-1:-1:1` loop
+(:132-141) runs in libhjbdp.  The forward simulation `get_optimal_path`
+(:189-311, RKF45 + orbital dynamics) is out of scope.
+
+Reference quirk kept bit for bit (:157-186): RK4_x integrates xdynamics(v) = v but
+feeds V + k*h/2 back as the "state", so x+ = x + h*(k1+2k2+2k3+k4)/6 with
+k1 = v, k2 = v + k1*h/2, ... does NOT depend on u; RK4_v has all k equal to u/Mass.
+All arithmetic is double, as in the reference.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .core import Backup
+from .matlab_compat import interp_nearest_point, sym_linspace_position
+from .problem import ProblemSpec, Term
+
+
+class NearestPolicy:
+    """griddedInterpolant({s_x,s_v}, U_vector(U_idx), 'nearest') (:144-146)."""
+
+    def __init__(self, knots, values):
+        self.GridVectors = knots
+        self.Values = values
+
+    def __call__(self, *x):
+        return interp_nearest_point(self.GridVectors, self.Values, x)
+
+
+class Solver_position:
+    def __init__(self):
+        # Solver_position.m:46-92
+        self.v_min, self.v_max = -0.5, 0.5
+        self.x_min, self.x_max = -0.5, 0.5
+        self.n_mesh_v = 200
+        self.n_mesh_x = 200
+        self.Mass = 4.16
+        self.Qx1 = self.Qx2 = self.Qx3 = 6.0
+        self.Qv1 = self.Qv2 = self.Qv3 = 6.0
+        self.R1 = self.R2 = self.R3 = 0.1
+        self.T_final = 30.0
+        self.h = 0.005
+        self._finish_init()
+        self.defaultX0 = np.zeros(6)
+        self.U_vector = np.array([-0.13, 0.0, 0.13]) * 2.0
+        self.U1_Opt = self.U2_Opt = self.U3_Opt = None
+        self.device = 0
+        self.F_values = [None, None, None]   # F_i.Values after the sweep
+        self.U_idx = [None, None, None]      # U_i_idx (1-based)
+        self.sweep_ms = [None, None, None]
+
+    def _finish_init(self):
+        # :75-81 (isinteger() of a double is always false -> always ceil)
+        self.N_stage = int(math.ceil(self.T_final / self.h))
+        self.T_final = self.h * self.N_stage
+
+    # -- Solver_position.m:152-186 on grid VECTORS (the 3-D arrays of the
+    #    reference are ndgrid copies of these) ------------------------------
+    def _dx_of_v(self, V, h):
+        k1 = V
+        k2 = V + k1 * h / 2
+        k3 = V + k2 * h / 2
+        k4 = V + k3 * h
+        return h * (k1 + 2 * k2 + 2 * k3 + k4) / 6
+
+    def _dv_of_u(self, U, h):
+        k = U / self.Mass
+        return h * (k + 2 * k + 2 * k + k) / 6
+
+    def build_spec(self, channel):
+        Qx = (self.Qx1, self.Qx2, self.Qx3)[channel]
+        Qv = (self.Qv1, self.Qv2, self.Qv3)[channel]
+        R = (self.R1, self.R2, self.R3)[channel]
+        s_x = sym_linspace_position(self.x_min, self.x_max, self.n_mesh_x)   # :97-104
+        s_v = sym_linspace_position(self.v_min, self.v_max, self.n_mesh_v)
+        U = np.asarray(self.U_vector, dtype=np.float64)
+        nxt = [[Term((0,), s_x), Term((1,), self._dx_of_v(s_v, self.h))],     # RK4_x :157-167
+               [Term((1,), s_v), Term((2,), self._dv_of_u(U, self.h))]]       # RK4_v :173-182
+        cost = [Term((0,), Qx * s_x ** 2), Term((1,), Qv * s_v ** 2), Term((2,), R * U ** 2)]  # :113
+        return ProblemSpec([s_x, s_v], [len(U)], nxt, cost, dtype=np.float64, index_base=1), s_x, s_v
+
+    def simplified_run(self, n_stages=None):
+        """n_stages overrides N_stage-1 (tests)."""
+        n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
+        for ch in range(3):
+            spec, s_x, s_v = self.build_spec(ch)
+            with Backup(spec, device=self.device) as bk:
+                out = bk.solve(n_st)
+            shape = (len(s_x), len(s_v))
+            self.F_values[ch] = out["J"].reshape(shape, order="F")
+            self.U_idx[ch] = out["idx"].reshape(shape, order="F")
+            self.sweep_ms[ch] = out["sweep_ms"]
+            pol = NearestPolicy([s_x, s_v], self.U_vector[self.U_idx[ch] - 1])
+            setattr(self, "U%d_Opt" % (ch + 1), pol)
+        self.n_mesh_x, self.n_mesh_v = len(s_x), len(s_v)                     # :100,:104
+        return self

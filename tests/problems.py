@@ -49,7 +49,7 @@ def random_problem(seed, n, m, dtype=np.float64, nonuniform=False, spread=0.35, 
         cost.append(Term((D + c,), 0.3 * rng.standard_normal(m[c]) ** 2))
     if D + C <= 5:
         cost.append(Term((0, D), 0.1 * rng.random((g[0], g[D]))))
-    return ProblemSpec(knots, m, nxt, cost[:8], dtype=dtype, index_base=index_base)
+    return ProblemSpec(knots, m, nxt, cost[:12], dtype=dtype, index_base=index_base)
 
 
 def random_terminal(spec, seed=0):
@@ -91,4 +91,4 @@ def nested_problem(seed, n, m, dtype=np.float32, nonuniform=False, spread=0.2, m
     cost = [Term((a,), (1.0 + a) * knots[a] ** 2) for a in range(D)]
     for c in range(C):
         cost.append(Term((D + c,), 0.3 * rng.standard_normal(m[c]) ** 2))
-    return ProblemSpec(knots, m, nxt, cost[:8], dtype=dtype, index_base=1)
+    return ProblemSpec(knots, m, nxt, cost[:12], dtype=dtype, index_base=1)

@@ -37,7 +37,7 @@ def test_struct_layout_matches_header(lib):
     from hjbdp import _abi
     assert C.sizeof(_abi.hjb_term) == 16
     expect = 4 * 2 + 4 * 6 + 4 * 3 + 4 * 2  # D,C,n,m,dtype,index_base = 52 -> pad to 56
-    expect = 56 + 8 * 6 + 4 * 6 + 16 * 8 * 6 + 8 + 16 * 8 + 16
+    expect = 56 + 8 * 6 + 4 * 6 + 16 * 12 * 6 + 8 + 16 * 12 + 16
     assert C.sizeof(_abi.hjb_problem) == expect
     assert C.sizeof(_abi.hjb_solve_opts) == 4 + 4 + 8 + 8 * 5 + 8 + 8
     assert C.sizeof(_abi.hjb_result) == 32

@@ -1,0 +1,123 @@
+"""GPU parity tests (-m gpu) of the spacecraft solver mirrors (SURVEY 8 rows
+a9-a12): the class drives libhjbdp; results are bit-exact against the C oracle
+twin on the same problem, plus the invariants SURVEY 8c lists (no reference
+artefact exists for these solvers: "parity unpinned")."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import hjbdp
+    from hjbdp import _abi
+    from oracle import c_oracle
+    if hjbdp.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    return hjbdp, _abi, c_oracle
+
+
+def test_solver_position_reference_grid(env):
+    """Solver_position.simplified_run on the reference's own 201x201x3 grid, 60 stages."""
+    hjbdp, _abi, c_oracle = env
+    sp = hjbdp.Solver_position()
+    specs = [hjbdp.Solver_position().build_spec(ch) for ch in range(3)]
+    sp.simplified_run(n_stages=60)
+    assert sp.n_mesh_x == 201 and sp.n_mesh_v == 201      # updated like Solver_position.m:100,104
+    for ch in range(3):
+        spec, s_x, s_v = specs[ch]
+        ref = c_oracle.sweep(_abi, spec, 60)
+        assert np.array_equal(sp.F_values[ch].reshape(-1, order="F"), ref["J"])
+        assert np.array_equal(sp.U_idx[ch].reshape(-1, order="F"), ref["idx"])
+    J = sp.F_values[0]
+    assert J.min() >= 0 and J[100, 100] == 0.0                 # J >= 0, J(0,0) = 0
+    assert np.allclose(J, J[::-1, ::-1], rtol=1e-9)            # J(x,v) = J(-x,-v) on the symmetric grid
+    assert sp.U1_Opt(0.0, 0.0) == 0.0                          # u*(0) = 0
+    assert sp.U1_Opt(0.3, 0.2) == -0.26 and sp.U1_Opt(-0.3, -0.2) == 0.26
+
+
+def test_solver_position_value_is_monotone_in_horizon(env):
+    hjbdp, _abi, c_oracle = env
+    sp = hjbdp.Solver_position()
+    sp.n_mesh_x = sp.n_mesh_v = 60
+    spec, _, _ = sp.build_spec(1)
+    with hjbdp.Backup(spec) as bk:
+        out = bk.solve(50, keep_J=True)
+    Js = out["J_stages"]          # column k_s-1; k_s = 50 computed first
+    assert np.all(Js[:, :-1] >= Js[:, 1:] - 1e-12)             # J_k non-decreasing as the horizon grows
+
+
+def test_solver_attitude_simplified(env):
+    hjbdp, _abi, c_oracle = env
+    sa = hjbdp.Solver_attitude(n_mesh_t=70, n_mesh_w_simplified=150)
+    sa.simplified_run(n_stages=40)
+    for ch in range(3):
+        spec, s_w, s_t = sa.build_spec_simplified(ch)
+        ref = c_oracle.sweep(_abi, spec, 40)
+        assert np.array_equal(sa.F_values[ch].reshape(-1, order="F"), ref["J"])
+        assert np.array_equal(sa.U_idx[ch].reshape(-1, order="F"), ref["idx"])
+
+
+def test_solver_attitude_full_6d(env):
+    """Solver_attitude.run semantics (6-D x 3-D, single) at a reduced size."""
+    hjbdp, _abi, c_oracle = env
+    sa = hjbdp.Solver_attitude(n_mesh_w=5, n_mesh_q=4)
+    sa.run(n_stages=6)
+    spec = sa.build_spec_full()
+    ref = c_oracle.sweep(_abi, spec, 6)
+    assert np.array_equal(sa.F_values.reshape(-1, order="F"), ref["J"])
+    lab = (sa.U_idx[0] - 1) + 3 * (sa.U_idx[1] - 1) + 9 * (sa.U_idx[2] - 1) + 1
+    assert np.array_equal(lab.reshape(-1, order="F"), ref["idx"])
+    assert set(np.unique(sa.U1_Opt)).issubset({np.float32(-0.11), np.float32(0), np.float32(0.11)})
+
+
+def test_solver_pos_att_channel_reference_grid(env):
+    """One pos-att channel on the reference's 30x30x20x15x9 grid, 12 stages."""
+    hjbdp, _abi, c_oracle = env
+    pa = hjbdp.Solver_pos_att()
+    sx, sv, st, sw = pa.grids()
+    args = (sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    c = pa.calculate_one_channel_U_Opt(*args, "chx", n_stages=12)
+    spec, _ = pa.build_channel_spec(*args)
+    ref = c_oracle.sweep(_abi, spec, 12, monitor_period=50, monitor_tol=1e-2)
+    assert np.array_equal(c["F_gI_Values"].reshape(-1, order="F"), ref["J"])
+    assert np.array_equal(c["U_Optimal_id"].reshape(-1, order="F"), ref["idx"])
+    assert c["U_Optimal_id"].min() >= 1 and c["U_Optimal_id"].max() <= 9
+
+
+def test_solver_pos_att_all_channels_with_monitor(env):
+    """simplified_run (4 channels incl. the thruster-failure one) on a small grid
+    with the early-stop monitor; stop stage and results equal the oracle's."""
+    hjbdp, _abi, c_oracle = env
+    pa = hjbdp.Solver_pos_att()
+    pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 8, 8, 6, 5
+    pa.monitor_period, pa.monitor_tol = 10, 5.0
+    events = []
+    pa.simplified_run(n_stages=120, progress=lambda k_s, e, e2, sec: events.append(k_s))
+    assert set(pa.controllers) == {"channel_x_controller_1", "channel_y_controller_1", "channel_z_controller_1",
+                                   "channel_x_controller_1_failure"}
+    sx, sv, st, sw = pa.grids()
+    spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, [0.0], pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                    pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    ref = c_oracle.sweep(_abi, spec, 120, monitor_period=10, monitor_tol=5.0)
+    c = pa.controllers["channel_x_controller_1_failure"]
+    assert len(c["f0_allcomb"]) == 6
+    assert c["stages_done"] == ref["stages_done"] and c["stopped_early"] == ref["stopped_early"]
+    assert np.array_equal(c["F_gI_Values"].reshape(-1, order="F"), ref["J"])
+    assert np.array_equal(c["U_Optimal_id"].reshape(-1, order="F"), ref["idx"])
+    assert events and all(k % 10 == 0 for k in events)
+
+
+def test_dynamic_solver_default_config_runs(env):
+    """C1b: the committed constructor defaults (100x100x1000, N=200, single)."""
+    hjbdp, _abi, c_oracle = env
+    ds = hjbdp.Dynamic_Solver()
+    ds.run()
+    assert ds.u_star.shape == (100, 100, 200) and ds.u_star.dtype == np.float32
+    assert not ds.u_star[:, :, 199].any()
+    X, U = ds.get_optimal_path()
+    # same qualitative trajectory as the fixture/Kirk Fig. 3-9(b): strong negative first control, decay to the origin
+    assert -9.0 < U[0] < -5.5 and np.abs(X[:, -1]).max() < 0.2
+    X2, U2 = ds.get_optimal_path(np.array([2.0, 1.0]), "ssu", 1)
+    assert ds.ssu_tol == 0.0 and ds.ssu_err_first == 0.0

@@ -1,0 +1,117 @@
+"""CPU tests of the host mirrors of the spacecraft solvers: the problems they
+build restate the reference's formulas (checked against independent closed forms
+and against the oracle at reduced sizes).  No GPU compute here."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def orc(built):
+    from hjbdp import _abi
+    from oracle import c_oracle, hjb_oracle
+    return _abi, c_oracle, hjb_oracle
+
+
+def test_sym_linspace_variants():
+    from hjbdp.matlab_compat import sym_linspace_pos_att, sym_linspace_position
+    v = sym_linspace_position(-0.5, 0.5, 200)          # Solver_position.m:363-371 -> 201 points
+    assert len(v) == 201 and v[100] == 0.0 and v[0] == -0.5 and v[-1] == 0.5
+    w = sym_linspace_pos_att(-0.2, 0.2, 30)            # Solver_pos_att.m:906-918 -> exactly n, non-uniform
+    assert len(w) == 30 and w[15] == 0.0
+    assert np.allclose(np.diff(w[:16]), 0.2 / 15) and np.allclose(np.diff(w[15:]), 0.2 / 14)
+    o = sym_linspace_pos_att(-1.0, 1.0, 15)            # odd n: 8 + 7 points
+    assert len(o) == 15 and o[7] == 0.0
+
+
+def test_position_next_state_quirk():
+    """x+ = x + h*v*(1 + h/2 + h^2/6 + h^3/24) and v+ = v + h*u/Mass."""
+    import hjbdp
+    sp = hjbdp.Solver_position()
+    assert sp.N_stage == 6000
+    spec, s_x, s_v = sp.build_spec(0)
+    assert spec.n == (201, 201) and spec.m == (3,)
+    h = sp.h
+    dx = spec.next_terms[0][1].data
+    assert np.allclose(dx, h * s_v * (1 + h / 2 + h * h / 6 + h ** 3 / 24), rtol=1e-14, atol=0)
+    assert spec.next_terms[0][1].dims == (1,)                      # independent of u
+    dv = spec.next_terms[1][1].data
+    assert np.allclose(dv, h * sp.U_vector / sp.Mass, rtol=1e-15)
+    assert np.array_equal(spec.cost_terms[2].data, 0.1 * sp.U_vector ** 2)
+
+
+def test_pos_att_control_set_and_grids():
+    import hjbdp
+    from hjbdp.solver_pos_att import vectors_allcomb
+    pa = hjbdp.Solver_pos_att()
+    T = 0.13
+    f = vectors_allcomb(pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7)
+    combos = list(zip(*[np.asarray(x) for x in f]))
+    expect = [(0, 0, 0, 0), (T, 0, 0, 0), (0, T, 0, 0), (T, T, 0, 0), (0, 0, -T, 0), (0, T, -T, 0),
+              (0, 0, 0, -T), (T, 0, 0, -T), (0, 0, -T, -T)]      # SURVEY 8(d) order
+    assert len(combos) == 9 and all(np.allclose(a, b) for a, b in zip(combos, expect))
+    assert len(vectors_allcomb([0.0], pa.F_Thr1, pa.F_Thr6, pa.F_Thr7)[0]) == 6   # failure channel
+    sx, sv, st, sw = pa.grids()
+    assert (len(sx), len(sv), len(st[0]), len(sw)) == (30, 30, 20, 15) and pa.N_stage == 2000
+    spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                    6, 6, .5, .5, .1, pa.J2)
+    assert spec.n == (30, 30, 20, 15) and spec.m == (9,) and spec.dtype == np.float32
+    assert spec.cost_terms[0].data.shape == (30, 30, 20, 15, 9)
+    # cells/stage displacement quoted in SURVEY 8e: w moves ~0.89 cell per stage
+    dw = np.abs(spec.next_terms[3][1].data).max() / np.diff(sw).min()
+    assert 0.8 < dw < 1.0
+
+
+def test_pos_att_exact_and_terms_cost_agree(orc):
+    import hjbdp
+    _abi, c_oracle, hjb_oracle = orc
+    pa = hjbdp.Solver_pos_att()
+    pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 8, 7, 6, 5
+    sx, sv, st, sw = pa.grids()
+    args = (sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
+    s_exact, _ = pa.build_channel_spec(*args)
+    pa.cost_mode = "terms"
+    s_terms, _ = pa.build_channel_spec(*args)
+    a = c_oracle.sweep(_abi, s_exact, 6)
+    b = c_oracle.sweep(_abi, s_terms, 6)
+    assert np.max(np.abs(a["J"] - b["J"]) / np.maximum(1e-6, np.abs(a["J"]))) < 1e-5
+    # symmetric grid + symmetric control set: J(0,...)=0 stays the minimum, policy at the origin = no thrust
+    shape = s_exact.n
+    J = a["J"].reshape(shape, order="F")
+    assert J.min() >= 0.0
+
+
+def test_attitude_full_problem_structure(orc):
+    import hjbdp
+    _abi, c_oracle, hjb_oracle = orc
+    sa = hjbdp.Solver_attitude(n_mesh_w=4, n_mesh_q=3)
+    spec = sa.build_spec_full()
+    assert spec.n == (4, 4, 4, 3, 3, 3) and spec.m == (3, 3, 3) and spec.dtype == np.float32
+    assert [t.dims for t in spec.next_terms[0]] == [(0,), (1, 2, 6)]
+    assert [t.dims for t in spec.next_terms[1]] == [(1,), (0, 2, 7)]
+    assert [t.dims for t in spec.next_terms[2]] == [(2,), (0, 1, 8)]
+    assert len(spec.cost_terms) == 9
+    # Euler's equations, first axis: w1+ = w1 + h*((J2-J3)/J1*w2*w3 + u1/J1)
+    w = spec.knots[0]
+    i, j, k, u = 1, 2, 3, 0
+    ref = sa.h * ((sa.J2 - sa.J3) / sa.J1 * w[j] * w[k] + sa.U_vector[u] / sa.J1)
+    assert abs(spec.next_terms[0][1].data[j, k, u] - ref) < 1e-6 * max(1.0, abs(ref))
+    # zero rates: the angles must stay where they are
+    sa0 = hjbdp.Solver_attitude(n_mesh_w=3, n_mesh_q=5)
+    s0 = sa0.build_spec_full()
+    yaw_n = s0.next_terms[3][0].data
+    assert np.allclose(yaw_n[1, 1, 1, :, 2, 2], s0.knots[3], atol=2e-6)    # w = 0 at the middle knot
+    # numpy oracle and C twin agree on this 6-D x 3-D problem (cascade argmin)
+    p = hjb_oracle.Problem(spec.knots, spec.m, spec.next_terms, spec.cost_terms, spec.dtype)
+    Jn, inp = hjb_oracle.backup_stage(p, np.zeros(spec.n, np.float32))
+    Jc, ic = c_oracle.backup_stage(_abi, spec, np.zeros(spec.nS, np.float32))
+    assert np.allclose(Jn.reshape(-1, order="F"), Jc, rtol=1e-5, atol=1e-6)
+    assert np.all(ic == 1 + 1 + 3 * (1 + 3 * 1))      # zero terminal cost: cheapest control = zero torque (1-based)
+
+
+def test_attitude_simplified_structure():
+    import hjbdp
+    sa = hjbdp.Solver_attitude()
+    spec, s_w, s_t = sa.build_spec_simplified(1)
+    assert spec.n == (1000, 300) and spec.m == (3,) and sa.N_stage == 6000
+    assert spec.next_terms[0][1].dims == (2,) and spec.next_terms[1][1].dims == (0,)   # w+ <- u ; theta+ <- w
+    assert np.isclose(s_t[0], -np.deg2rad(20)) and np.isclose(s_w[-1], np.deg2rad(50))
