@@ -10,12 +10,14 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/hjbdp.h"
 #include "hjbdp_dev.h"
 #include "kernels_generic.h"
 #include "kernels_nested.h"
+#include "kernels_packed.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -44,6 +46,8 @@ struct Handle {
     DNested *dn = nullptr;
     bool nested_ok = false;
     bool nested_fast = false;
+    int packed_mode = 0;          // variant 2 eligibility
+    size_t packed_lds = 0;
     size_t nested_lds = 0;
     int variant = 0;
     int forced_variant = -1;
@@ -146,6 +150,19 @@ void term_minmax_along(const hjb_problem *p, const hjb_term &t, int dim, std::ve
         }
     }
     for (int i = 0; i < nd; ++i) { lo[i] += tlo[i]; hi[i] += thi[i]; }
+}
+
+template <typename T>
+void launch_prep(int D, int grid, const DParams *dp, int a, const int32_t *dsz, int64_t n, int2 *tab) {
+    dim3 g(grid), b(256);
+    switch (D) {
+        case 2: hipLaunchKernelGGL((k_prep_axis_table<T, 2>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        case 3: hipLaunchKernelGGL((k_prep_axis_table<T, 3>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        case 4: hipLaunchKernelGGL((k_prep_axis_table<T, 4>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        case 5: hipLaunchKernelGGL((k_prep_axis_table<T, 5>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        case 6: hipLaunchKernelGGL((k_prep_axis_table<T, 6>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        default: break;   // D == 1 has no outer axis
+    }
 }
 
 template <typename T>
@@ -289,17 +306,71 @@ int build(Handle *h, const hjb_problem *p) {
             }
         }
         N.n_slots = slots;
+        // loop levels (see DNested): o1 runs over control dim C-2, o0 over control dim 0 when C == 3
+        N.m_o0 = (C == 3) ? p->m[0] : 1;
+        N.m_o1 = (C >= 2) ? p->m[C - 2] : 1;
+        const uint32_t o1_bit = (C >= 2) ? (1u << (D + C - 2)) : 0u;
+        for (int a = 0; a < D; ++a) {
+            const DAxis &ax = P.axis[a];
+            const int endk = (a == D - 1) ? ax_kin : ax.n_terms;
+            int l0 = endk;
+            for (int k = endk - 1; k >= ax.n_prefix; --k)
+                if (p->next_terms[a][k].mask & o1_bit) l0 = k;
+            N.ax_l0[a] = std::max(l0, ax.n_prefix);
+        }
+        {
+            int l0 = cost_kin;
+            for (int k = cost_kin - 1; k >= P.n_cost_prefix; --k)
+                if (p->cost_terms[k].mask & o1_bit) l0 = k;
+            N.cost_l0 = std::max(l0, P.n_cost_prefix);
+        }
         h->nested_lds = ((size_t)2 * p->n[D - 1] + (size_t)kMaxInner * (N.m_in + 1)) * sizeof(T);
         h->nested_fast = ok && N.n_ax_in == 1 && N.n_cost_in == 1 && N.in[0].lds_slot >= 0 &&
                          N.in[kMaxInAx].lds_slot >= 0 && ax_kin > 0 && cost_kin > 0;
         if (h->nested_lds > 64 * 1024) ok = false;
         h->nested_ok = ok;
-        if (ok) {
-            void *dnn = nullptr;
-            int st2 = dev_alloc(h, sizeof(DNested), &dnn);
-            if (st2) return st2;
-            h->dn = (DNested *)dnn;
-            HIP_TRY(h, hipMemcpy(h->dn, &N, sizeof(DNested), hipMemcpyHostToDevice));
+        h->packed_mode = 0;
+        if (ok && h->nested_fast && p->dtype == HJB_F32 && h->j_elems < ((int64_t)1 << 31) && p->n[D - 1] >= 2) {
+            bool pk = (ax_kin == P.axis[D - 1].n_prefix) && N.m_in <= kPackedMaxIn;   // last axis: state part + b[u_in] only
+            // canonical shape: last axis = state part + b[u_in]; <= 1 cost term per outer loop level;
+            // outer axes may have any terms (their cells/weights are precomputed below)
+            for (int i = 0; i < HJB_MAX_D + 2; ++i) { memset(&N.ot[i], 0, sizeof N.ot[i]); N.ot[i].lds_off = -1; }
+            int32_t ot_floats = 0;
+            auto fill = [&](DNested::DOuterTerm &o, const DTerm &t, uint32_t mask, bool first) {
+                o.data = t.data;
+                for (int a = 0; a < HJB_MAX_D; ++a) o.sstride[a] = a < D ? t.stride[a] : 0;
+                o.c0 = (C == 3) ? t.stride[D + 0] : 0;
+                o.c1 = (C == 3) ? t.stride[D + 1] : ((C == 2) ? t.stride[D + 0] : 0);
+                o.present = 1;
+                o.level = (C == 3 && !(mask & (1u << (D + 1)))) ? 0 : 1;
+                o.first = first ? 1 : 0;
+                o.lds_off = -1;
+                o.lds_len = 0;
+                if ((mask & ((1u << D) - 1u)) == 0) {      // control-only: stage the whole table in LDS
+                    o.lds_len = (int32_t)term_elems(p, mask);
+                    o.lds_off = ot_floats;
+                    ot_floats += o.lds_len;
+                }
+            };
+            if (pk) {
+                const int c0n = N.cost_l0 - P.n_cost_prefix, c1n = cost_kin - N.cost_l0;
+                if (c0n > 1 || c1n > 1) pk = false;
+                else {
+                    if (c0n == 1) {
+                        fill(N.ot[HJB_MAX_D], P.cost[P.n_cost_prefix], p->cost_terms[P.n_cost_prefix].mask, P.n_cost_prefix == 0);
+                        N.ot[HJB_MAX_D].level = 0;
+                    }
+                    if (c1n == 1) {
+                        fill(N.ot[HJB_MAX_D + 1], P.cost[N.cost_l0], p->cost_terms[N.cost_l0].mask,
+                             P.n_cost_prefix == 0 && c0n == 0);
+                        N.ot[HJB_MAX_D + 1].level = 1;
+                    }
+                }
+            }
+            h->packed_mode = pk ? 1 : 0;
+            h->packed_lds = (size_t)(N.m_in + 1) * 256 * 8 + (size_t)(N.m_in + 1) * 8 + (size_t)2 * p->n[D - 1] * 4 +
+                            (size_t)ot_floats * 4;
+            if (h->packed_lds > 64 * 1024) h->packed_mode = 0;
         }
     }
     void *dst = nullptr;
@@ -313,13 +384,73 @@ int build(Handle *h, const hjb_problem *p) {
     if (st) return st;
     h->dp = (DParams *)dpp;
     HIP_TRY(h, hipMemcpy(h->dp, &P, sizeof(DParams), hipMemcpyHostToDevice));
+    // ---- variant 2: precompute the stage-invariant (cell, weight) tables of the outer axes -------
+    if (h->packed_mode) {
+        DNested &N = h->hn;
+        const int owned_last = P.n[D - 1];
+        size_t total = 0;
+        bool fits = true;
+        int64_t nent[HJB_MAX_D] = {0};
+        uint32_t dom[HJB_MAX_D] = {0};
+        for (int a = 0; a < D - 1; ++a) {
+            uint32_t m = 0;
+            for (int k = 0; k < p->n_next_terms[a]; ++k) m |= p->next_terms[a][k].mask;
+            dom[a] = m;
+            int64_t ne = 1;
+            for (int d = 0; d < D + C; ++d)
+                if (m & (1u << d)) ne *= (d < D) ? (d == D - 1 ? owned_last : p->n[d]) : p->m[d - D];
+            nent[a] = ne;
+            if (ne >= ((int64_t)1 << 31)) fits = false;
+            total += (size_t)ne * sizeof(int2);
+        }
+        if (!fits || total > ((size_t)24 << 30)) {
+            h->packed_mode = 0;   // tables too large: variant 1 evaluates on the fly
+        } else {
+            for (int a = 0; a < D - 1; ++a) {
+                DNested::DAxisTable &A = N.at[a];
+                memset(&A, 0, sizeof A);
+                std::vector<int32_t> dsz(HJB_MAX_G, 1);
+                int64_t stride = 1;
+                for (int d = 0; d < D + C; ++d) {
+                    if (!(dom[a] & (1u << d))) continue;
+                    const int sz = (d < D) ? (d == D - 1 ? owned_last : p->n[d]) : p->m[d - D];
+                    dsz[d] = sz;
+                    if (d < D) A.sstride[d] = (int32_t)stride;
+                    else if (C == 3 && d == D + 0) A.c0 = (int32_t)stride;
+                    else if ((C == 3 && d == D + 1) || (C == 2 && d == D + 0)) A.c1 = (int32_t)stride;
+                    stride *= sz;
+                }
+                const bool has_o1 = (C >= 2) && (dom[a] & (1u << (D + C - 2)));
+                const bool has_o0 = (C == 3) && (dom[a] & (1u << D));
+                A.level = has_o1 ? 1 : (has_o0 ? 0 : -1);
+                void *dsz_d = nullptr, *tab = nullptr;
+                int st3 = upload(h, dsz, &dsz_d);
+                if (st3) return st3;
+                st3 = dev_alloc(h, (size_t)nent[a] * sizeof(int2), &tab);
+                if (st3) return st3;
+                const int grid = (int)std::min<int64_t>((nent[a] + 255) / 256, 65536);
+                launch_prep<T>(D, grid, h->dp, a, (const int32_t *)dsz_d, nent[a], (int2 *)tab);
+                A.tab = tab;
+            }
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipDeviceSynchronize());
+        }
+    }
+    if (h->nested_ok) {
+        void *dnn = nullptr;
+        int st2 = dev_alloc(h, sizeof(DNested), &dnn);
+        if (st2) return st2;
+        h->dn = (DNested *)dnn;
+        HIP_TRY(h, hipMemcpy(h->dn, &h->hn, sizeof(DNested), hipMemcpyHostToDevice));
+    }
     return HJB_OK;
 }
 
 void choose_launch(Handle *h) {
-    h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->nested_ok ? 1 : 0);
+    h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->packed_mode ? 2 : (h->nested_ok ? 1 : 0));
     h->block = 256;
-    int64_t blocks = (h->n_owned + h->block - 1) / h->block;
+    const int per_block = h->variant == 2 ? 512 : 256;   // variant 2: two states per lane
+    int64_t blocks = (h->n_owned + per_block - 1) / per_block;
     h->grid = (int)std::min<int64_t>(blocks, 256 * 16);
     if (h->grid < 1) h->grid = 1;
 }
@@ -328,6 +459,25 @@ template <typename T>
 int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t st) {
     const int D = h->hp.D;
     dim3 g(h->grid), b(h->block);
+    if (h->variant == 2) {
+        if constexpr (std::is_same<T, float>::value) {
+            const size_t lds = h->packed_lds;
+#define HJB_LAUNCH_PACKED(DD)                                                                                        \
+    case DD:                                                                                                         \
+        hipLaunchKernelGGL((k_backup_packed<DD>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);                       \
+        break;
+            switch (D) {
+                HJB_LAUNCH_PACKED(1) HJB_LAUNCH_PACKED(2) HJB_LAUNCH_PACKED(3) HJB_LAUNCH_PACKED(4) HJB_LAUNCH_PACKED(5)
+                HJB_LAUNCH_PACKED(6)
+                default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
+            }
+#undef HJB_LAUNCH_PACKED
+            HIP_TRY(h, hipGetLastError());
+            return HJB_OK;
+        } else {
+            return fail(h, HJB_E_UNSUPPORTED, "variant 2 is float32 only");
+        }
+    }
     if (h->variant == 1) {
         const size_t lds = h->nested_lds;
         switch (D) {
@@ -526,7 +676,7 @@ int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
     info->n_controls = h->nU;
     info->j_elems = h->j_elems;
     info->kernel_variant = h->variant;
-    info->lds_bytes = h->variant == 1 ? (int32_t)h->nested_lds : 0;
+    info->lds_bytes = h->variant == 2 ? (int32_t)h->packed_lds : (h->variant == 1 ? (int32_t)h->nested_lds : 0);
     info->block = h->block;
     info->grid = h->grid;
     info->halo_needed_lo = h->halo_need_lo;
@@ -538,7 +688,9 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     Handle *h = (Handle *)hh;
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) {
-        if (value < -1 || value > 1) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value < -1 || value > 2) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value == 2 && !h->packed_mode)
+            return fail(h, HJB_E_UNSUPPORTED, "variant 2 (packed) needs float32 and the canonical spacecraft structure (see kernels_packed.h)");
         if (value == 1 && !h->nested_ok)
             return fail(h, HJB_E_UNSUPPORTED, "variant 1 (control-nested) needs: only the last state axis depends on the innermost control dim");
         h->forced_variant = (int)value;

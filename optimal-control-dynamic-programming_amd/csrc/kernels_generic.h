@@ -170,4 +170,44 @@ k_backup_generic(const DParams *__restrict__ P, const T *__restrict__ Jn, T *__r
     }
 }
 
+// Stage-invariant per-axis (cell, weight) table over the axis' broadcast domain
+// (used by variant 2).  One thread per domain entry; same canonical arithmetic as
+// the stage kernels: q = ordered term sum, exact cell search, t = (q-k[c])*rdx[c].
+// dom_size[d] = grid size of dim d if d is in the domain, else 1; entries are laid
+// out column-major over the domain dims in increasing dim order.
+template <typename T, int D>
+__global__ void __launch_bounds__(256)
+k_prep_axis_table(const DParams *__restrict__ P, int a, const int32_t *__restrict__ dom_size, int64_t n_entries,
+                  int2 *__restrict__ out) {
+    const DAxis &ax = P->axis[a];
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_entries;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        int si[D];
+        int cj[HJB_MAX_C] = {0, 0, 0};
+        int64_t r = e;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int sz = dom_size[d];
+            si[d] = (int)(r % sz);
+            r /= sz;
+        }
+#pragma unroll
+        for (int c = 0; c < HJB_MAX_C; ++c) {
+            const int sz = dom_size[D + c];
+            cj[c] = (int)(r % sz);
+            r /= sz;
+        }
+        si[D - 1] += P->slab_begin;   // term tables are indexed by GLOBAL grid indices; the domain covers owned planes
+        T q = (T)0;
+        for (int k = 0; k < ax.n_terms; ++k) {
+            T x = term_value<T, D>(ax.t[k], si, cj);
+            q = (k == 0) ? x : (T)(q + x);
+        }
+        const T *kk = static_cast<const T *>(ax.knots);
+        const int cell = find_cell<T>(kk, ax.n, q, ax.uniform, (T)ax.x0, (T)ax.inv_h);
+        const float t = (float)((T)((T)(q - kk[cell]) * static_cast<const T *>(ax.rdx)[cell]));
+        out[e] = make_int2(cell, __float_as_int(t));
+    }
+}
+
 }  // namespace hjb

@@ -40,7 +40,39 @@ struct DNested {
     int32_t cost_kin;     // first cost term that is evaluated per control
     int32_t n_ax_in, n_cost_in;
     int32_t n_slots, pad;
+    // Outer control loops: o0 over m_o0 (control dim 0 when C == 3, else 1 trip),
+    // o1 over m_o1 (control dim C-2 when C >= 2, else 1 trip).  A term is evaluated
+    // at the outermost level that keeps the left-to-right order: terms
+    // [n_prefix, l0) once per o0 step, [l0, end) once per (o0,o1) step.
+    int32_t m_o0, m_o1;
+    int32_t ax_l0[HJB_MAX_D];   // per axis (last axis: end bounded by ax_kin)
+    int32_t cost_l0;
+    int32_t pad2;
     DInnerTerm in[kMaxInner];  // [0,n_ax_in): last-axis terms, [kMaxInAx, kMaxInAx+n_cost_in): cost
+    // Variant 2 (packed) only: the canonical shape has at most ONE non-prefix,
+    // non-inner term per axis and one cost term per outer level.  ot[a] (a < D):
+    // axis a's outer term; ot[HJB_MAX_D], ot[HJB_MAX_D+1]: the cost's level-0 / level-1 term.
+    struct DOuterTerm {
+        const void *data;
+        int32_t sstride[HJB_MAX_D];  // element strides along the state dims
+        int32_t c0, c1;              // element strides along the o0 / o1 loop counters
+        int32_t present;             // 0: no such term
+        int32_t level;               // 0: evaluate once per o0 step, 1: once per (o0,o1) step
+        int32_t first;               // 1: it is the first term of its sum (no prefix before it)
+        int32_t lds_off;             // >= 0: control-only table staged in LDS at this float offset; -1: global
+        int32_t lds_len;             // elements staged
+        int32_t pad;
+    } ot[HJB_MAX_D + 2];
+    // Variant 2: stage-invariant (cell, weight) of every outer axis a < D-1, precomputed at
+    // hjb_create over the axis' own broadcast domain (union of its terms' masks) with the
+    // canonical arithmetic: entry = {int32 cell, float t}.
+    struct DAxisTable {
+        const void *tab;             // int2-sized entries
+        int32_t sstride[HJB_MAX_D];  // entry strides along the state dims of the domain (0 = not in domain)
+        int32_t c0, c1;              // entry strides along the o0 / o1 loop counters
+        int32_t level;               // -1: state-only domain, 0: changes per o0 step, 1: per (o0,o1) step
+        int32_t pad;
+    } at[HJB_MAX_D];
 };
 
 // per-axis tracked cell
@@ -172,30 +204,64 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
 
         T best = (T)0;
         int best_uo = 0, best_j = 0;
-        for (int uo = 0; uo < nUo; ++uo) {
-            // ---- once per outer control step -------------------------------
+        const int m_o0 = N->m_o0, m_o1 = N->m_o1;
+        int uo = 0;
+        for (int o0 = 0; o0 < m_o0; ++o0) {
+            if (C == 3) cj[0] = o0;
+            // ---- level 0: once per step of the outermost control dim ----------
             T tw[D > 1 ? D - 1 : 1];
-            int64_t base = 0;
+            T q0[D > 1 ? D - 1 : 1];
 #pragma unroll
             for (int a = 0; a < D - 1; ++a) {
                 const DAxis &ax = P->axis[a];
                 T q = qpre[a];
-                for (int k = ax.n_prefix; k < ax.n_terms; ++k) {
+                for (int k = ax.n_prefix; k < N->ax_l0[a]; ++k) {
                     T x = term_value<T, D>(ax.t[k], si, cj);
                     q = (k == 0) ? x : (T)(q + x);
                 }
-                track_update<T>(trk[a], static_cast<const T *>(ax.knots), static_cast<const T *>(ax.rdx), ax.n, q,
-                                ax.uniform, (T)ax.x0, (T)ax.inv_h);
-                tw[a] = (T)((T)(q - trk[a].kc) * trk[a].rc);
+                q0[a] = q;
+                if (N->ax_l0[a] == ax.n_terms) {   // fully resolved at this level
+                    track_update<T>(trk[a], static_cast<const T *>(ax.knots), static_cast<const T *>(ax.rdx), ax.n, q,
+                                    ax.uniform, (T)ax.x0, (T)ax.inv_h);
+                    tw[a] = (T)((T)(q - trk[a].kc) * trk[a].rc);
+                }
+            }
+            T qo0 = qpre[D - 1];
+            for (int k = axl.n_prefix; k < N->ax_l0[D - 1]; ++k) {
+                T x = term_value<T, D>(axl.t[k], si, cj);
+                qo0 = (k == 0) ? x : (T)(qo0 + x);
+            }
+            T go0 = gpre;
+            for (int k = P->n_cost_prefix; k < N->cost_l0; ++k) {
+                T x = term_value<T, D>(P->cost[k], si, cj);
+                go0 = (k == 0) ? x : (T)(go0 + x);
+            }
+          for (int o1 = 0; o1 < m_o1; ++o1, ++uo) {
+            if (C == 3) cj[1] = o1; else if (C == 2) cj[0] = o1;
+            // ---- level 1: once per outer control step --------------------------
+            int64_t base = 0;
+#pragma unroll
+            for (int a = 0; a < D - 1; ++a) {
+                const DAxis &ax = P->axis[a];
+                if (N->ax_l0[a] != ax.n_terms) {
+                    T q = q0[a];
+                    for (int k = N->ax_l0[a]; k < ax.n_terms; ++k) {
+                        T x = term_value<T, D>(ax.t[k], si, cj);
+                        q = (k == 0) ? x : (T)(q + x);
+                    }
+                    track_update<T>(trk[a], static_cast<const T *>(ax.knots), static_cast<const T *>(ax.rdx), ax.n, q,
+                                    ax.uniform, (T)ax.x0, (T)ax.inv_h);
+                    tw[a] = (T)((T)(q - trk[a].kc) * trk[a].rc);
+                }
                 base += P->jstride[a] * trk[a].cell;
             }
-            T qo = qpre[D - 1];
-            for (int k = axl.n_prefix; k < ax_kin; ++k) {
+            T qo = qo0;
+            for (int k = N->ax_l0[D - 1]; k < ax_kin; ++k) {
                 T x = term_value<T, D>(axl.t[k], si, cj);
                 qo = (k == 0) ? x : (T)(qo + x);
             }
-            T go = gpre;
-            for (int k = P->n_cost_prefix; k < cost_kin; ++k) {
+            T go = go0;
+            for (int k = N->cost_l0; k < cost_kin; ++k) {
                 T x = term_value<T, D>(P->cost[k], si, cj);
                 go = (k == 0) ? x : (T)(go + x);
             }
@@ -318,13 +384,8 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                     }
                 }
             }
-            // next outer control: dims 0..C-2, dim C-2 fastest
-            if (C == 3) {
-                if (++cj[1] == P->m[1]) { cj[1] = 0; ++cj[0]; }
-            } else if (C == 2) {
-                ++cj[0];
-            }
-        }
+          }  // o1
+        }  // o0
         // visiting order (dim 0 slowest) -> column-major label (dim 0 fastest)
         int64_t label;
         if (C == 1) {

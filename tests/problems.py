@@ -57,7 +57,7 @@ def random_terminal(spec, seed=0):
     return rng.random(spec.nS).astype(spec.dtype)
 
 
-def nested_problem(seed, n, m, dtype=np.float32, nonuniform=False, spread=0.2, mixed_inner=False):
+def nested_problem(seed, n, m, dtype=np.float32, nonuniform=False, spread=0.2, mixed_inner=False, monotone=None):
     """Structure of the spacecraft solvers: control dim c drives state axis
     D-C+c only (the innermost control dim drives the LAST axis); every axis also
     couples to other state dims.  mixed_inner adds an inner term that also
@@ -86,7 +86,10 @@ def nested_problem(seed, n, m, dtype=np.float32, nonuniform=False, spread=0.2, m
                 d = int(others[0])
                 dims = tuple(sorted((d, D + c)))
                 terms.append(Term(dims, spread * rng.standard_normal(tuple(g[x] for x in dims))))
-            terms.append(Term((D + c,), spread * rng.standard_normal(g[D + c])))
+            tab = spread * rng.standard_normal(g[D + c])
+            if monotone and c == C - 1:       # monotone inner control table (what real actuator levels are)
+                tab = np.sort(tab) if monotone == "inc" else np.sort(tab)[::-1].copy()
+            terms.append(Term((D + c,), tab))
         nxt.append(terms)
     cost = [Term((a,), (1.0 + a) * knots[a] ** 2) for a in range(D)]
     for c in range(C):

@@ -119,7 +119,7 @@ def test_nested_variant_bit_exact(env, n, m, dtype, nonuniform, mixed):
     from problems import nested_problem, random_terminal
     spec = nested_problem(4321 + len(n), n, m, dtype=dtype, nonuniform=nonuniform, mixed_inner=mixed)
     term = random_terminal(spec, 9)
-    with hjbdp.Backup(spec) as bk:
+    with hjbdp.Backup(spec, variant=1) as bk:
         assert bk.info()["kernel_variant"] == 1
         out = bk.solve(4, terminal=term, keep_J=True, keep_idx=True)
     with hjbdp.Backup(spec, variant=0) as bk:
@@ -131,13 +131,59 @@ def test_nested_variant_bit_exact(env, n, m, dtype, nonuniform, mixed):
         assert np.array_equal(o["idx_stages"], ref["idx_stages"])
 
 
+PACKED = [
+    ((9, 8), (3,), False, "inc"),
+    ((40, 37), (7,), True, "dec"),                 # > 512 states, odd tail
+    ((9, 8, 7), (5, 4, 3), False, "inc"),          # C2 shape, 504 states (< one workgroup pass)
+    ((13, 11, 9), (4, 5), True, "dec"),
+    ((6, 5, 4, 5), (3, 4), False, "inc"),
+    ((4, 3, 4, 3, 3, 5), (3, 3, 3), False, "dec"),  # C3 shape
+]
+
+
+@pytest.mark.parametrize("n,m,nonuniform,mono", PACKED)
+def test_packed_variant_bit_exact(env, n, m, nonuniform, mono):
+    """Variant 2 (two states per lane, packed fp32, one-sided cell test) is chosen
+    for float32 spacecraft-shaped problems with a monotone inner control table and
+    agrees bit for bit with the oracle; large spread forces many cell crossings."""
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    spec = nested_problem(777 + len(n), n, m, dtype=np.float32, nonuniform=nonuniform, monotone=mono, spread=0.45)
+    term = random_terminal(spec, 11)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 2
+        out = bk.solve(4, terminal=term, keep_J=True, keep_idx=True)
+    ref = c_oracle.sweep(_abi, spec, 4, terminal=term, keep_J=True, keep_idx=True)
+    assert np.array_equal(out["J_stages"], ref["J_stages"])
+    assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+    for v in (0, 1):
+        with hjbdp.Backup(spec, variant=v) as bk:
+            o = bk.solve(4, terminal=term)
+        assert np.array_equal(o["J"], ref["J"]) and np.array_equal(o["idx"], ref["idx"])
+
+
+def test_packed_variant_slab(env):
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    spec = nested_problem(55, (9, 8, 14), (4, 3), dtype=np.float32, monotone="inc", spread=0.1)
+    term = random_terminal(spec, 3)
+    Jw, iw = c_oracle.backup_stage(_abi, spec, term)
+    T3 = term.reshape(72, 14, order="F")
+    b, e, lo, hi = 5, 10, 2, 2
+    with hjbdp.Backup(spec, slab=(b, e, lo, hi)) as bk:
+        assert bk.info()["kernel_variant"] == 2
+        Jo, io = bk.backup_stage(np.asfortranarray(T3[:, b - lo:e + hi]).reshape(-1, order="F"))
+    assert np.array_equal(Jo.reshape(72, -1, order="F")[:, lo:lo + e - b], Jw.reshape(72, 14, order="F")[:, b:e])
+    assert np.array_equal(io, iw.reshape(72, 14, order="F")[:, b:e].reshape(-1, order="F"))
+
+
 def test_c2_workload_small_bit_exact(env):
     """BASELINE configs[1] (Solver_position 3-DOF) at a size the oracle finishes in seconds."""
     hjbdp, _abi, c_oracle = env
     from hjbdp.synthetic import position3d_spec
     spec = position3d_spec(n=15, mu=7)
     with hjbdp.Backup(spec) as bk:
-        assert bk.info()["kernel_variant"] == 1
+        assert bk.info()["kernel_variant"] == 2
         out = bk.solve(6, keep_J=True, keep_idx=True)
     ref = c_oracle.sweep(_abi, spec, 6, keep_J=True, keep_idx=True)
     assert np.array_equal(out["J_stages"], ref["J_stages"])
