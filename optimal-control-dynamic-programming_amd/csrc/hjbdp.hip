@@ -18,6 +18,7 @@
 #include "kernels_generic.h"
 #include "kernels_nested.h"
 #include "kernels_packed.h"
+#include "kernels_ctrlsplit.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -47,6 +48,7 @@ struct Handle {
     bool nested_ok = false;
     bool nested_fast = false;
     int packed_mode = 0;          // variant 2 eligibility
+    bool split_j_in_lds = false;  // variant 3: whole J buffer staged in LDS
     size_t packed_lds = 0;
     size_t nested_lds = 0;
     int variant = 0;
@@ -447,11 +449,15 @@ int build(Handle *h, const hjb_problem *p) {
 }
 
 void choose_launch(Handle *h) {
-    h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->packed_mode ? 2 : (h->nested_ok ? 1 : 0));
+    // few states x many controls (Kirk): one wave per state, controls across lanes
+    const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
+    h->variant = h->forced_variant >= 0 ? h->forced_variant
+                                        : (h->packed_mode ? 2 : (h->nested_ok ? 1 : (want_split ? 3 : 0)));
     h->block = 256;
-    const int per_block = h->variant == 2 ? 512 : 256;   // variant 2: two states per lane
+    h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
+    const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass
     int64_t blocks = (h->n_owned + per_block - 1) / per_block;
-    h->grid = (int)std::min<int64_t>(blocks, 256 * 16);
+    h->grid = (int)std::min<int64_t>(blocks, h->variant == 3 ? 1024 : 256 * 16);
     if (h->grid < 1) h->grid = 1;
 }
 
@@ -459,6 +465,22 @@ template <typename T>
 int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t st) {
     const int D = h->hp.D;
     dim3 g(h->grid), b(h->block);
+    if (h->variant == 3) {
+        const size_t lds = h->split_j_in_lds ? (size_t)h->j_elems * sizeof(T) : 0;
+#define HJB_LAUNCH_SPLIT(DD)                                                                                         \
+    case DD:                                                                                                         \
+        if (h->split_j_in_lds) hipLaunchKernelGGL((k_backup_ctrlsplit<T, DD, true>), g, b, lds, st, h->dp, dJn, dJo, didx); \
+        else hipLaunchKernelGGL((k_backup_ctrlsplit<T, DD, false>), g, b, 0, st, h->dp, dJn, dJo, didx);              \
+        break;
+        switch (D) {
+            HJB_LAUNCH_SPLIT(1) HJB_LAUNCH_SPLIT(2) HJB_LAUNCH_SPLIT(3) HJB_LAUNCH_SPLIT(4) HJB_LAUNCH_SPLIT(5)
+            HJB_LAUNCH_SPLIT(6)
+            default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
+        }
+#undef HJB_LAUNCH_SPLIT
+        HIP_TRY(h, hipGetLastError());
+        return HJB_OK;
+    }
     if (h->variant == 2) {
         if constexpr (std::is_same<T, float>::value) {
             const size_t lds = h->packed_lds;
@@ -676,7 +698,9 @@ int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
     info->n_controls = h->nU;
     info->j_elems = h->j_elems;
     info->kernel_variant = h->variant;
-    info->lds_bytes = h->variant == 2 ? (int32_t)h->packed_lds : (h->variant == 1 ? (int32_t)h->nested_lds : 0);
+    info->lds_bytes = h->variant == 2 ? (int32_t)h->packed_lds
+                      : (h->variant == 1 ? (int32_t)h->nested_lds
+                      : (h->variant == 3 && h->split_j_in_lds ? (int32_t)(h->j_elems * h->esz) : 0));
     info->block = h->block;
     info->grid = h->grid;
     info->halo_needed_lo = h->halo_need_lo;
@@ -688,7 +712,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     Handle *h = (Handle *)hh;
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) {
-        if (value < -1 || value > 2) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value < -1 || value > 3) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
         if (value == 2 && !h->packed_mode)
             return fail(h, HJB_E_UNSUPPORTED, "variant 2 (packed) needs float32 and the canonical spacecraft structure (see kernels_packed.h)");
         if (value == 1 && !h->nested_ok)

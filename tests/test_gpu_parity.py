@@ -81,7 +81,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [None, 0])
+@pytest.mark.parametrize("variant", [None, 0, 3])
 @pytest.mark.parametrize("n,m,dtype,nonuniform", SHAPES)
 def test_random_problems_bit_exact(env, n, m, dtype, nonuniform, variant):
     hjbdp, _abi, c_oracle = env
@@ -198,6 +198,26 @@ def test_variant_1_refused_when_not_applicable(env):
         with pytest.raises(hjbdp.HjbError) as ei:
             bk.set_option("variant", 1)
         assert ei.value.status == _abi.HJB_E_UNSUPPORTED
+
+
+def test_ctrlsplit_variant_selected_for_kirk(env):
+    """Few states x many controls -> variant 3 (wave min-reduction over the control axis),
+    J staged in LDS; ties across lanes keep the first index."""
+    hjbdp, _abi, c_oracle = env
+    spec = _kirk(hjbdp, "single", 6, 40, 300).build_spec()
+    with hjbdp.Backup(spec) as bk:
+        inf = bk.info()
+        assert inf["kernel_variant"] == 3 and inf["lds_bytes"] == 40 * 40 * 4
+        out = bk.solve(5, keep_J=True, keep_idx=True)
+    ref = c_oracle.sweep(_abi, spec, 5, keep_J=True, keep_idx=True)
+    assert np.array_equal(out["J_stages"], ref["J_stages"]) and np.array_equal(out["idx_stages"], ref["idx_stages"])
+    # every control ties (cost and next state independent of u): label must be the first
+    k = np.linspace(-1, 1, 7)
+    tie = hjbdp.ProblemSpec([k, k], [200], [[hjbdp.Term((0,), k)], [hjbdp.Term((1,), k)]],
+                            [hjbdp.Term((0,), k ** 2), hjbdp.Term((2,), np.zeros(200))], dtype=np.float64, index_base=1)
+    with hjbdp.Backup(tie, variant=3) as bk:
+        J, idx = bk.backup_stage(np.arange(49, dtype=np.float64))
+    assert np.all(idx == 1)
 
 
 def test_exact_ties_first_index_wins(env):

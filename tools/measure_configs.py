@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Times the reference-sized configurations (and the C4 synthetic grid) on one
+MI355X through the host mirrors; prints a markdown table.  Not a test, not the
+bench contract - it feeds the numbers quoted in DESIGN.md / README.md."""
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "optimal-control-dynamic-programming_amd"))
+import numpy as np
+import hjbdp
+from hjbdp.matlab_compat import sym_linspace_pos_att
+
+rows = []
+
+
+def add(name, backups, ms, variant, note=""):
+    rows.append((name, backups, ms, backups / (ms * 1e-3), variant, note))
+
+
+def solve_timed(spec, n_st, **kw):
+    with hjbdp.Backup(spec) as bk:
+        bk.solve(min(n_st, 3))
+        out = bk.solve(n_st, **kw)
+        v = bk.info()["kernel_variant"]
+    return out, v
+
+
+ds = hjbdp.Dynamic_Solver(precision="double"); ds.N, ds.dx, ds.du = 130, 35, 100
+out, v = solve_timed(ds.build_spec(), 129, keep_J=True, keep_idx=True)
+add("C1a Kirk fixture 35x35x100, 129 stages, f64", 35 * 35 * 100 * 129, out["sweep_ms"], v)
+ds = hjbdp.Dynamic_Solver()
+out, v = solve_timed(ds.build_spec(), 199, keep_J=True, keep_idx=True)
+add("C1b Kirk defaults 100x100x1000, 199 stages, f32", 100 * 100 * 1000 * 199, out["sweep_ms"], v)
+sp = hjbdp.Solver_position()
+spec, _, _ = sp.build_spec(0)
+out, v = solve_timed(spec, 5999)
+add("Solver_position channel 201x201x3, 5999 stages, f64", spec.nS * 3 * 5999, out["sweep_ms"], v, "launch-bound")
+sa = hjbdp.Solver_attitude()
+spec, _, _ = sa.build_spec_simplified(0)
+out, v = solve_timed(spec, 5999)
+add("Solver_attitude simplified channel 1000x300x3, 5999 stages, f64", spec.nS * 3 * 5999, out["sweep_ms"], v)
+sa = hjbdp.Solver_attitude(n_mesh_w=11, n_mesh_q=10)
+spec = sa.build_spec_full()
+out, v = solve_timed(spec, 19)
+add("Solver_attitude.run 11^3x10^3 x 27, 19 stages, f32", spec.nS * 27 * 19, out["sweep_ms"], v)
+pa = hjbdp.Solver_pos_att()
+sx, sv, st, sw = pa.grids()
+spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
+out, v = solve_timed(spec, 1999, monitor_period=50, monitor_tol=1e-2)
+add("Solver_pos_att channel 30x30x20x15 x 9, <=1999 stages (monitor), f32", spec.nS * 9 * out["stages_done"],
+    out["sweep_ms"], v, "stopped after %d stages" % out["stages_done"])
+# C4: 120^4 x 9, terms cost mode
+pa.cost_mode = "terms"
+pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = 120
+sx, sv, st, sw = pa.grids()
+spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
+out, v = solve_timed(spec, 5)
+add("C4 pos-att 120^4 x 9, 5 stages, f32", spec.nS * 9 * 5, out["sweep_ms"], v)
+print("| config | backups | sweep ms | backups/s | kernel variant | note |")
+print("|---|---|---|---|---|---|")
+for r in rows:
+    print("| %s | %.3g | %.2f | %.3g | %d | %s |" % r)
