@@ -25,6 +25,8 @@ using namespace hjb;
 
 namespace {
 
+constexpr int kGraphStages = 32;   // even: a replay starts and ends in dJ[0]
+
 thread_local std::string g_last_error;
 
 struct Handle {
@@ -49,6 +51,11 @@ struct Handle {
     bool nested_fast = false;
     int packed_mode = 0;          // variant 2 eligibility
     bool split_j_in_lds = false;  // variant 3: whole J buffer staged in LDS
+    // launch-bound sweeps: the ping-pong stage loop captured once into a hipGraph of kGraphStages launches
+    hipStream_t stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int gexec_variant = -1;
+    bool use_graph = true;
     size_t packed_lds = 0;
     size_t nested_lds = 0;
     int variant = 0;
@@ -449,6 +456,7 @@ int build(Handle *h, const hjb_problem *p) {
 }
 
 void choose_launch(Handle *h) {
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     // few states x many controls (Kirk): one wave per state, controls across lanes
     const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
     h->variant = h->forced_variant >= 0 ? h->forced_variant
@@ -686,6 +694,8 @@ int32_t hjb_destroy(hjb_handle hh) {
     if (!h) return HJB_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     for (void *d : h->allocs) (void)hipFree(d);
     delete h;
     return HJB_OK;
@@ -719,6 +729,10 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             return fail(h, HJB_E_UNSUPPORTED, "variant 1 (control-nested) needs: only the last state axis depends on the innermost control dim");
         h->forced_variant = (int)value;
         choose_launch(h);
+        return HJB_OK;
+    }
+    if (!strcmp(key, "graph")) {
+        h->use_graph = value != 0;
         return HJB_OK;
     }
     return fail(h, HJB_E_INVALID, "unknown option '%s'", key);
@@ -769,7 +783,8 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     if (st) return st;
     const int64_t nS = h->n_owned;
     const size_t jb = (size_t)nS * h->esz;
-    hipStream_t stream = nullptr;
+    if (!h->stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    hipStream_t stream = h->stream;
     // optional per-stage capture: kernels write straight into the stage planes
     char *dJst = nullptr;
     int32_t *dIst = nullptr;
@@ -802,6 +817,27 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     } while (0)
     if (o->terminal) SOLVE_TRY(hipMemcpy(h->dJ[0], o->terminal, jb, hipMemcpyHostToDevice));
     else SOLVE_TRY(hipMemset(h->dJ[0], 0, jb));
+    SOLVE_TRY(hipDeviceSynchronize());   // the sweep runs on the handle's own stream from here
+    // launch-bound sweeps: replay kGraphStages ping-pong launches per hipGraphLaunch
+    const bool graph_ok = h->use_graph && !dJst && !dIst && o->n_stages >= 2 * kGraphStages;
+    if (graph_ok && !h->gexec) {
+        hipGraph_t graph = nullptr;
+        SOLVE_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int cst = HJB_OK;
+        for (int i = 0; i < kGraphStages / 2 && cst == HJB_OK; ++i) {
+            cst = launch_stage(h, h->dJ[0], h->dJ[1], h->d_idx, stream);
+            if (cst == HJB_OK) cst = launch_stage(h, h->dJ[1], h->dJ[0], h->d_idx, stream);
+        }
+        hipError_t ce = hipStreamEndCapture(stream, &graph);
+        if (cst != HJB_OK || ce != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            cleanup();
+            return fail(h, HJB_E_DEVICE, "stage-loop graph capture failed: %s", hipGetErrorString(ce));
+        }
+        ce = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ce != hipSuccess) { cleanup(); return fail(h, HJB_E_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(ce)); }
+    }
     hipEvent_t ev0, ev1;
     SOLVE_TRY(hipEventCreate(&ev0));
     SOLVE_TRY(hipEventCreate(&ev1));
@@ -811,16 +847,35 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     int32_t *cur_idx = h->d_idx;
     int done = 0, early = 0;
     double fprev = 0, iprev = 0, e = 0, e2 = 0;
-    for (int k_s = o->n_stages; k_s >= 1; --k_s) {
-        void *outJ = dJst ? (void *)(dJst + (size_t)(k_s - 1) * jb) : h->dJ[pp];
-        int32_t *outI = dIst ? dIst + (size_t)(k_s - 1) * nS : h->d_idx;
-        st = launch_stage(h, cur, outJ, outI, stream);
-        if (st) { cleanup(); return st; }
-        cur = outJ;
-        cur_idx = outI;
-        if (!dJst) pp ^= 1;
-        ++done;
-        if (o->monitor_period > 0 && (k_s % o->monitor_period) == 0) {
+    int k_s = o->n_stages;
+    while (k_s >= 1) {
+        // stages up to and including the next monitor point (or all of them)
+        int stop = 1;
+        if (o->monitor_period > 0) stop = std::max(1, (k_s / o->monitor_period) * o->monitor_period);
+        int run = k_s - stop + 1;
+        if (graph_ok && run >= kGraphStages) {
+            if (pp == 0) {   // make dJ[0] the current buffer: one eager stage
+                st = launch_stage(h, cur, h->dJ[pp], h->d_idx, stream);
+                if (st) { cleanup(); return st; }
+                cur = h->dJ[pp]; pp ^= 1; ++done; --run; --k_s;
+            }
+            while (run >= kGraphStages) {
+                SOLVE_TRY(hipGraphLaunch(h->gexec, stream));
+                done += kGraphStages; run -= kGraphStages; k_s -= kGraphStages;
+            }
+        }
+        for (; run > 0; --run, --k_s) {
+            void *outJ = dJst ? (void *)(dJst + (size_t)(k_s - 1) * jb) : h->dJ[pp];
+            int32_t *outI = dIst ? dIst + (size_t)(k_s - 1) * nS : h->d_idx;
+            st = launch_stage(h, cur, outJ, outI, stream);
+            if (st) { cleanup(); return st; }
+            cur = outJ;
+            cur_idx = outI;
+            if (!dJst) pp ^= 1;
+            ++done;
+        }
+        // here k_s == stop - 1; the stage just computed has reference index `stop`
+        if (o->monitor_period > 0 && (stop % o->monitor_period) == 0) {
             // Solver_pos_att.m:273-285: fsum50 = sum(F.Values(:)), idsum50 = sum(U_Optimal_id(:))
             st = launch_monitor_sums(h->dtype, cur, cur_idx, nS, h->d_partials, h->d_sums, stream);
             if (st != HJB_OK) { cleanup(); return fail(h, HJB_E_DEVICE, "monitor reduction launch failed"); }
@@ -836,7 +891,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
                 (void)hipEventRecord(ev1, stream);
                 (void)hipEventSynchronize(ev1);
                 (void)hipEventElapsedTime(&ms, ev0, ev1);
-                o->progress(o->progress_user, k_s, e, e2, ms * 1e-3);
+                o->progress(o->progress_user, stop, e, e2, ms * 1e-3);
             }
             if (std::fabs(e) < o->monitor_tol) { early = 1; break; }
         }

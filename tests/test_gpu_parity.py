@@ -301,6 +301,27 @@ def test_monitor_early_stop_matches_oracle(env):
     assert out["last_e2"] == ref["last_e2"]
 
 
+@pytest.mark.parametrize("monitor", [0, 40])
+def test_graph_replay_matches_eager_and_oracle(env, monitor):
+    """Long sweeps replay the ping-pong stage loop from a hipGraph (32 launches per
+    replay); results, stage counts and the monitor must not change."""
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    spec = nested_problem(8, (12, 11), (3,), dtype=np.float64, spread=0.05)
+    term = random_terminal(spec, 4)
+    n_st = 151                                     # odd: exercises the parity-fixing eager stage
+    with hjbdp.Backup(spec) as bk:
+        a = bk.solve(n_st, terminal=term, monitor_period=monitor, monitor_tol=0.0)
+        a2 = bk.solve(n_st, terminal=term, monitor_period=monitor, monitor_tol=0.0)   # cached graph
+        bk.set_option("graph", 0)
+        b = bk.solve(n_st, terminal=term, monitor_period=monitor, monitor_tol=0.0)
+    ref = c_oracle.sweep(_abi, spec, n_st, terminal=term, monitor_period=monitor, monitor_tol=0.0)
+    for o in (a, a2, b):
+        assert o["stages_done"] == n_st
+        assert np.array_equal(o["J"], ref["J"]) and np.array_equal(o["idx"], ref["idx"])
+        assert o["last_e2"] == ref["last_e2"]
+
+
 def test_device_buffer_entry_point_with_torch(env):
     """hjb_backup_stage_device on torch-owned HBM buffers and a torch stream."""
     hjbdp, _abi, c_oracle = env
