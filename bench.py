@@ -162,7 +162,7 @@ def main():
                    "kernel_variant": info["kernel_variant"]},
         "roofline": {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                     "kernel": {2: "k_backup_packed<3>", 1: "k_backup_nested<float,3,true>"}.get(info["kernel_variant"], "k_backup_generic<float,3>"),
+                     "kernel": {4: "k_backup_packed2<3>", 2: "k_backup_packed<3>", 1: "k_backup_nested<float,3,true>"}.get(info["kernel_variant"], "k_backup_generic<float,3>"),
                      "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(D),
                      "note": "fp32 vector (VALU) roofline binds (SURVEY 8d); peak = MI355X fp32 vector = f32-MFMA rate",
                      "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,

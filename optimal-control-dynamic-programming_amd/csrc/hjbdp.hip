@@ -18,6 +18,7 @@
 #include "kernels_generic.h"
 #include "kernels_nested.h"
 #include "kernels_packed.h"
+#include "kernels_packed2.h"
 #include "kernels_ctrlsplit.h"
 #include "kernels_reduce.h"
 
@@ -57,6 +58,8 @@ struct Handle {
     int gexec_variant = -1;
     bool use_graph = true;
     size_t packed_lds = 0;
+    size_t packed2_lds = 0;       // variant 4 (two controls per packed op)
+    size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
     size_t nested_lds = 0;
     int variant = 0;
     int forced_variant = -1;
@@ -379,6 +382,11 @@ int build(Handle *h, const hjb_problem *p) {
             h->packed_mode = pk ? 1 : 0;
             h->packed_lds = (size_t)(N.m_in + 1) * 256 * 8 + (size_t)(N.m_in + 1) * 8 + (size_t)2 * p->n[D - 1] * 4 +
                             (size_t)ot_floats * 4;
+            {
+                const size_t np = (size_t)(N.m_in + 1) / 2;
+                h->packed2_lds = (np + 1) * 256 * 8 + (np + 1) * 8 + (size_t)N.m_in * 4 + (size_t)2 * p->n[D - 1] * 4 +
+                                 (size_t)ot_floats * 4;
+            }
             if (h->packed_lds > 64 * 1024) h->packed_mode = 0;
         }
     }
@@ -460,10 +468,10 @@ void choose_launch(Handle *h) {
     // few states x many controls (Kirk): one wave per state, controls across lanes
     const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
     h->variant = h->forced_variant >= 0 ? h->forced_variant
-                                        : (h->packed_mode ? 2 : (h->nested_ok ? 1 : (want_split ? 3 : 0)));
+                                        : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : 0)));
     h->block = 256;
     h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
-    const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass
+    const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass (variant 4: 256)
     int64_t blocks = (h->n_owned + per_block - 1) / per_block;
     h->grid = (int)std::min<int64_t>(blocks, h->variant == 3 ? 1024 : 256 * 16);
     if (h->grid < 1) h->grid = 1;
@@ -488,6 +496,25 @@ int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t s
 #undef HJB_LAUNCH_SPLIT
         HIP_TRY(h, hipGetLastError());
         return HJB_OK;
+    }
+    if (h->variant == 4) {
+        if constexpr (std::is_same<T, float>::value) {
+            const size_t lds = h->packed2_lds + h->lds_pad;
+#define HJB_LAUNCH_PACKED2(DD)                                                                                       \
+    case DD:                                                                                                         \
+        hipLaunchKernelGGL((k_backup_packed2<DD>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);                      \
+        break;
+            switch (D) {
+                HJB_LAUNCH_PACKED2(1) HJB_LAUNCH_PACKED2(2) HJB_LAUNCH_PACKED2(3) HJB_LAUNCH_PACKED2(4)
+                HJB_LAUNCH_PACKED2(5) HJB_LAUNCH_PACKED2(6)
+                default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
+            }
+#undef HJB_LAUNCH_PACKED2
+            HIP_TRY(h, hipGetLastError());
+            return HJB_OK;
+        } else {
+            return fail(h, HJB_E_UNSUPPORTED, "variant 4 is float32 only");
+        }
     }
     if (h->variant == 2) {
         if constexpr (std::is_same<T, float>::value) {
@@ -708,7 +735,7 @@ int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
     info->n_controls = h->nU;
     info->j_elems = h->j_elems;
     info->kernel_variant = h->variant;
-    info->lds_bytes = h->variant == 2 ? (int32_t)h->packed_lds
+    info->lds_bytes = h->variant == 4 ? (int32_t)h->packed2_lds : h->variant == 2 ? (int32_t)h->packed_lds
                       : (h->variant == 1 ? (int32_t)h->nested_lds
                       : (h->variant == 3 && h->split_j_in_lds ? (int32_t)(h->j_elems * h->esz) : 0));
     info->block = h->block;
@@ -722,13 +749,20 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     Handle *h = (Handle *)hh;
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) {
-        if (value < -1 || value > 3) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value < -1 || value > 4) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value == 4 && !h->packed_mode)
+            return fail(h, HJB_E_UNSUPPORTED, "variant 4 (packed, control pairs) needs float32 and the canonical spacecraft structure");
         if (value == 2 && !h->packed_mode)
             return fail(h, HJB_E_UNSUPPORTED, "variant 2 (packed) needs float32 and the canonical spacecraft structure (see kernels_packed.h)");
         if (value == 1 && !h->nested_ok)
             return fail(h, HJB_E_UNSUPPORTED, "variant 1 (control-nested) needs: only the last state axis depends on the innermost control dim");
         h->forced_variant = (int)value;
         choose_launch(h);
+        return HJB_OK;
+    }
+    if (!strcmp(key, "lds_pad")) {
+        if (value < 0 || value > 128 * 1024) return fail(h, HJB_E_INVALID, "lds_pad out of range");
+        h->lds_pad = (size_t)value;
         return HJB_OK;
     }
     if (!strcmp(key, "graph")) {

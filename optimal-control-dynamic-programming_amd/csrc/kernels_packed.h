@@ -75,7 +75,9 @@ __device__ __forceinline__ void contract(float (&v)[1 << D], const float (&tw)[D
     dE = v[1] - v[0];
 }
 
-constexpr int kPackedMaxIn = 64;   // crossing masks are 64-bit
+constexpr int kPackedMaxIn = 32;   // crossing masks are 32-bit
+// Unrolling the hot loop x3 saves scalar/branch issue but costs ~20 VGPRs (2 instead of 3 waves/SIMD).
+constexpr bool kPackedUnroll3 = false;
 
 template <int D>
 __global__ void __launch_bounds__(256)
@@ -162,7 +164,7 @@ k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, co
         float tw[2][DM];
         int lc0[2];                           // local plane of the last-axis cell at control 0
         int lc1[2];                           // ... and after this state's FIRST cell change (= lc0 if none)
-        unsigned long long cm[2] = {0ull, 0ull};   // bit j: this state's last-axis cell changes at control j
+        unsigned int cm[2] = {0u, 0u};        // bit j: this state's last-axis cell changes at control j
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             int si[D];                        // GLOBAL grid indices (tables of terms are global)
@@ -225,8 +227,8 @@ k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                     if (j == 0) {
                         lc0[s] = lc1[s] = tl[s].cell - plane0;
                     } else if (ch) {
-                        if (cm[s] == 0ull) lc1[s] = tl[s].cell - plane0;
-                        cm[s] |= 1ull << j;
+                        if (cm[s] == 0u) lc1[s] = tl[s].cell - plane0;
+                        cm[s] |= 1u << j;
                     }
                     t[s] = (q - tl[s].kc) * tl[s].rc;
                 }
@@ -234,10 +236,10 @@ k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, co
             }
         }
         // wave-uniform union of the crossing bits (lanes only read their own s_t column: no barrier needed)
-        unsigned long long U = 0ull;
+        unsigned int U = 0u;
         for (int j = 1; j < m_in; ++j) {
-            const bool mine = ((cm[0] | cm[1]) >> j) & 1ull;
-            if (__ballot(mine)) U |= 1ull << j;
+            const bool mine = ((cm[0] | cm[1]) >> j) & 1u;
+            if (__ballot(mine)) U |= 1u << j;
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -252,9 +254,7 @@ k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, co
         }
         // a state whose query changes cell more than once per inner sweep takes the general (search +
         // gather) path at its 2nd, 3rd ... crossing; wave-uniform flag
-        const bool multi = __ballot((cm[0] & (cm[0] - 1ull)) != 0ull || (cm[1] & (cm[1] - 1ull)) != 0ull) != 0ull;
-        // first crossing of each state as a mask (lowest set bit)
-        const unsigned long long cf[2] = {cm[0] & (0ull - cm[0]), cm[1] & (0ull - cm[1])};
+        const bool multi = __ballot((cm[0] & (cm[0] - 1u)) != 0u || (cm[1] & (cm[1] - 1u)) != 0u) != 0ull;
         float best[2] = {0.f, 0.f};
         int best_uo[2] = {0, 0}, best_j[2] = {0, 0};
 
@@ -350,10 +350,11 @@ k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                 auto cross = [&](int j) {                        // executed only where some lane changes cell
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        if ((cf[s] >> j) & 1ull) {               // first crossing: corners were prefetched
+                        const unsigned int first = cm[s] & (0u - cm[s]);   // lowest set bit = first crossing
+                        if ((first >> j) & 1u) {                 // first crossing: corners were prefetched
                             E0[s] = E0b[s];
                             dE[s] = dEb[s];
-                        } else if (multi && ((cm[s] >> j) & 1ull)) {   // later crossings: general path
+                        } else if (multi && ((cm[s] >> j) & 1u)) {     // later crossings: general path
                             const float q = ql[s] + s_br[j].x;
                             int lc = find_cell<float>(s_k, nl, q, l_uniform, l_x0, l_invh) - plane0;
                             if (lc < 0 || lc + 1 >= nplanes) {
@@ -377,13 +378,13 @@ k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                     if (tot.y < ibest[1]) { ibest[1] = tot.y; ij[1] = j; }
                 };
                 int j = 0;
-                for (; j + 3 <= m_in; j += 3) {
-                    if ((U >> j) & 7ull) {                       // scalar test for the whole group
-                        if ((U >> j) & 1ull) cross(j);
+                for (; kPackedUnroll3 && j + 3 <= m_in; j += 3) {
+                    if ((U >> j) & 7u) {                         // scalar test for the whole group
+                        if ((U >> j) & 1u) cross(j);
                         body(j);
-                        if ((U >> (j + 1)) & 1ull) cross(j + 1);
+                        if ((U >> (j + 1)) & 1u) cross(j + 1);
                         body(j + 1);
-                        if ((U >> (j + 2)) & 1ull) cross(j + 2);
+                        if ((U >> (j + 2)) & 1u) cross(j + 2);
                         body(j + 2);
                     } else {
                         body(j);
@@ -392,7 +393,7 @@ k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                     }
                 }
                 for (; j < m_in; ++j) {
-                    if ((U >> j) & 1ull) cross(j);
+                    if ((U >> j) & 1u) cross(j);
                     body(j);
                 }
 #pragma unroll

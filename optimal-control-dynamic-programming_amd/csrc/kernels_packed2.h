@@ -1,0 +1,308 @@
+// kernels_packed2.h - variant 4: like variant 2 (kernels_packed.h) but the two halves
+// of every packed fp32 instruction are two CONSECUTIVE CONTROLS (j, j+1) of ONE state
+// per lane instead of two states.  Same packed-instruction count per backup, but the
+// per-lane state is half as large (more waves per SIMD) and the grid has twice as many
+// waves (C2: 16,100 waves over 4,096 resident slots = 3.93 rounds instead of 2.62 -> 3),
+// which removes most of the tail loss.  An inner-dim size that is odd is padded with a
+// control whose cost is +inf (never selected).  A cell crossing at an odd control
+// changes only the upper half of (E0, dE); the halves are re-synchronised after the
+// pair.  Arithmetic per backup is the canonical order: bit-identical results.
+#pragma once
+#include "hjbdp_dev.h"
+#include "kernels_nested.h"
+#include "kernels_packed.h"
+
+namespace hjb {
+
+template <int D>
+__global__ void __launch_bounds__(256)
+k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const float *__restrict__ Jn,
+                 float *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+    constexpr int DM = D > 1 ? D - 1 : 1;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const DAxis &axl = P->axis[D - 1];
+    const int nl = axl.n;
+    const int m_in = N->m_in;
+    const int npairs = (m_in + 1) >> 1;
+    // LDS: {t_2p, t_2p+1} per lane [npairs+1][256] float2 | {r_2p, r_2p+1} [npairs+1] | b[m_in] |
+    //      knots, rdx of the last axis | control-only cost tables
+    f2 *s_t = reinterpret_cast<f2 *>(smem_raw);
+    f2 *s_r2 = s_t + (size_t)(npairs + 1) * 256;
+    float *s_b = reinterpret_cast<float *>(s_r2 + (npairs + 1));
+    float *s_k = s_b + m_in;
+    float *s_r = s_k + nl;
+    float *s_ot = s_r + nl;
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+        s_k[i] = static_cast<const float *>(axl.knots)[i];
+        s_r[i] = static_cast<const float *>(axl.rdx)[i];
+    }
+    {
+        const DInnerTerm &tb = N->in[0];
+        const DInnerTerm &tr = N->in[kMaxInAx];
+        for (int i = threadIdx.x; i < m_in; i += blockDim.x) s_b[i] = static_cast<const float *>(tb.data)[i * tb.stride_in];
+        for (int p = threadIdx.x; p <= npairs; p += blockDim.x) {
+            f2 x = {INFINITY, INFINITY};          // padding controls: infinite cost, never selected
+            if (2 * p < m_in) x.x = static_cast<const float *>(tr.data)[(2 * p) * tr.stride_in];
+            if (2 * p + 1 < m_in) x.y = static_cast<const float *>(tr.data)[(2 * p + 1) * tr.stride_in];
+            s_r2[p] = x;
+        }
+        s_t[(size_t)npairs * 256 + threadIdx.x] = (f2){0.f, 0.f};
+    }
+    constexpr int CL0 = HJB_MAX_D, CL1 = HJB_MAX_D + 1;
+#pragma unroll
+    for (int i = CL0; i <= CL1; ++i) {
+        const auto &t = N->ot[i];
+        if (t.present && t.lds_off >= 0)
+            for (int e = threadIdx.x; e < t.lds_len; e += blockDim.x)
+                s_ot[t.lds_off + e] = static_cast<const float *>(t.data)[e];
+    }
+    __syncthreads();
+
+    const int C = P->C;
+    const int n_owned = (int)P->n_owned;
+    const int l_uniform = axl.uniform;
+    const float l_x0 = (float)axl.x0, l_invh = (float)axl.inv_h;
+    const int plane0 = P->plane0, nplanes = P->nplanes;
+    const int m_o0 = N->m_o0, m_o1 = N->m_o1;
+    int js[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) js[a] = (int)P->jstride[a];
+    const int inner_sz = (int)P->inner;
+    f2 *my_t = s_t + threadIdx.x;
+    const int2 *atab[DM];
+    int a_c0[DM], a_c1[DM], a_lvl[DM];
+#pragma unroll
+    for (int a = 0; a < D - 1; ++a) {
+        atab[a] = static_cast<const int2 *>(N->at[a].tab);
+        a_c0[a] = N->at[a].c0;
+        a_c1[a] = N->at[a].c1;
+        a_lvl[a] = N->at[a].level;
+    }
+    const bool cl0_present = N->ot[CL0].present, cl1_present = N->ot[CL1].present;
+    const bool cl0_first = N->ot[CL0].first, cl1_first = N->ot[CL1].first;
+
+    for (int blk = blockIdx.x * 256; blk < n_owned; blk += gridDim.x * 256) {
+        int ls = blk + threadIdx.x;
+        const bool valid = ls < n_owned;
+        if (!valid) ls = n_owned - 1;         // harmless duplicate work, store skipped
+
+        float ql, gpre;
+        int aoff[DM], coff[2], cell[DM];
+        float tw[DM];
+        int lc0, lc1;
+        unsigned int cm = 0u;                 // bit j: the last-axis cell changes at control j
+        {
+            int si[D];
+            int r = ls;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                int na = P->n[a];
+                si[a] = r % na;
+                r /= na;
+            }
+            const int last_local = si[D - 1];
+            si[D - 1] += P->slab_begin;
+            float q = 0.f;
+            for (int k = 0; k < axl.n_prefix; ++k) {
+                float x = term_value32<D>(axl.t[k], si);
+                q = (k == 0) ? x : q + x;
+            }
+            ql = q;
+            float g = 0.f;
+            for (int k = 0; k < P->n_cost_prefix; ++k) {
+                float x = term_value32<D>(P->cost[k], si);
+                g = (k == 0) ? x : g + x;
+            }
+            gpre = g;
+#pragma unroll
+            for (int a = 0; a < D - 1; ++a) {
+                int off = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) off += N->at[a].sstride[d] * (d == D - 1 ? last_local : si[d]);
+                aoff[a] = off;
+                if (a_lvl[a] < 0) {
+                    const int2 e = atab[a][off];
+                    cell[a] = e.x;
+                    tw[a] = __int_as_float(e.y);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const auto &t = N->ot[CL0 + i];
+                int off = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) off += t.sstride[d] * si[d];
+                coff[i] = off;
+            }
+        }
+        // ---- once per state: inner weights t_j (pairs) and cell-crossing bits --------
+        {
+            CellTrack<float> tl;
+            track_reset(tl);
+            f2 t = {0.f, 0.f};
+            for (int j = 0; j < m_in; ++j) {
+                const float q = ql + s_b[j];
+                const bool ch = track_update<float>(tl, s_k, s_r, nl, q, l_uniform, l_x0, l_invh);
+                if (j == 0) {
+                    lc0 = lc1 = tl.cell - plane0;
+                } else if (ch) {
+                    if (cm == 0u) lc1 = tl.cell - plane0;
+                    cm |= 1u << j;
+                }
+                const float tj = (q - tl.kc) * tl.rc;
+                if (j & 1) { t.y = tj; my_t[(j >> 1) * 256] = t; }
+                else { t.x = tj; t.y = 0.f; if (j == m_in - 1) my_t[(j >> 1) * 256] = t; }
+            }
+        }
+        unsigned int U = 0u;
+        for (int j = 1; j < m_in; ++j)
+            if (__ballot((cm >> j) & 1u)) U |= 1u << j;
+        if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
+        if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
+        float best = 0.f;
+        int best_uo = 0, best_j = 0;
+
+        auto cterm = [&](int slot, int o0, int o1) -> float {
+            const auto &t = N->ot[slot];
+            if (t.lds_off >= 0) return s_ot[t.lds_off + o0 * t.c0 + o1 * t.c1];
+            return static_cast<const float *>(t.data)[coff[slot - CL0] + o0 * t.c0 + o1 * t.c1];
+        };
+
+        int uo = 0;
+        for (int o0 = 0; o0 < m_o0; ++o0) {
+            // ---- level 0 ------------------------------------------------------------
+#pragma unroll
+            for (int a = 0; a < D - 1; ++a) {
+                if (a_lvl[a] == 0) {
+                    const int2 e = atab[a][aoff[a] + o0 * a_c0[a]];
+                    cell[a] = e.x;
+                    tw[a] = __int_as_float(e.y);
+                }
+            }
+            float go0 = gpre;
+            if (cl0_present) {
+                const float x = cterm(CL0, o0, 0);
+                go0 = cl0_first ? x : go0 + x;
+            }
+            auto prepare = [&](int o1, int &base, float (&twc)[DM], float &go) {
+                int b = 0;
+#pragma unroll
+                for (int a = 0; a < D - 1; ++a) {
+                    if (a_lvl[a] == 1) {
+                        const int2 e = atab[a][aoff[a] + o0 * a_c0[a] + o1 * a_c1[a]];
+                        cell[a] = e.x;
+                        tw[a] = __int_as_float(e.y);
+                    }
+                    b += js[a] * cell[a];
+                    twc[a] = tw[a];
+                }
+                base = b;
+                float g = go0;
+                if (cl1_present) {
+                    const float x = cterm(CL1, o0, o1);
+                    g = cl1_first ? x : g + x;
+                }
+                go = g;
+            };
+            int base, base_n;
+            float twc[DM], twn[DM];
+            float go, go_n;
+            float G[1 << D], H[1 << D];
+            prepare(0, base, twc, go);
+            load_corners<D>(Jn, base + js[D - 1] * lc0, js, G);
+            load_corners<D>(Jn, base + js[D - 1] * lc1, js, H);
+            for (int o1 = 0; o1 < m_o1; ++o1, ++uo) {
+                // ---- level 1: contract the prefetched corners of this step -----------
+                float e0a, dea, e0b, deb;
+                contract<D>(G, twc, e0a, dea);
+                contract<D>(H, twc, e0b, deb);
+                const bool has_next = o1 + 1 < m_o1;
+                if (has_next) {
+                    prepare(o1 + 1, base_n, twn, go_n);
+                    load_corners<D>(Jn, base_n + js[D - 1] * lc0, js, G);
+                    load_corners<D>(Jn, base_n + js[D - 1] * lc1, js, H);
+                }
+                f2 E0 = {e0a, e0a}, dE = {dea, dea};
+                const f2 go2 = {go, go};
+                float ibest = INFINITY;
+                int ij = 0;
+                // new (E0, dE) when this lane's query enters another cell at control j
+                auto crossed = [&](int j, float &e0, float &de) {
+                    const unsigned int first = cm & (0u - cm);
+                    if ((first >> j) & 1u) {             // first crossing: corners were prefetched
+                        e0 = e0b;
+                        de = deb;
+                    } else {                             // later crossings: general path
+                        const float q = ql + s_b[j];
+                        int lc = find_cell<float>(s_k, nl, q, l_uniform, l_x0, l_invh) - plane0;
+                        if (lc < 0 || lc + 1 >= nplanes) {
+                            *P->status = 1;
+                            lc = lc < 0 ? 0 : nplanes - 2;
+                        }
+                        float v[1 << D];
+                        load_corners<D>(Jn, base + js[D - 1] * lc, js, v);
+                        contract<D>(v, twc, e0, de);
+                    }
+                };
+                // ---- inner loop over control PAIRS: packed, no loads, no cell tests on the vector pipe
+                f2 t = my_t[0];
+                f2 r2 = s_r2[0];
+                for (int p = 0; p < npairs; ++p) {
+                    const int jb = 2 * p;
+                    const unsigned int u2 = (U >> jb) & 3u;          // scalar
+                    if (u2) {
+                        if ((u2 & 1u) && ((cm >> jb) & 1u)) {
+                            float e0, de;
+                            crossed(jb, e0, de);
+                            E0 = (f2){e0, e0};
+                            dE = (f2){de, de};
+                        }
+                        if ((u2 & 2u) && ((cm >> (jb + 1)) & 1u)) {
+                            float e0, de;
+                            crossed(jb + 1, e0, de);
+                            E0.y = e0;
+                            dE.y = de;
+                        }
+                    }
+                    const f2 g = go2 + r2;
+                    const f2 tot = g + __builtin_elementwise_fma(t, dE, E0);
+                    t = my_t[(p + 1) * 256];                         // next pair's rows (row npairs is padding)
+                    r2 = s_r2[p + 1];
+                    if (tot.x < ibest) { ibest = tot.x; ij = jb; }
+                    if (tot.y < ibest) { ibest = tot.y; ij = jb + 1; }
+                    if (u2 & 2u) {                                   // re-synchronise the halves after an odd crossing
+                        E0.x = E0.y;
+                        dE.x = dE.y;
+                    }
+                }
+                if (uo == 0 || ibest < best) {
+                    best = ibest;
+                    best_uo = uo;
+                    best_j = ij;
+                }
+                if (has_next) {
+                    base = base_n;
+#pragma unroll
+                    for (int a = 0; a < D - 1; ++a) twc[a] = twn[a];
+                    go = go_n;
+                }
+            }  // o1
+        }      // o0
+        if (valid) {
+            int label;
+            if (C == 1) {
+                label = best_j;
+            } else if (C == 2) {
+                label = best_uo + P->m[0] * best_j;
+            } else {
+                const int j1 = best_uo % P->m[1], j0 = best_uo / P->m[1];
+                label = j0 + P->m[0] * (j1 + P->m[1] * best_j);
+            }
+            const int in_plane = ls % inner_sz, pl = ls / inner_sz;
+            Jout[in_plane + inner_sz * (pl + P->halo_lo)] = best;
+            if (idx_out) idx_out[ls] = label + P->index_base;
+        }
+    }
+}
+
+}  // namespace hjb

@@ -5,13 +5,14 @@ from hjbdp.synthetic import position3d_spec
 n = int(sys.argv[1]) if len(sys.argv)>1 else 101
 mu = int(sys.argv[2]) if len(sys.argv)>2 else 21
 st = int(sys.argv[3]) if len(sys.argv)>3 else 5
+var = int(sys.argv[4]) if len(sys.argv)>4 else None
 spec = position3d_spec(n, mu)
-with hjbdp.Backup(spec) as bk:
+pad = int(sys.argv[5]) if len(sys.argv)>5 else 0
+with hjbdp.Backup(spec, variant=var) as bk:
+    if pad: bk.set_option('lds_pad', pad)
     print(bk.info())
     out = bk.solve(2)
     out = bk.solve(st)
     ms = out['sweep_ms']/st
     print('n=%d mu=%d: %.3f ms/stage, %.3e backups/s' % (n, mu, ms, spec.nS*spec.nU/ (ms*1e-3)))
     print('J range', out['J'].min(), out['J'].max(), 'idx range', out['idx'].min(), out['idx'].max())
-import torch
-print('torch sees', torch.cuda.is_available(), torch.cuda.device_count())
