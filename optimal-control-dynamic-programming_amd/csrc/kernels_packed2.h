@@ -157,6 +157,9 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         unsigned int U = 0u;
         for (int j = 1; j < m_in; ++j)
             if (__ballot((cm >> j) & 1u)) U |= 1u << j;
+        unsigned int PU = 0u;                 // bit p: some lane changes cell at control 2p or 2p+1
+        for (int p = 0; p < npairs; ++p)
+            if ((U >> (2 * p)) & 3u) PU |= 1u << p;
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
         float best = 0.f;
@@ -214,24 +217,37 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             for (int o1 = 0; o1 < m_o1; ++o1, ++uo) {
                 // ---- level 1: contract the prefetched corners of this step -----------
                 float e0a, dea, e0b, deb;
-                contract<D>(G, twc, e0a, dea);
-                contract<D>(H, twc, e0b, deb);
+                {
+                    f2 v[1 << D];                                    // {first cell, second cell} contracted together
+#pragma unroll
+                    for (int c = 0; c < (1 << D); ++c) v[c] = (f2){G[c], H[c]};
+#pragma unroll
+                    for (int a = 0; a < D - 1; ++a) {
+                        const f2 w = {twc[a], twc[a]};
+#pragma unroll
+                        for (int jj = 0; jj < (1 << (D - 1 - a)); ++jj)
+                            v[jj] = __builtin_elementwise_fma(w, v[2 * jj + 1] - v[2 * jj], v[2 * jj]);
+                    }
+                    const f2 d = v[1] - v[0];
+                    e0a = v[0].x; e0b = v[0].y;
+                    dea = d.x;    deb = d.y;
+                }
                 const bool has_next = o1 + 1 < m_o1;
                 if (has_next) {
                     prepare(o1 + 1, base_n, twn, go_n);
                     load_corners<D>(Jn, base_n + js[D - 1] * lc0, js, G);
                     load_corners<D>(Jn, base_n + js[D - 1] * lc1, js, H);
                 }
-                f2 E0 = {e0a, e0a}, dE = {dea, dea};
+                float e0 = e0a, de = dea;                            // (E0, dE) of the cell the query is in
                 const f2 go2 = {go, go};
                 float ibest = INFINITY;
-                int ij = 0;
+                int ip = 0;                                          // first PAIR attaining the running minimum
                 // new (E0, dE) when this lane's query enters another cell at control j
-                auto crossed = [&](int j, float &e0, float &de) {
+                auto crossed = [&](int j, float &ne0, float &nde) {
                     const unsigned int first = cm & (0u - cm);
                     if ((first >> j) & 1u) {             // first crossing: corners were prefetched
-                        e0 = e0b;
-                        de = deb;
+                        ne0 = e0b;
+                        nde = deb;
                     } else {                             // later crossings: general path
                         const float q = ql + s_b[j];
                         int lc = find_cell<float>(s_k, nl, q, l_uniform, l_x0, l_invh) - plane0;
@@ -241,39 +257,63 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         }
                         float v[1 << D];
                         load_corners<D>(Jn, base + js[D - 1] * lc, js, v);
-                        contract<D>(v, twc, e0, de);
+                        contract<D>(v, twc, ne0, nde);
                     }
                 };
-                // ---- inner loop over control PAIRS: packed, no loads, no cell tests on the vector pipe
+                // ---- inner loop over control PAIRS: packed, no loads, no cell tests on the vector pipe.
+                // Per pair: 3 packed math (E0, dE broadcast to both halves), v_min3, one compare/select.
+                // The pair loop is cut at the (wave-uniform, scalar) pairs where some lane changes cell, so
+                // that inside a segment (E0, dE) are loop-invariant registers.
                 f2 t = my_t[0];
                 f2 r2 = s_r2[0];
-                for (int p = 0; p < npairs; ++p) {
-                    const int jb = 2 * p;
-                    const unsigned int u2 = (U >> jb) & 3u;          // scalar
-                    if (u2) {
-                        if ((u2 & 1u) && ((cm >> jb) & 1u)) {
-                            float e0, de;
-                            crossed(jb, e0, de);
-                            E0 = (f2){e0, e0};
-                            dE = (f2){de, de};
-                        }
-                        if ((u2 & 2u) && ((cm >> (jb + 1)) & 1u)) {
-                            float e0, de;
-                            crossed(jb + 1, e0, de);
-                            E0.y = e0;
-                            dE.y = de;
+                int p = 0;
+                while (p < npairs) {
+                    const unsigned int rest = PU >> p;
+                    const int pstop = rest ? p + __builtin_ctz(rest) : npairs;   // next pair with a crossing
+                    const f2 e0v = {e0, e0}, dev = {de, de};
+                    for (; p < pstop; ++p) {
+                        const f2 tot = (go2 + r2) + __builtin_elementwise_fma(t, dev, e0v);
+                        t = my_t[(p + 1) * 256];                     // next pair's rows (row npairs is padding)
+                        r2 = s_r2[p + 1];
+                        const float nb = __builtin_fminf(ibest, __builtin_fminf(tot.x, tot.y));   // v_min3_f32
+                        ip = (nb == ibest) ? ip : p;                 // nb < ibest: the FIRST pair reaching the minimum
+                        ibest = nb;
+                    }
+                    if (p < npairs) {                                // a pair in which some lane changes cell
+                        const int jb = 2 * p;
+                        if ((cm >> jb) & 1u) crossed(jb, e0, de);
+                        float e0y = e0, dey = de;
+                        if ((cm >> (jb + 1)) & 1u) crossed(jb + 1, e0y, dey);
+                        const f2 tot = (go2 + r2) + __builtin_elementwise_fma(t, (f2){de, dey}, (f2){e0, e0y});
+                        e0 = e0y;
+                        de = dey;
+                        t = my_t[(p + 1) * 256];
+                        r2 = s_r2[p + 1];
+                        const float nb = __builtin_fminf(ibest, __builtin_fminf(tot.x, tot.y));
+                        ip = (nb == ibest) ? ip : p;
+                        ibest = nb;
+                        ++p;
+                    }
+                }
+                // which half of pair ip holds the minimum?  Re-evaluate its FIRST control exactly as the loop
+                // did; if that reproduces ibest the first control wins (first-minimum rule), else the second.
+                int ij;
+                {
+                    const int j0 = 2 * ip;
+                    float xe0 = e0a, xde = dea;
+                    if (cm != 0u && (cm & ((2u << j0) - 1u)) != 0u) {        // some crossing at a control <= j0
+                        const unsigned int upto = cm & ((2u << j0) - 1u);
+                        if ((upto & (upto - 1u)) == 0u) {                     // exactly one: the prefetched cell
+                            xe0 = e0b;
+                            xde = deb;
+                        } else {                                              // several: general path at the last one
+                            const int jl = 31 - __builtin_clz(upto);
+                            crossed(jl, xe0, xde);
                         }
                     }
-                    const f2 g = go2 + r2;
-                    const f2 tot = g + __builtin_elementwise_fma(t, dE, E0);
-                    t = my_t[(p + 1) * 256];                         // next pair's rows (row npairs is padding)
-                    r2 = s_r2[p + 1];
-                    if (tot.x < ibest) { ibest = tot.x; ij = jb; }
-                    if (tot.y < ibest) { ibest = tot.y; ij = jb + 1; }
-                    if (u2 & 2u) {                                   // re-synchronise the halves after an odd crossing
-                        E0.x = E0.y;
-                        dE.x = dE.y;
-                    }
+                    const float tx = my_t[ip * 256].x;
+                    const float tot0 = (go + s_r2[ip].x) + __builtin_fmaf(tx, xde, xe0);
+                    ij = (tot0 == ibest) ? j0 : j0 + 1;
                 }
                 if (uo == 0 || ibest < best) {
                     best = ibest;
