@@ -179,6 +179,41 @@ def test_packed_variant_slab(env):
         assert np.array_equal(io, iw.reshape(72, 14, order="F")[:, b:e].reshape(-1, order="F"))
 
 
+EDGE = [
+    # (n, m, dtype): minimum axis sizes, single-control dims, inner dim of 1/2/odd size, nU == 64
+    ((2, 2), (1,), np.float32),
+    ((2, 3, 2), (1, 1, 1), np.float32),
+    ((5, 4, 2), (3, 1, 2), np.float32),
+    ((5, 4, 3), (1, 2, 1), np.float32),
+    ((6, 5), (64,), np.float32),
+    ((6, 5), (65,), np.float64),
+    ((3, 3, 3, 3), (2, 32), np.float32),      # inner dim at the packed kernels' 32-control limit
+    ((3, 3, 3), (2, 33), np.float32),         # ... and just above it (falls back to variant 1)
+    ((300, 2), (5,), np.float32),
+]
+
+
+@pytest.mark.parametrize("n,m,dtype", EDGE)
+def test_edge_shapes_all_variants(env, n, m, dtype):
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    spec = nested_problem(2024, n, m, dtype=dtype, spread=0.5)
+    term = random_terminal(spec, 1)
+    ref = c_oracle.sweep(_abi, spec, 3, terminal=term)
+    seen = set()
+    for v in (None, 0, 1, 2, 3, 4):
+        try:
+            bk = hjbdp.Backup(spec, variant=v)
+        except hjbdp.HjbError as e:
+            assert e.status == _abi.HJB_E_UNSUPPORTED and v in (1, 2, 4)
+            continue
+        with bk:
+            seen.add(bk.info()["kernel_variant"])
+            o = bk.solve(3, terminal=term)
+        assert np.array_equal(o["J"], ref["J"]) and np.array_equal(o["idx"], ref["idx"]), (v, n, m)
+    assert {0, 3} <= seen
+
+
 def test_c2_workload_small_bit_exact(env):
     """BASELINE configs[1] (Solver_position 3-DOF) at a size the oracle finishes in seconds."""
     hjbdp, _abi, c_oracle = env
