@@ -155,6 +155,18 @@ int32_t hjb_check_device_status(hjb_handle h, void *stream);
 /* The whole backward sweep (the `for k` loops of the reference). */
 int32_t hjb_solve(hjb_handle h, const hjb_solve_opts *opts, hjb_result *result);
 
+/* Batched evaluation of a gridded function at nq points - what the reference does with the
+ * sweep's results: griddedInterpolant({grid vectors}, U_vector(U_idx), 'nearest') policy lookups
+ * (Solver_position.m:144-146, Solver_pos_att.m:851-861, :404-449) and 'linear' lookups of
+ * u_star(:,:,k) / J (Dynamic_Solver.m:132-135).  values: [n_1..n_D] column-major, dtype;
+ * queries: [D x nq] column-major (point i = queries[D*i .. D*i+D-1]), dtype; out: [nq] dtype.
+ * method HJB_LOOKUP_LINEAR: N-linear with linear extrapolation (same arithmetic as the sweep);
+ * HJB_LOOKUP_NEAREST: per axis the nearer knot of the enclosing cell, the upper one at the midpoint. */
+#define HJB_LOOKUP_NEAREST 0
+#define HJB_LOOKUP_LINEAR 1
+int32_t hjb_policy_lookup(int32_t device, int32_t dtype, int32_t D, const int32_t *n, const double *const *knots,
+                          const void *values, int64_t nq, const void *queries, int32_t method, void *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@
 #include "kernels_packed.h"
 #include "kernels_packed2.h"
 #include "kernels_ctrlsplit.h"
+#include "kernels_lookup.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -613,6 +614,63 @@ int check_status(Handle *h, hipStream_t st) {
 
 }  // namespace
 
+template <typename T>
+int policy_lookup_t(int32_t D, const int32_t *n, const double *const *knots, const void *values, int64_t nq,
+                           const void *queries, int32_t method, void *out) {
+    Handle tmp;   // only for allocation bookkeeping and error text
+    Handle *h = &tmp;
+    DLookup L{};
+    L.D = D;
+    L.method = method;
+    int64_t s = 1;
+    for (int a = 0; a < D; ++a) {
+        std::vector<T> kk(n[a]), rdx(n[a]);
+        for (int i = 0; i < n[a]; ++i) kk[i] = (T)knots[a][i];
+        for (int i = 0; i + 1 < n[a]; ++i) {
+            if (!(kk[i + 1] > kk[i])) { g_last_error = "lookup: knots not strictly increasing"; return HJB_E_INVALID; }
+            rdx[i] = (T)1 / (T)(kk[i + 1] - kk[i]);
+        }
+        rdx[n[a] - 1] = (T)0;
+        void *dk = nullptr, *dr = nullptr;
+        int st = upload(h, kk, &dk);
+        if (!st) st = upload(h, rdx, &dr);
+        if (st) { for (void *d : h->allocs) (void)hipFree(d); return st; }
+        L.knots[a] = dk;
+        L.rdx[a] = dr;
+        L.n[a] = n[a];
+        L.stride[a] = s;
+        s *= n[a];
+    }
+    void *dV = nullptr, *dQ = nullptr, *dO = nullptr;
+    int st = dev_alloc(h, (size_t)s * sizeof(T), &dV);
+    if (!st) st = dev_alloc(h, (size_t)nq * D * sizeof(T), &dQ);
+    if (!st) st = dev_alloc(h, (size_t)nq * sizeof(T), &dO);
+    hipError_t e = hipSuccess;
+    if (!st) {
+        e = hipMemcpy(dV, values, (size_t)s * sizeof(T), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dQ, queries, (size_t)nq * D * sizeof(T), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const int grid = (int)std::min<int64_t>((nq + 255) / 256, 65536);
+            dim3 g(std::max(grid, 1)), b(256);
+            switch (D) {
+                case 1: hipLaunchKernelGGL((k_policy_lookup<T, 1>), g, b, 0, nullptr, L, (const T *)dV, nq, (const T *)dQ, (T *)dO); break;
+                case 2: hipLaunchKernelGGL((k_policy_lookup<T, 2>), g, b, 0, nullptr, L, (const T *)dV, nq, (const T *)dQ, (T *)dO); break;
+                case 3: hipLaunchKernelGGL((k_policy_lookup<T, 3>), g, b, 0, nullptr, L, (const T *)dV, nq, (const T *)dQ, (T *)dO); break;
+                case 4: hipLaunchKernelGGL((k_policy_lookup<T, 4>), g, b, 0, nullptr, L, (const T *)dV, nq, (const T *)dQ, (T *)dO); break;
+                case 5: hipLaunchKernelGGL((k_policy_lookup<T, 5>), g, b, 0, nullptr, L, (const T *)dV, nq, (const T *)dQ, (T *)dO); break;
+                default: hipLaunchKernelGGL((k_policy_lookup<T, 6>), g, b, 0, nullptr, L, (const T *)dV, nq, (const T *)dQ, (T *)dO); break;
+            }
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpy(out, dO, (size_t)nq * sizeof(T), hipMemcpyDeviceToHost);
+        }
+    }
+    for (void *d : h->allocs) (void)hipFree(d);
+    h->allocs.clear();
+    if (st) return st;
+    if (e != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hjb_policy_lookup: %s", hipGetErrorString(e));
+    return HJB_OK;
+}
+
 extern "C" {
 
 const char *hjb_version(void) { return "hjbdp 0.1.0 (gfx950)"; }
@@ -952,6 +1010,25 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     }
     return HJB_OK;
 #undef SOLVE_TRY
+}
+
+int32_t hjb_policy_lookup(int32_t device, int32_t dtype, int32_t D, const int32_t *n, const double *const *knots,
+                          const void *values, int64_t nq, const void *queries, int32_t method, void *out) {
+    if (!n || !knots || !values || !queries || !out) return fail(nullptr, HJB_E_INVALID, "null argument");
+    if (D < 1 || D > HJB_MAX_D) return fail(nullptr, HJB_E_UNSUPPORTED, "D=%d", D);
+    if (dtype != HJB_F32 && dtype != HJB_F64) return fail(nullptr, HJB_E_UNSUPPORTED, "dtype %d", dtype);
+    if (method != HJB_LOOKUP_NEAREST && method != HJB_LOOKUP_LINEAR) return fail(nullptr, HJB_E_INVALID, "method %d", method);
+    if (nq < 0) return fail(nullptr, HJB_E_INVALID, "nq < 0");
+    for (int a = 0; a < D; ++a)
+        if (n[a] < 2 || !knots[a]) return fail(nullptr, HJB_E_INVALID, "axis %d: need >= 2 knots", a);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, HJB_E_DEVICE, "no HIP device visible (libhjbdp has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, HJB_E_INVALID, "device %d", device);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hipSetDevice failed");
+    if (nq == 0) return HJB_OK;
+    return dtype == HJB_F32 ? policy_lookup_t<float>(D, n, knots, values, nq, queries, method, out)
+                            : policy_lookup_t<double>(D, n, knots, values, nq, queries, method, out);
 }
 
 }  // extern "C"

@@ -72,6 +72,27 @@ def _check(lib, handle, st):
         raise HjbError(st, (msg or b"").decode() or lib.hjb_status_string(st).decode())
 
 
+def policy_lookup(knots, values, points, method="nearest", device=0):
+    """Batched griddedInterpolant(knots, values, method) at `points` [nq, D] on the GPU
+    (hjb_policy_lookup).  values.dtype (float32/float64) is the arithmetic type."""
+    lib = load_library()
+    values = np.asarray(values)
+    dt = values.dtype if values.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+    D = len(knots)
+    V = np.ascontiguousarray(np.asarray(values, dtype=dt).reshape(-1, order="F"))
+    Q = np.ascontiguousarray(np.asarray(points, dtype=dt).reshape(-1, D))
+    nq = Q.shape[0]
+    ks = [np.ascontiguousarray(k, dtype=np.float64) for k in knots]
+    n = (C.c_int32 * D)(*[len(k) for k in ks])
+    kp = (C.POINTER(C.c_double) * D)(*[k.ctypes.data_as(C.POINTER(C.c_double)) for k in ks])
+    out = np.empty(nq, dtype=dt)
+    meth = {"nearest": _abi.HJB_LOOKUP_NEAREST, "linear": _abi.HJB_LOOKUP_LINEAR}[method]
+    st = lib.hjb_policy_lookup(int(device), _abi.HJB_F32 if dt == np.float32 else _abi.HJB_F64, D, n, kp,
+                               V.ctypes.data, nq, Q.ctypes.data, meth, out.ctypes.data)
+    _check(lib, None, st)
+    return out
+
+
 class Backup:
     """A problem resident on one GPU.  Mirrors the C handle one to one."""
 

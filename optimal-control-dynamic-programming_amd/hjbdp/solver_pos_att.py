@@ -130,6 +130,45 @@ class Solver_pos_att:
         }
         return self.controllers[file_name]
 
+    # ---- controller artefacts (Solver_pos_att.m:289 save, :849-884 set_controller) ----------
+    def save_controllers(self, directory):
+        """Write one MATLAB-loadable v5 .mat per channel with the variables the reference saves
+        (`U_Optimal_id`, `f0_allcomb`, `f1_allcomb`, `f6_allcomb`, `f7_allcomb`); the interpolant
+        object `F_gI` cannot be serialised outside MATLAB, so its two properties are stored as
+        `F_gI_GridVectors` (1x4 cell) and `F_gI_Values` (single)."""
+        import os
+        import scipy.io
+        os.makedirs(directory, exist_ok=True)
+        paths = []
+        for name, c in self.controllers.items():
+            gv = np.empty((1, 4), dtype=object)
+            for i, g in enumerate(c["GridVectors"]):
+                gv[0, i] = np.asarray(g, dtype=np.float64).reshape(1, -1)
+            path = os.path.join(directory, name + ".mat")
+            scipy.io.savemat(path, {
+                "F_gI_GridVectors": gv, "F_gI_Values": c["F_gI_Values"].astype(np.float32),
+                "U_Optimal_id": c["U_Optimal_id"].astype(np.float64),     # MATLAB's min returns double indices
+                "f0_allcomb": c["f0_allcomb"].reshape(-1, 1), "f1_allcomb": c["f1_allcomb"].reshape(-1, 1),
+                "f6_allcomb": c["f6_allcomb"].reshape(-1, 1), "f7_allcomb": c["f7_allcomb"].reshape(-1, 1)})
+            paths.append(path)
+        return paths
+
+    def set_controller(self, file, channel):
+        """Solver_pos_att.m:849-884: four 'nearest' interpolants of the thruster levels selected by
+        U_Optimal_id, stored on the object under the channel's thruster names."""
+        import scipy.io
+        from .solver_position import NearestPolicy
+        Cc = scipy.io.loadmat(file)
+        gv = [np.asarray(g, dtype=np.float64).reshape(-1) for g in Cc["F_gI_GridVectors"][0]]
+        idx = Cc["U_Optimal_id"].astype(np.int64) - 1
+        pols = [NearestPolicy(gv, Cc[k].reshape(-1)[idx]) for k in ("f0_allcomb", "f1_allcomb", "f6_allcomb", "f7_allcomb")]
+        names = {"x": (0, 1, 6, 7), "y": (2, 3, 8, 9), "z": (4, 5, 10, 11)}
+        if channel not in names:
+            raise ValueError("wrong channel, must be one of x-y-z values")
+        for pol, t in zip(pols, names[channel]):
+            setattr(self, "Opt_F_Thr%d" % t, pol)
+        return pols
+
     def simplified_run(self, n_stages=None, progress=None):
         sx, sv, st, sw = self.grids()
         ch = self.calculate_one_channel_U_Opt

@@ -31,6 +31,11 @@ class NearestPolicy:
     def __call__(self, *x):
         return interp_nearest_point(self.GridVectors, self.Values, x)
 
+    def lookup_many(self, points, device=0):
+        """Batched evaluation at points [nq, D] on the GPU (hjb_policy_lookup, 'nearest')."""
+        from .core import policy_lookup
+        return policy_lookup(self.GridVectors, self.Values, points, "nearest", device=device)
+
 
 class Solver_position:
     def __init__(self):

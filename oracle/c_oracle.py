@@ -36,6 +36,9 @@ def lib(abi):
         l.orc_sweep.restype = C.c_int
         l.orc_sweep.argtypes = [C.POINTER(abi.hjb_problem), C.POINTER(abi.hjb_solve_opts), C.POINTER(abi.hjb_result), C.c_int]
         l.orc_max_threads.restype = C.c_int
+        l.orc_lookup.restype = C.c_int
+        l.orc_lookup.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_double)), C.c_void_p,
+                                 C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         _lib = l
     return _lib
 
@@ -86,3 +89,22 @@ def sweep(abi, spec, n_stages, terminal=None, keep_J=False, keep_idx=False, moni
         raise RuntimeError("orc_sweep status %d" % st)
     return {"J": J, "idx": idx, "J_stages": Js, "idx_stages": Is, "stages_done": res.stages_done,
             "stopped_early": bool(res.stopped_early), "last_e": res.last_e, "last_e2": res.last_e2}
+
+
+def lookup(abi, knots, values, points, method="nearest"):
+    """Canonical batched gridded lookup on the CPU (checker for hjb_policy_lookup)."""
+    l = lib(abi)
+    values = np.asarray(values)
+    dt = values.dtype if values.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+    D = len(knots)
+    V = np.ascontiguousarray(np.asarray(values, dtype=dt).reshape(-1, order="F"))
+    Q = np.ascontiguousarray(np.asarray(points, dtype=dt).reshape(-1, D))
+    ks = [np.ascontiguousarray(k, dtype=np.float64) for k in knots]
+    n = (C.c_int32 * D)(*[len(k) for k in ks])
+    kp = (C.POINTER(C.c_double) * D)(*[k.ctypes.data_as(C.POINTER(C.c_double)) for k in ks])
+    out = np.empty(Q.shape[0], dtype=dt)
+    st = l.orc_lookup(0 if dt == np.float32 else 1, D, n, kp, V.ctypes.data, Q.shape[0], Q.ctypes.data,
+                      {"nearest": 0, "linear": 1}[method], out.ctypes.data)
+    if st != 0:
+        raise RuntimeError("orc_lookup status %d" % st)
+    return out

@@ -236,6 +236,58 @@ int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, in
     return st;
 }
 
+/* Batched gridded lookup (policy use: Solver_position.m:144-146 'nearest',
+ * Dynamic_Solver.m:132-135 'linear'); same canonical arithmetic as the sweep.
+ * method 0 = nearest (upper knot at the midpoint), 1 = linear with extrapolation. */
+#define DEFINE_LOOKUP(T, NAME, FMA)                                                                  \
+    static void NAME(int D, const int32_t *n, const double *const *knots, const T *V, int64_t nq,      \
+                     const T *Q, int method, T *out) {                                                \
+        T *kk[HJB_MAX_D], *rdx[HJB_MAX_D];                                                            \
+        int64_t stride[HJB_MAX_D], s = 1;                                                             \
+        for (int a = 0; a < D; ++a) {                                                                 \
+            kk[a] = (T *)malloc(sizeof(T) * n[a]);                                                    \
+            rdx[a] = (T *)malloc(sizeof(T) * n[a]);                                                   \
+            for (int i = 0; i < n[a]; ++i) kk[a][i] = (T)knots[a][i];                                 \
+            for (int i = 0; i + 1 < n[a]; ++i) rdx[a][i] = (T)1 / (kk[a][i + 1] - kk[a][i]);          \
+            stride[a] = s;                                                                            \
+            s *= n[a];                                                                                \
+        }                                                                                             \
+        for (int64_t i = 0; i < nq; ++i) {                                                            \
+            T tw[HJB_MAX_D], v[1 << HJB_MAX_D];                                                       \
+            int64_t base = 0;                                                                         \
+            for (int a = 0; a < D; ++a) {                                                             \
+                T q = Q[i * D + a];                                                                   \
+                int lo = 0, hi = n[a] - 1;                                                            \
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (kk[a][mid] <= q) lo = mid; else hi = mid; } \
+                if (method == 0) { if ((T)(q - kk[a][lo]) >= (T)(kk[a][lo + 1] - q)) ++lo; tw[a] = 0; } \
+                else tw[a] = (T)((T)(q - kk[a][lo]) * rdx[a][lo]);                                    \
+                base += stride[a] * lo;                                                               \
+            }                                                                                         \
+            if (method == 0) { out[i] = V[base]; continue; }                                          \
+            for (int c = 0; c < (1 << D); ++c) {                                                      \
+                int64_t off = base;                                                                   \
+                for (int a = 0; a < D; ++a) if (c & (1 << a)) off += stride[a];                       \
+                v[c] = V[off];                                                                        \
+            }                                                                                         \
+            for (int a = 0; a < D; ++a) {                                                             \
+                int half = 1 << (D - 1 - a);                                                          \
+                for (int j = 0; j < half; ++j) v[j] = FMA(tw[a], (T)(v[2 * j + 1] - v[2 * j]), v[2 * j]); \
+            }                                                                                         \
+            out[i] = v[0];                                                                            \
+        }                                                                                             \
+        for (int a = 0; a < D; ++a) { free(kk[a]); free(rdx[a]); }                                    \
+    }
+DEFINE_LOOKUP(float, lookup_f32, fmaf)
+DEFINE_LOOKUP(double, lookup_f64, fma)
+
+int orc_lookup(int dtype, int D, const int32_t *n, const double *const *knots, const void *V, int64_t nq,
+               const void *Q, int method, void *out) {
+    if (D < 1 || D > HJB_MAX_D) return HJB_E_UNSUPPORTED;
+    if (dtype == HJB_F32) lookup_f32(D, n, knots, (const float *)V, nq, (const float *)Q, method, (float *)out);
+    else lookup_f64(D, n, knots, (const double *)V, nq, (const double *)Q, method, (double *)out);
+    return HJB_OK;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

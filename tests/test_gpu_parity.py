@@ -379,3 +379,24 @@ def test_device_buffer_entry_point_with_torch(env):
         bk.check_device_status()
     Jr, ir = c_oracle.backup_stage(_abi, spec, term)
     assert np.array_equal(Jo.cpu().numpy(), Jr) and np.array_equal(idx.cpu().numpy(), ir)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_policy_lookup_bit_exact(env, dtype):
+    """hjb_policy_lookup ('nearest' policy tables, 'linear' value/policy lookups) vs the C oracle."""
+    hjbdp, _abi, c_oracle = env
+    rng = np.random.default_rng(3)
+    for D in (1, 2, 4):
+        knots = [np.sort(rng.uniform(-1, 1, 6 + a)).astype(dtype).astype(np.float64) for a in range(D)]
+        V = rng.standard_normal(tuple(len(k) for k in knots)).astype(dtype)
+        pts = rng.uniform(-1.4, 1.4, size=(5000, D)).astype(dtype)
+        pts[:50] = np.stack([rng.choice(k, 50) for k in knots], axis=1)      # exactly on knots
+        for method in ("nearest", "linear"):
+            got = hjbdp.policy_lookup(knots, V, pts, method)
+            ref = c_oracle.lookup(_abi, knots, V, pts, method)
+            assert np.array_equal(got, ref), (D, method)
+    # the policy object of the position solver uses it for batched queries
+    pol = hjbdp.solver_position.NearestPolicy([np.linspace(-1, 1, 5), np.linspace(-1, 1, 4)],
+                                              rng.standard_normal((5, 4)))
+    q = rng.uniform(-1, 1, size=(100, 2))
+    assert np.array_equal(pol.lookup_many(q), np.array([pol(*p) for p in q]))

@@ -133,3 +133,48 @@ def test_slab_oracle_matches_whole_grid(orc):
     Jo, io = c_oracle.backup_stage(_abi, spec, Jin, slab=(b, e, lo, hi))
     assert np.array_equal(Jo.reshape(72, -1, order="F")[:, lo:lo + e - b], Jw.reshape(72, 12, order="F")[:, b:e])
     assert np.array_equal(io, iw.reshape(72, 12, order="F")[:, b:e].reshape(-1, order="F"))
+
+
+def test_lookup_oracle_against_scipy(orc):
+    """The lookup checker itself is checked against an independent implementation
+    (scipy RegularGridInterpolator, linear + extrapolation; nearest away from midpoints)."""
+    from scipy.interpolate import RegularGridInterpolator
+    _abi, c_oracle, hjb_oracle = orc
+    rng = np.random.default_rng(5)
+    knots = [np.sort(rng.uniform(-1, 1, 9)), np.linspace(-2, 3, 7), np.cumsum(rng.uniform(0.2, 1.0, 5))]
+    V = rng.standard_normal((9, 7, 5))
+    pts = np.stack([rng.uniform(-1.5, 1.5, 400), rng.uniform(-3, 4, 400), rng.uniform(0, 4, 400)], axis=1)
+    lin = c_oracle.lookup(_abi, knots, V, pts, "linear")
+    ref = RegularGridInterpolator(knots, V, method="linear", bounds_error=False, fill_value=None)(pts)
+    assert np.max(np.abs(lin - ref)) < 1e-11
+    inside = pts.copy()
+    for a in range(3):
+        inside[:, a] = np.clip(inside[:, a], knots[a][0], knots[a][-1])
+    near = c_oracle.lookup(_abi, knots, V, inside, "nearest")
+    refn = RegularGridInterpolator(knots, V, method="nearest")(inside)
+    assert np.mean(near == refn) > 0.99          # only exact-midpoint ties may differ
+
+
+def test_pos_att_controller_artefact_roundtrip(tmp_path):
+    """save_controllers -> MATLAB v5 .mat -> set_controller (Solver_pos_att.m:289, :849-884)."""
+    import scipy.io
+    import hjbdp
+    pa = hjbdp.Solver_pos_att()
+    rng = np.random.default_rng(0)
+    gv = [np.linspace(-1, 1, 4), np.linspace(-1, 1, 3), np.linspace(-1, 1, 3), np.linspace(-1, 1, 2)]
+    ids = rng.integers(1, 10, size=(4, 3, 3, 2))
+    from hjbdp.solver_pos_att import vectors_allcomb
+    f = vectors_allcomb(pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7)
+    pa.controllers["channel_x_controller_1"] = {
+        "GridVectors": gv, "F_gI_Values": rng.random((4, 3, 3, 2)).astype(np.float32), "U_Optimal_id": ids,
+        "f0_allcomb": f[0], "f1_allcomb": f[1], "f6_allcomb": f[2], "f7_allcomb": f[3]}
+    (path,) = pa.save_controllers(tmp_path)
+    m = scipy.io.loadmat(path)
+    assert m["U_Optimal_id"].dtype == np.float64 and m["F_gI_Values"].dtype == np.float32
+    pols = pa.set_controller(path, "x")
+    assert pa.Opt_F_Thr0 is pols[0] and pa.Opt_F_Thr7 is pols[3]
+    x = (0.9, -0.1, 0.2, 1.0)
+    i = (3, 1, 1, 1)
+    assert pols[1](*x) == f[1][ids[i] - 1]
+    with pytest.raises(ValueError):
+        pa.set_controller(path, "q")
