@@ -160,11 +160,13 @@ def main():
                    "sharding": "last state axis, %d planes per GPU, halo %d/%d planes exchanged per stage"
                                % (args.n, sw.halo_lo, sw.halo_hi) if world > 1 else "none",
                    "kernel_variant": info["kernel_variant"]},
-        "roofline": {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "pipe": "valu (v_pk_fma_f32; no MFMA applies: interpolation is a gather, K = D <= 6)",
+                     "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
                      "kernel": {4: "k_backup_packed2<3>", 2: "k_backup_packed<3>", 1: "k_backup_nested<float,3,true>"}.get(info["kernel_variant"], "k_backup_generic<float,3>"),
                      "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(D),
-                     "note": "fp32 vector (VALU) roofline binds (SURVEY 8d); peak = MI355X fp32 vector = f32-MFMA rate",
+                     "note": "compute roofline binds (SURVEY 8d), HBM does not; peak = dense f32 MFMA peak = fp32 vector peak "
+                             "(157.3 TFLOP/s); achieved = ALGORITHMIC flops (41 per backup) / launch time",
                      "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                              "alg_bytes_per_state": 2 * spec.dtype.itemsize + 4}},
         "checksum_sum_J": checksum,
