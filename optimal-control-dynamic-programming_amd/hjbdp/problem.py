@@ -101,3 +101,32 @@ class ProblemSpec:
             p.slab_begin, p.slab_end, p.halo_lo, p.halo_hi = (int(x) for x in slab)
         keep.append(self.knots)
         return p, keep
+
+
+def permute_state_axes(spec: ProblemSpec, order):
+    """Relabel the state axes: new axis i = old axis order[i].  Pure bookkeeping (which
+    axis is "last" decides which stage kernel applies and the order of the 1-D lerps);
+    returns (new_spec, to_old) where to_old(array_flat_F) maps a result laid out on
+    the new grid back to the old grid's column-major order."""
+    order = tuple(int(a) for a in order)
+    D, C = spec.D, spec.C
+    if sorted(order) != list(range(D)):
+        raise ValueError("order must be a permutation of the state axes")
+    new_of_old = {old: new for new, old in enumerate(order)}
+    for c in range(C):
+        new_of_old[D + c] = D + c
+
+    def remap(t):
+        nd = [new_of_old[d] for d in t.dims]
+        perm = sorted(range(len(nd)), key=lambda i: nd[i])
+        return Term(tuple(nd[i] for i in perm), np.transpose(t.data, perm))
+    knots = [spec.knots[a] for a in order]
+    nxt = [[remap(t) for t in spec.next_terms[a]] for a in order]
+    cost = [remap(t) for t in spec.cost_terms]
+    new = ProblemSpec(knots, spec.m, nxt, cost, dtype=spec.dtype, index_base=spec.index_base)
+    inv = [order.index(a) for a in range(D)]
+
+    def to_old(flat):
+        arr = np.asarray(flat).reshape(new.n, order="F")
+        return np.transpose(arr, inv).reshape(-1, order="F")
+    return new, to_old

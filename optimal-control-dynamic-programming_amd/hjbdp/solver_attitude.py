@@ -159,14 +159,24 @@ class Solver_attitude:
         nu = len(UV)
         return ProblemSpec(knots, [nu, nu, nu], nxt, cost, dtype=np.float32, index_base=1)
 
-    def run(self, n_stages=None):
+    # state-axis labelling handed to the library: w3 (driven by the innermost torque U3) LAST, so the
+    # control-nested stage kernel applies; results are mapped back to the reference's dim order.
+    AXIS_ORDER = (0, 1, 3, 4, 5, 2)
+
+    def run(self, n_stages=None, relabel=True):
         spec = self.build_spec_full()
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
-        with Backup(spec, device=self.device) as bk:
-            out = bk.solve(n_st)
         shape = spec.n
-        self.F_values = out["J"].reshape(shape, order="F")
-        lab = out["idx"].reshape(shape, order="F") - 1
+        if relabel:
+            from .problem import permute_state_axes
+            pspec, to_old = permute_state_axes(spec, self.AXIS_ORDER)
+        else:
+            pspec, to_old = spec, (lambda x: x)
+        with Backup(pspec, device=self.device) as bk:
+            out = bk.solve(n_st)
+            self.kernel_variant = bk.info()["kernel_variant"]
+        self.F_values = to_old(out["J"]).reshape(shape, order="F")
+        lab = to_old(out["idx"]).reshape(shape, order="F") - 1
         nu = len(self.U_vector)
         i1, i2, i3 = lab % nu, (lab // nu) % nu, lab // (nu * nu)
         self.U_idx = (i1 + 1, i2 + 1, i3 + 1)

@@ -59,11 +59,27 @@ def test_solver_attitude_simplified(env):
         assert np.array_equal(sa.U_idx[ch].reshape(-1, order="F"), ref["idx"])
 
 
+def test_solver_attitude_relabelled_axes(env):
+    """run() hands the library the axes with w3 last (control-nested kernel); bit-exact against the
+    oracle on the SAME relabelled problem, and equal to the reference labelling up to lerp-order
+    rounding (a few ulp of float32)."""
+    hjbdp, _abi, c_oracle = env
+    sa = hjbdp.Solver_attitude(n_mesh_w=5, n_mesh_q=4)
+    sa.run(n_stages=6)
+    assert sa.kernel_variant == 1
+    spec = sa.build_spec_full()
+    pspec, to_old = hjbdp.permute_state_axes(spec, sa.AXIS_ORDER)
+    ref = c_oracle.sweep(_abi, pspec, 6)
+    assert np.array_equal(sa.F_values.reshape(-1, order="F"), to_old(ref["J"]))
+    plain = c_oracle.sweep(_abi, spec, 6)
+    assert np.max(np.abs(sa.F_values.reshape(-1, order="F") - plain["J"]) / np.maximum(1e-3, np.abs(plain["J"]))) < 2e-5
+
+
 def test_solver_attitude_full_6d(env):
     """Solver_attitude.run semantics (6-D x 3-D, single) at a reduced size."""
     hjbdp, _abi, c_oracle = env
     sa = hjbdp.Solver_attitude(n_mesh_w=5, n_mesh_q=4)
-    sa.run(n_stages=6)
+    sa.run(n_stages=6, relabel=False)
     spec = sa.build_spec_full()
     ref = c_oracle.sweep(_abi, spec, 6)
     assert np.array_equal(sa.F_values.reshape(-1, order="F"), ref["J"])

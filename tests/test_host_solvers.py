@@ -115,3 +115,22 @@ def test_attitude_simplified_structure():
     assert spec.n == (1000, 300) and spec.m == (3,) and sa.N_stage == 6000
     assert spec.next_terms[0][1].dims == (2,) and spec.next_terms[1][1].dims == (0,)   # w+ <- u ; theta+ <- w
     assert np.isclose(s_t[0], -np.deg2rad(20)) and np.isclose(s_w[-1], np.deg2rad(50))
+
+
+def test_permute_state_axes_is_a_relabelling(orc):
+    """Relabelled problem == original problem (up to lerp-order rounding) after mapping back."""
+    import hjbdp
+    from problems import random_problem, random_terminal
+    _abi, c_oracle, hjb_oracle = orc
+    spec = random_problem(9, (5, 4, 6), (3, 2), dtype=np.float64)
+    term = random_terminal(spec, 2)
+    pspec, to_old = hjbdp.permute_state_axes(spec, (2, 0, 1))
+    assert pspec.n == (6, 5, 4)
+    tperm = np.transpose(term.reshape(spec.n, order="F"), (2, 0, 1)).reshape(-1, order="F")
+    assert np.array_equal(to_old(tperm), term)
+    a = c_oracle.sweep(_abi, spec, 3, terminal=term)
+    b = c_oracle.sweep(_abi, pspec, 3, terminal=tperm)
+    assert np.max(np.abs(to_old(b["J"]) - a["J"]) / np.maximum(1.0, np.abs(a["J"]))) < 1e-12
+    assert np.mean(to_old(b["idx"]) == a["idx"]) > 0.99
+    with pytest.raises(ValueError):
+        hjbdp.permute_state_axes(spec, (0, 0, 1))

@@ -44,7 +44,10 @@ add("Solver_attitude simplified channel 1000x300x3, 5999 stages, f64", spec.nS *
 sa = hjbdp.Solver_attitude(n_mesh_w=11, n_mesh_q=10)
 spec = sa.build_spec_full()
 out, v = solve_timed(spec, 19)
-add("Solver_attitude.run 11^3x10^3 x 27, 19 stages, f32", spec.nS * 27 * 19, out["sweep_ms"], v)
+add("Solver_attitude.run 11^3x10^3 x 27, 19 stages, f32 (reference axis order)", spec.nS * 27 * 19, out["sweep_ms"], v)
+pspec, _ = hjbdp.permute_state_axes(spec, sa.AXIS_ORDER)
+out, v = solve_timed(pspec, 19)
+add("Solver_attitude.run, same, w3 relabelled last", spec.nS * 27 * 19, out["sweep_ms"], v)
 pa = hjbdp.Solver_pos_att()
 sx, sv, st, sw = pa.grids()
 spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
