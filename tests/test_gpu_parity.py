@@ -400,3 +400,35 @@ def test_policy_lookup_bit_exact(env, dtype):
                                               rng.standard_normal((5, 4)))
     q = rng.uniform(-1, 1, size=(100, 2))
     assert np.array_equal(pol.lookup_many(q), np.array([pol(*p) for p in q]))
+
+
+def test_c2_full_size_properties(env):
+    """BASELINE configs[1] at its FULL size (101^3 states x 21^3 controls): too big for a whole
+    oracle sweep, so (1) two independent kernels (control-nested variant 1 and packed variant 4)
+    must agree bit for bit on every state, (2) one whole plane of stage 2 is recomputed by the
+    oracle from the GPU's own stage-1 J (slab with halos) and must match bit for bit, and
+    (3) size-independent properties hold: J >= 0, J(0) = 0, J(x) = J(-x), J_k monotone in the horizon."""
+    hjbdp, _abi, c_oracle = env
+    from hjbdp.synthetic import position3d_spec
+    spec = position3d_spec(n=101, mu=21)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 4
+        o4 = bk.solve(2, keep_J=True, keep_idx=True)
+    with hjbdp.Backup(spec, variant=1) as bk:
+        o1 = bk.solve(2)
+    assert np.array_equal(o4["J"], o1["J"]) and np.array_equal(o4["idx"], o1["idx"])
+    J1 = o4["J_stages"][:, 1].reshape(101 * 101, 101, order="F")      # stage computed first (k_s = 2)
+    J2 = o4["J_stages"][:, 0].reshape(101 * 101, 101, order="F")
+    I2 = o4["idx_stages"][:, 0].reshape(101 * 101, 101, order="F")
+    p = 37
+    Jo, io = c_oracle.backup_stage(_abi, spec, np.asfortranarray(J1[:, p - 1:p + 2]).reshape(-1, order="F"),
+                                   slab=(p, p + 1, 1, 1))
+    assert np.array_equal(Jo.reshape(101 * 101, 3, order="F")[:, 1], J2[:, p])
+    assert np.array_equal(io, I2[:, p])
+    G = o4["J"].reshape(101, 101, 101, order="F")
+    assert G.min() >= 0.0 and G[50, 50, 50] == 0.0
+    assert np.allclose(G, G[::-1, ::-1, ::-1], rtol=2e-5, atol=1e-6)     # symmetric grid and control set
+    assert np.all(J2 >= J1 - 1e-6)                                       # longer horizon never cheaper
+    lab = o4["idx"] - 1
+    u = np.stack([lab % 21, (lab // 21) % 21, lab // 441], axis=1)
+    assert np.array_equal(u[(50 + 101 * (50 + 101 * 50))], [10, 10, 10])  # u*(0) = 0
