@@ -137,3 +137,31 @@ def test_dynamic_solver_default_config_runs(env):
     assert -9.0 < U[0] < -5.5 and np.abs(X[:, -1]).max() < 0.2
     X2, U2 = ds.get_optimal_path(np.array([2.0, 1.0]), "ssu", 1)
     assert ds.ssu_tol == 0.0 and ds.ssu_err_first == 0.0
+
+
+def test_c4_full_size_plane_vs_oracle(env):
+    """BASELINE configs[3] size (pos-att channel on 120^4 = 2.07e8 cells x 9 thruster combinations,
+    non-uniform sym_linspace knots): one stage on the GPU from a smooth terminal cost; one whole
+    plane of the last axis is recomputed by the oracle (slab + halos) and must match bit for bit."""
+    hjbdp, _abi, c_oracle = env
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = "terms"
+    pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = 120
+    sx, sv, st, sw = pa.grids()
+    spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                    pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    assert spec.nS == 120 ** 4
+    X, V, T = np.meshgrid(sx, sv, st[0], indexing="ij")
+    inner = (np.sin(7 * X) + 3 * V ** 2 + np.cos(5 * T)).astype(np.float32).reshape(-1, order="F")
+    term = (inner[:, None] * (1.0 + 10.0 * sw[None, :] ** 2).astype(np.float32)).astype(np.float32)   # [120^3, 120]
+    with hjbdp.Backup(spec) as bk:
+        need = bk.info()
+        J, idx = bk.backup_stage(term.reshape(-1, order="F"))
+    hl, hh = need["halo_needed_lo"], need["halo_needed_hi"]
+    assert 6 <= hl <= 9 and 6 <= hh <= 9            # w moves up to ~7.5 cells per stage on this fine grid
+    p = 61
+    sub = np.asfortranarray(term[:, p - hl:p + 1 + hh]).reshape(-1, order="F")
+    Jo, io = c_oracle.backup_stage(_abi, spec, sub, slab=(p, p + 1, hl, hh))
+    n3 = 120 ** 3
+    assert np.array_equal(Jo.reshape(n3, -1, order="F")[:, hl], J.reshape(n3, 120, order="F")[:, p])
+    assert np.array_equal(io, idx.reshape(n3, 120, order="F")[:, p])

@@ -1,5 +1,8 @@
+"""Quick timing of the C2 stage kernel: python tools/time_c2.py [n] [mu] [stages] [variant] [lds_pad]"""
 import sys, time
-sys.path.insert(0,'optimal-control-dynamic-programming_amd'); sys.path.insert(0,'.')
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / 'optimal-control-dynamic-programming_amd'))
 import numpy as np, hjbdp
 from hjbdp.synthetic import position3d_spec
 n = int(sys.argv[1]) if len(sys.argv)>1 else 101
