@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--mu", type=int, default=21, help="control grid points per axis (config: 21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None, help="force a stage-kernel variant (testing)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --share-gpu is a 1-GPU test mode")
+    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses cuda:0")
+    ap.add_argument("--weak-mult", type=int, default=1, help="testing: planes per rank = n * weak-mult")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,15 +95,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # weak scaling: every rank owns args.n planes of the last axis
-    spec = position3d_spec(n=args.n, mu=args.mu, n_last=args.n * world)
+    spec = position3d_spec(n=args.n, mu=args.mu, n_last=args.n * world * args.weak_mult)
     sw = ShardedSweep(spec, rank, world, dev)
     if args.variant is not None:
         sw._handle.set_option("variant", args.variant)
@@ -127,7 +135,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     sw._handle.check_device_status()
     if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt[0])
 
@@ -149,7 +157,11 @@ def main():
         except Exception:
             traffic = None
     J_final = sw.owned_J()
-    checksum = float(J_final.double().sum())
+    cs = J_final.double().sum().reshape(1)
+    if world > 1:
+        cs = cs.cpu() if args.backend != "nccl" else cs
+        dist.all_reduce(cs)
+    checksum = float(cs[0])
     out = {
         "metric": "bellman_backups_per_s", "value": value, "unit": "backups/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,

@@ -144,6 +144,20 @@ class ShardedSweep:
             if self.halo_hi:
                 ops.append(dist.P2POp(dist.irecv, J[lo0 + self.owned:], self.rank + 1, group=self.group))
         if ops:
+            if J.is_cuda and dist.get_backend(self.group) == "gloo":
+                # test-only transport (several ranks sharing one GPU): gloo moves host memory
+                staged = []
+                for op in ops:
+                    host = op.tensor.cpu() if op.op is dist.isend else self.torch.empty(
+                        op.tensor.shape, dtype=op.tensor.dtype)
+                    staged.append((op, host))
+                works = dist.batch_isend_irecv([dist.P2POp(op.op, host, op.peer, group=self.group) for op, host in staged])
+                for w in works:
+                    w.wait()
+                for op, host in staged:
+                    if op.op is dist.irecv:
+                        op.tensor.copy_(host)
+                return
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 

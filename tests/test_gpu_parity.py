@@ -432,3 +432,30 @@ def test_c2_full_size_properties(env):
     lab = o4["idx"] - 1
     u = np.stack([lab % 21, (lab // 21) % 21, lab // 441], axis=1)
     assert np.array_equal(u[(50 + 101 * (50 + 101 * 50))], [10, 10, 10])  # u*(0) = 0
+
+
+def test_two_rank_sharded_bench_matches_single_rank(env):
+    """bench.py's multi-GPU path on ONE GPU: two torchrun ranks share cuda:0 and exchange halos over
+    gloo (the RCCL transport itself needs >1 GPU); the summed checksum must equal a single-rank run
+    on the same 2x-planes grid."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    common = ["--steps", "4", "--warmup", "1", "--n", "33", "--mu", "7", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, str(root / "bench.py"), "--weak-mult", "2"] + common,
+                         capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(root / "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                         capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and "halo" in b["config"]["sharding"]
+    assert abs(a["checksum_sum_J"] - b["checksum_sum_J"]) <= 1e-12 * abs(a["checksum_sum_J"])
+    assert b["config"]["states_per_gpu"] * 2 == a["config"]["states_per_gpu"]
