@@ -71,8 +71,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=101, help="state grid points per axis (config: 101)")
-    ap.add_argument("--mu", type=int, default=21, help="control grid points per axis (config: 21)")
+    ap.add_argument("--grid-n", dest="n", type=int, default=101, help="state grid points per axis (config: 101)")
+    ap.add_argument("--grid-mu", dest="mu", type=int, default=21, help="control grid points per axis (config: 21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None, help="force a stage-kernel variant (testing)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --share-gpu is a 1-GPU test mode")

@@ -445,7 +445,7 @@ def test_two_rank_sharded_bench_matches_single_rank(env):
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    common = ["--steps", "4", "--warmup", "1", "--n", "33", "--mu", "7", "--no-cpu-baseline"]
+    common = ["--steps", "4", "--warmup", "1", "--grid-n", "33", "--grid-mu", "7", "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, str(root / "bench.py"), "--weak-mult", "2"] + common,
                          capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-2000:]
