@@ -21,6 +21,7 @@
 #include "kernels_packed2.h"
 #include "kernels_ctrlsplit.h"
 #include "kernels_lookup.h"
+#include "kernels_tabled.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -61,6 +62,11 @@ struct Handle {
     size_t packed_lds = 0;
     size_t packed2_lds = 0;       // variant 4 (two controls per packed op)
     size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
+    bool tabled_ok = false;       // variant 5: per-axis (cell, t) tables for every axis (built on first use)
+    uint32_t dom_mask[HJB_MAX_D] = {0};
+    int64_t dom_entries[HJB_MAX_D] = {0};
+    DTabled htb{};
+    DTabled *dtb = nullptr;
     size_t nested_lds = 0;
     int variant = 0;
     int forced_variant = -1;
@@ -175,6 +181,19 @@ void launch_prep(int D, int grid, const DParams *dp, int a, const int32_t *dsz, 
         case 5: hipLaunchKernelGGL((k_prep_axis_table<T, 5>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
         case 6: hipLaunchKernelGGL((k_prep_axis_table<T, 6>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
         default: break;   // D == 1 has no outer axis
+    }
+}
+
+template <typename T>
+void launch_prep_t(int D, int grid, const DParams *dp, int a, const int32_t *dsz, int64_t n, TabEntry<T> *tab) {
+    dim3 g(grid), b(256);
+    switch (D) {
+        case 1: hipLaunchKernelGGL((k_prep_axis_table_t<T, 1>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        case 2: hipLaunchKernelGGL((k_prep_axis_table_t<T, 2>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        case 3: hipLaunchKernelGGL((k_prep_axis_table_t<T, 3>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        case 4: hipLaunchKernelGGL((k_prep_axis_table_t<T, 4>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        case 5: hipLaunchKernelGGL((k_prep_axis_table_t<T, 5>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
+        default: hipLaunchKernelGGL((k_prep_axis_table_t<T, 6>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
     }
 }
 
@@ -454,6 +473,26 @@ int build(Handle *h, const hjb_problem *p) {
             HIP_TRY(h, hipDeviceSynchronize());
         }
     }
+    // ---- variant 5 eligibility: (cell, t) tables of EVERY axis over its own domain (built lazily) ---
+    {
+        const int owned_last = P.n[D - 1];
+        size_t total = 0;
+        bool fits = true;
+        for (int a = 0; a < D; ++a) {
+            uint32_t m = 0;
+            for (int k = 0; k < p->n_next_terms[a]; ++k) m |= p->next_terms[a][k].mask;
+            h->dom_mask[a] = m;
+            int64_t ne = 1;
+            for (int d = 0; d < D + C; ++d)
+                if (m & (1u << d)) ne *= (d < D) ? (d == D - 1 ? owned_last : p->n[d]) : p->m[d - D];
+            h->dom_entries[a] = ne;
+            if (ne >= ((int64_t)1 << 31)) fits = false;
+            total += (size_t)ne * sizeof(TabEntry<T>);
+        }
+        // worth it only when the tables are small next to the per-stage work (nS * nU backups)
+        const bool small = total <= ((size_t)512 << 20) || (double)total <= 0.5 * (double)h->n_owned * (double)h->nU;
+        h->tabled_ok = fits && small && total <= ((size_t)16 << 30);
+    }
     if (h->nested_ok) {
         void *dnn = nullptr;
         int st2 = dev_alloc(h, sizeof(DNested), &dnn);
@@ -464,12 +503,57 @@ int build(Handle *h, const hjb_problem *p) {
     return HJB_OK;
 }
 
+template <typename T>
+int ensure_tabled_t(Handle *h) {
+    if (h->dtb) return HJB_OK;
+    const DParams &P = h->hp;
+    const int D = P.D, C = P.C;
+    const int owned_last = P.n[D - 1];
+    DTabled &TBh = h->htb;
+    memset(&TBh, 0, sizeof TBh);
+    for (int a = 0; a < D; ++a) {
+        DTabled::Axis &A = TBh.ax[a];
+        std::vector<int32_t> dsz(HJB_MAX_G, 1);
+        int64_t stride = 1;
+        for (int d = 0; d < D + C; ++d) {
+            if (!(h->dom_mask[a] & (1u << d))) continue;
+            const int sz = (d < D) ? (d == D - 1 ? owned_last : h->prob.n[d]) : h->prob.m[d - D];
+            dsz[d] = sz;
+            if (d < D) A.sstride[d] = (int32_t)stride;
+            else { A.cstride[d - D] = (int32_t)stride; A.has_ctrl = 1; }
+            stride *= sz;
+        }
+        void *dsz_d = nullptr, *tab = nullptr;
+        int st3 = upload(h, dsz, &dsz_d);
+        if (st3) return st3;
+        st3 = dev_alloc(h, (size_t)h->dom_entries[a] * sizeof(TabEntry<T>), &tab);
+        if (st3) return st3;
+        const int grid = (int)std::min<int64_t>((h->dom_entries[a] + 255) / 256, 65536);
+        launch_prep_t<T>(D, grid, h->dp, a, (const int32_t *)dsz_d, h->dom_entries[a], (TabEntry<T> *)tab);
+        A.tab = tab;
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipDeviceSynchronize());
+    void *d = nullptr;
+    int st3 = dev_alloc(h, sizeof(DTabled), &d);
+    if (st3) return st3;
+    HIP_TRY(h, hipMemcpy(d, &TBh, sizeof(DTabled), hipMemcpyHostToDevice));
+    h->dtb = (DTabled *)d;
+    return HJB_OK;
+}
+
+int ensure_tabled(Handle *h) {
+    return h->dtype == HJB_F32 ? ensure_tabled_t<float>(h) : ensure_tabled_t<double>(h);
+}
+
 void choose_launch(Handle *h) {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     // few states x many controls (Kirk): one wave per state, controls across lanes
     const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
     h->variant = h->forced_variant >= 0 ? h->forced_variant
-                                        : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : 0)));
+                                        : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : (h->tabled_ok ? 5 : 0))));
+    // build variant 5's tables now (never inside a launch: launches may be under graph capture)
+    if (h->variant == 5 && ensure_tabled(h) != HJB_OK) h->variant = 0;
     h->block = 256;
     h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
     const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass (variant 4: 256)
@@ -495,6 +579,20 @@ int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t s
             default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
         }
 #undef HJB_LAUNCH_SPLIT
+        HIP_TRY(h, hipGetLastError());
+        return HJB_OK;
+    }
+    if (h->variant == 5) {
+        if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 5 tables missing");
+        switch (D) {
+            case 1: hipLaunchKernelGGL((k_backup_tabled<T, 1>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 2: hipLaunchKernelGGL((k_backup_tabled<T, 2>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 3: hipLaunchKernelGGL((k_backup_tabled<T, 3>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 4: hipLaunchKernelGGL((k_backup_tabled<T, 4>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 5: hipLaunchKernelGGL((k_backup_tabled<T, 5>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 6: hipLaunchKernelGGL((k_backup_tabled<T, 6>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
+        }
         HIP_TRY(h, hipGetLastError());
         return HJB_OK;
     }
@@ -807,7 +905,9 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     Handle *h = (Handle *)hh;
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) {
-        if (value < -1 || value > 4) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value < -1 || value > 5) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value == 5 && !h->tabled_ok)
+            return fail(h, HJB_E_UNSUPPORTED, "variant 5 (tabled) needs per-axis tables that fit (see hjbdp.hip)");
         if (value == 4 && !h->packed_mode)
             return fail(h, HJB_E_UNSUPPORTED, "variant 4 (packed, control pairs) needs float32 and the canonical spacecraft structure");
         if (value == 2 && !h->packed_mode)

@@ -81,7 +81,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [None, 0, 3])
+@pytest.mark.parametrize("variant", [None, 0, 3, 5])
 @pytest.mark.parametrize("n,m,dtype,nonuniform", SHAPES)
 def test_random_problems_bit_exact(env, n, m, dtype, nonuniform, variant):
     hjbdp, _abi, c_oracle = env
@@ -171,7 +171,7 @@ def test_packed_variant_slab(env):
     Jw, iw = c_oracle.backup_stage(_abi, spec, term)
     T3 = term.reshape(72, 14, order="F")
     b, e, lo, hi = 5, 10, 2, 2
-    for v in (2, 4):
+    for v in (2, 4, 5):
         with hjbdp.Backup(spec, slab=(b, e, lo, hi), variant=v) as bk:
             assert bk.info()["kernel_variant"] == v
             Jo, io = bk.backup_stage(np.asfortranarray(T3[:, b - lo:e + hi]).reshape(-1, order="F"))
@@ -201,7 +201,7 @@ def test_edge_shapes_all_variants(env, n, m, dtype):
     term = random_terminal(spec, 1)
     ref = c_oracle.sweep(_abi, spec, 3, terminal=term)
     seen = set()
-    for v in (None, 0, 1, 2, 3, 4):
+    for v in (None, 0, 1, 2, 3, 4, 5):
         try:
             bk = hjbdp.Backup(spec, variant=v)
         except hjbdp.HjbError as e:
@@ -231,7 +231,7 @@ def test_variant_1_refused_when_not_applicable(env):
     hjbdp, _abi, c_oracle = env
     spec = _kirk(hjbdp, "double", 5, 8, 9).build_spec()   # both axes depend on u
     with hjbdp.Backup(spec) as bk:
-        assert bk.info()["kernel_variant"] == 0
+        assert bk.info()["kernel_variant"] == 5           # general shape -> table-driven generic kernel
         with pytest.raises(hjbdp.HjbError) as ei:
             bk.set_option("variant", 1)
         assert ei.value.status == _abi.HJB_E_UNSUPPORTED
