@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --share-gpu is a 1-GPU test mode")
     ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses cuda:0")
     ap.add_argument("--weak-mult", type=int, default=1, help="testing: planes per rank = n * weak-mult")
+    ap.add_argument("--j-storage", default="f32", choices=["f32", "f16"],
+                    help="f16: cost-to-go stored as IEEE half, float32 arithmetic (BASELINE config 5; not the headline line)")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,7 +110,8 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # weak scaling: every rank owns args.n planes of the last axis
-    spec = position3d_spec(n=args.n, mu=args.mu, n_last=args.n * world * args.weak_mult)
+    spec = position3d_spec(n=args.n, mu=args.mu, n_last=args.n * world * args.weak_mult,
+                           j_storage=np.float16 if args.j_storage == "f16" else None)
     sw = ShardedSweep(spec, rank, world, dev)
     if args.variant is not None:
         sw._handle.set_option("variant", args.variant)
@@ -146,7 +149,7 @@ def main():
     launch_ms = dev_ms / args.steps                                 # one kernel per step
     D = spec.D
     alg_flops = f_alg(D) * backups_per_launch
-    alg_bytes = (2 * spec.dtype.itemsize + 4) * states_per_rank     # read J_{k+1}, write J_k + int32 argmin
+    alg_bytes = (2 * spec.j_dtype.itemsize + 4) * states_per_rank   # read J_{k+1}, write J_k + int32 argmin
     tflops = alg_flops / (launch_ms * 1e-3) / 1e12
     gbs = alg_bytes / (launch_ms * 1e-3) / 1e9
     traffic = None
@@ -165,7 +168,8 @@ def main():
     out = {
         "metric": "bellman_backups_per_s", "value": value, "unit": "backups/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.j_storage == "f32" else "f32 (J stored as f16)", "data": "synthetic",
         "config": {"workload": "C2 Solver_position 3-DOF: %d^2 x %d states x %d^3 controls, 1 stage per step"
                                % (args.n, args.n * world, args.mu),
                    "states_per_gpu": states_per_rank, "controls": spec.nU, "stages": args.steps,
@@ -180,7 +184,7 @@ def main():
                      "note": "compute roofline binds (SURVEY 8d), HBM does not; peak = dense f32 MFMA peak = fp32 vector peak "
                              "(157.3 TFLOP/s); achieved = ALGORITHMIC flops (41 per backup) / launch time",
                      "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                             "alg_bytes_per_state": 2 * spec.dtype.itemsize + 4}},
+                             "alg_bytes_per_state": 2 * spec.j_dtype.itemsize + 4}},
         "checksum_sum_J": checksum,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

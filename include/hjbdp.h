@@ -49,6 +49,9 @@ extern "C" {
 
 #define HJB_F32 0
 #define HJB_F64 1
+#define HJB_F16S 2   /* float32 arithmetic, tables and knots; J buffers (terminal, J_final, J_stages,
+                        device J) stored as IEEE binary16, rounded to nearest even on store -
+                        halves the cost-to-go footprint (288 GB sizing of the 6-D grids)   */
 
 /* One broadcast term of an ordered sum  q = ((t0 + t1) + t2) + ...
  * This is MATLAB implicit expansion of vectors/arrays reshaped onto the
@@ -67,7 +70,7 @@ typedef struct hjb_problem {
     int32_t C;                      /* number of control axes, 1..HJB_MAX_C    */
     int32_t n[HJB_MAX_D];           /* state grid sizes (>= 2)                 */
     int32_t m[HJB_MAX_C];           /* control grid sizes (>= 1)               */
-    int32_t dtype;                  /* HJB_F32 / HJB_F64: arithmetic type of J,
+    int32_t dtype;                  /* HJB_F32 / HJB_F64 / HJB_F16S: arithmetic type of J,
                                        tables, knots and weights               */
     int32_t index_base;             /* 0 or 1 (MATLAB) for argmin labels       */
     const double *knots[HJB_MAX_D]; /* grid vectors, strictly increasing, may be

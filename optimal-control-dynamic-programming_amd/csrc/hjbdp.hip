@@ -362,7 +362,7 @@ int build(Handle *h, const hjb_problem *p) {
         if (h->nested_lds > 64 * 1024) ok = false;
         h->nested_ok = ok;
         h->packed_mode = 0;
-        if (ok && h->nested_fast && p->dtype == HJB_F32 && h->j_elems < ((int64_t)1 << 31) && p->n[D - 1] >= 2) {
+        if (ok && h->nested_fast && p->dtype != HJB_F64 && h->j_elems < ((int64_t)1 << 31) && p->n[D - 1] >= 2) {
             bool pk = (ax_kin == P.axis[D - 1].n_prefix) && N.m_in <= kPackedMaxIn;   // last axis: state part + b[u_in] only
             // canonical shape: last axis = state part + b[u_in]; <= 1 cost term per outer loop level;
             // outer axes may have any terms (their cells/weights are precomputed below)
@@ -543,7 +543,7 @@ int ensure_tabled_t(Handle *h) {
 }
 
 int ensure_tabled(Handle *h) {
-    return h->dtype == HJB_F32 ? ensure_tabled_t<float>(h) : ensure_tabled_t<double>(h);
+    return h->dtype != HJB_F64 ? ensure_tabled_t<float>(h) : ensure_tabled_t<double>(h);
 }
 
 void choose_launch(Handle *h) {
@@ -552,6 +552,8 @@ void choose_launch(Handle *h) {
     const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
     h->variant = h->forced_variant >= 0 ? h->forced_variant
                                         : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : (h->tabled_ok ? 5 : 0))));
+    if (h->dtype == HJB_F16S && h->variant >= 1 && h->variant <= 3)     // float16 J storage: variants 0, 4, 5 only
+        h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->tabled_ok ? 5 : 0);
     // build variant 5's tables now (never inside a launch: launches may be under graph capture)
     if (h->variant == 5 && ensure_tabled(h) != HJB_OK) h->variant = 0;
     h->block = 256;
@@ -562,10 +564,47 @@ void choose_launch(Handle *h) {
     if (h->grid < 1) h->grid = 1;
 }
 
-template <typename T>
-int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t st) {
+template <typename T, typename TJ>
+int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t st) {
+    constexpr bool same = std::is_same<T, TJ>::value;   // variants 1-3 exist for J stored in the arithmetic type only
     const int D = h->hp.D;
     dim3 g(h->grid), b(h->block);
+    if (h->variant == 5) {
+        if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 5 tables missing");
+        switch (D) {
+            case 1: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 1>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 2: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 2>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 3: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 3>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 4: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 4>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 5: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 5>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 6: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 6>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return HJB_OK;
+    }
+    if (h->variant == 4) {
+        if constexpr (std::is_same<T, float>::value) {
+            const size_t lds = h->packed2_lds + h->lds_pad;
+#define HJB_LAUNCH_PACKED2(DD)                                                                                       \
+    case DD:                                                                                                         \
+        hipLaunchKernelGGL((k_backup_packed2<TJ, DD>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);                      \
+        break;
+            switch (D) {
+                HJB_LAUNCH_PACKED2(1) HJB_LAUNCH_PACKED2(2) HJB_LAUNCH_PACKED2(3) HJB_LAUNCH_PACKED2(4)
+                HJB_LAUNCH_PACKED2(5) HJB_LAUNCH_PACKED2(6)
+                default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
+            }
+#undef HJB_LAUNCH_PACKED2
+            HIP_TRY(h, hipGetLastError());
+            return HJB_OK;
+        } else {
+            return fail(h, HJB_E_UNSUPPORTED, "variant 4 is float32 only");
+        }
+    }
+    if (h->variant >= 1 && h->variant <= 3 && !same)
+        return fail(h, HJB_E_UNSUPPORTED, "variant %d does not support float16 J storage (use 0, 4 or 5)", h->variant);
+    if constexpr (same) {
     if (h->variant == 3) {
         const size_t lds = h->split_j_in_lds ? (size_t)h->j_elems * sizeof(T) : 0;
 #define HJB_LAUNCH_SPLIT(DD)                                                                                         \
@@ -581,39 +620,6 @@ int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t s
 #undef HJB_LAUNCH_SPLIT
         HIP_TRY(h, hipGetLastError());
         return HJB_OK;
-    }
-    if (h->variant == 5) {
-        if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 5 tables missing");
-        switch (D) {
-            case 1: hipLaunchKernelGGL((k_backup_tabled<T, 1>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 2: hipLaunchKernelGGL((k_backup_tabled<T, 2>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 3: hipLaunchKernelGGL((k_backup_tabled<T, 3>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 4: hipLaunchKernelGGL((k_backup_tabled<T, 4>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 5: hipLaunchKernelGGL((k_backup_tabled<T, 5>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 6: hipLaunchKernelGGL((k_backup_tabled<T, 6>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
-        }
-        HIP_TRY(h, hipGetLastError());
-        return HJB_OK;
-    }
-    if (h->variant == 4) {
-        if constexpr (std::is_same<T, float>::value) {
-            const size_t lds = h->packed2_lds + h->lds_pad;
-#define HJB_LAUNCH_PACKED2(DD)                                                                                       \
-    case DD:                                                                                                         \
-        hipLaunchKernelGGL((k_backup_packed2<DD>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);                      \
-        break;
-            switch (D) {
-                HJB_LAUNCH_PACKED2(1) HJB_LAUNCH_PACKED2(2) HJB_LAUNCH_PACKED2(3) HJB_LAUNCH_PACKED2(4)
-                HJB_LAUNCH_PACKED2(5) HJB_LAUNCH_PACKED2(6)
-                default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
-            }
-#undef HJB_LAUNCH_PACKED2
-            HIP_TRY(h, hipGetLastError());
-            return HJB_OK;
-        } else {
-            return fail(h, HJB_E_UNSUPPORTED, "variant 4 is float32 only");
-        }
     }
     if (h->variant == 2) {
         if constexpr (std::is_same<T, float>::value) {
@@ -660,13 +666,16 @@ int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t s
         HIP_TRY(h, hipGetLastError());
         return HJB_OK;
     }
+    }  // if constexpr (same)
+    if (h->variant != 0)   // every other variant returned above: never fall through to the generic kernel silently
+        return fail(h, HJB_E_DEVICE, "internal: kernel variant %d was not dispatched", h->variant);
     switch (D) {
-        case 1: hipLaunchKernelGGL((k_backup_generic<T, 1>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 2: hipLaunchKernelGGL((k_backup_generic<T, 2>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 3: hipLaunchKernelGGL((k_backup_generic<T, 3>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 4: hipLaunchKernelGGL((k_backup_generic<T, 4>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 5: hipLaunchKernelGGL((k_backup_generic<T, 5>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 6: hipLaunchKernelGGL((k_backup_generic<T, 6>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 1: hipLaunchKernelGGL((k_backup_generic<T, TJ, 1>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 2: hipLaunchKernelGGL((k_backup_generic<T, TJ, 2>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 3: hipLaunchKernelGGL((k_backup_generic<T, TJ, 3>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 4: hipLaunchKernelGGL((k_backup_generic<T, TJ, 4>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 5: hipLaunchKernelGGL((k_backup_generic<T, TJ, 5>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
+        case 6: hipLaunchKernelGGL((k_backup_generic<T, TJ, 6>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
         default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
     }
     HIP_TRY(h, hipGetLastError());
@@ -674,8 +683,9 @@ int launch_stage_t(Handle *h, const T *dJn, T *dJo, int32_t *didx, hipStream_t s
 }
 
 int launch_stage(Handle *h, const void *dJn, void *dJo, int32_t *didx, hipStream_t st) {
-    if (h->dtype == HJB_F32) return launch_stage_t<float>(h, (const float *)dJn, (float *)dJo, didx, st);
-    return launch_stage_t<double>(h, (const double *)dJn, (double *)dJo, didx, st);
+    if (h->dtype == HJB_F16S) return launch_stage_t<float, _Float16>(h, (const _Float16 *)dJn, (_Float16 *)dJo, didx, st);
+    if (h->dtype == HJB_F32) return launch_stage_t<float, float>(h, (const float *)dJn, (float *)dJo, didx, st);
+    return launch_stage_t<double, double>(h, (const double *)dJn, (double *)dJo, didx, st);
 }
 
 int ensure_work(Handle *h) {
@@ -801,7 +811,7 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
     *out = nullptr;
     if (p->D < 1 || p->D > HJB_MAX_D) return fail(nullptr, HJB_E_UNSUPPORTED, "D=%d not in 1..%d", p->D, HJB_MAX_D);
     if (p->C < 1 || p->C > HJB_MAX_C) return fail(nullptr, HJB_E_UNSUPPORTED, "C=%d not in 1..%d", p->C, HJB_MAX_C);
-    if (p->dtype != HJB_F32 && p->dtype != HJB_F64) return fail(nullptr, HJB_E_UNSUPPORTED, "dtype %d", p->dtype);
+    if (p->dtype != HJB_F32 && p->dtype != HJB_F64 && p->dtype != HJB_F16S) return fail(nullptr, HJB_E_UNSUPPORTED, "dtype %d", p->dtype);
     if (p->index_base != 0 && p->index_base != 1) return fail(nullptr, HJB_E_INVALID, "index_base must be 0 or 1");
     const int G = p->D + p->C;
     int64_t nS = 1, nU = 1;
@@ -846,7 +856,7 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
     Handle *h = new Handle();
     h->device = device;
     h->dtype = p->dtype;
-    h->esz = p->dtype == HJB_F32 ? 4 : 8;
+    h->esz = p->dtype == HJB_F16S ? 2 : (p->dtype == HJB_F32 ? 4 : 8);
     h->prob = *p;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) {
@@ -854,7 +864,7 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
         delete h;
         return st;
     }
-    int st = p->dtype == HJB_F32 ? build<float>(h, p) : build<double>(h, p);
+    int st = p->dtype != HJB_F64 ? build<float>(h, p) : build<double>(h, p);
     if (st) {
         g_last_error = h->err;
         for (void *d : h->allocs) (void)hipFree(d);

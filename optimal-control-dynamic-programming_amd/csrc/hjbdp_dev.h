@@ -47,4 +47,10 @@ struct DParams {
     DTerm cost[HJB_MAX_TERMS];
 };
 
+// J storage type helpers: J may be stored narrower than the arithmetic type (HJB_F16S: IEEE binary16
+// storage, float32 arithmetic; conversion to half rounds to nearest even, widening is exact).
+typedef _Float16 half_t;
+template <typename T, typename TJ> __device__ __forceinline__ T ldj(const TJ *__restrict__ p, int64_t i) { return (T)p[i]; }
+template <typename T, typename TJ> __device__ __forceinline__ void stj(TJ *__restrict__ p, int64_t i, T v) { p[i] = (TJ)v; }
+
 }  // namespace hjb

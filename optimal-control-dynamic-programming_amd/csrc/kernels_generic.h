@@ -51,9 +51,9 @@ __device__ __forceinline__ T term_value(const DTerm &t, const int (&si)[D], cons
     return static_cast<const T *>(t.data)[off];
 }
 
-template <typename T, int D>
+template <typename T, typename TJ, int D>
 __global__ void __launch_bounds__(256)
-k_backup_generic(const DParams *__restrict__ P, const T *__restrict__ Jn, T *__restrict__ Jout,
+k_backup_generic(const DParams *__restrict__ P, const TJ *__restrict__ Jn, TJ *__restrict__ Jout,
                  int32_t *__restrict__ idx_out) {
     const int C = P->C;
     const int64_t n_owned = P->n_owned;
@@ -121,7 +121,7 @@ k_backup_generic(const DParams *__restrict__ P, const T *__restrict__ Jn, T *__r
 #pragma unroll
                 for (int a = 0; a < D; ++a)
                     if (c & (1 << a)) off += P->jstride[a];
-                v[c] = Jn[off];
+                v[c] = ldj<T, TJ>(Jn, off);
             }
 #pragma unroll
             for (int a = 0; a < D; ++a) {
@@ -165,7 +165,7 @@ k_backup_generic(const DParams *__restrict__ P, const T *__restrict__ Jn, T *__r
             label = j0 + (int64_t)P->m[0] * (j1 + (int64_t)P->m[1] * j2);
         }
         const int64_t in_plane = ls % P->inner, pl = ls / P->inner;
-        Jout[in_plane + P->inner * (pl + P->halo_lo)] = best;
+        stj<T, TJ>(Jout, in_plane + P->inner * (pl + P->halo_lo), best);
         if (idx_out) idx_out[ls] = (int32_t)(label + P->index_base);
     }
 }

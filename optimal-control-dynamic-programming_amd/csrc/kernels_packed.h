@@ -42,6 +42,28 @@ __device__ __forceinline__ float term_value32(const DTerm &t, const int (&si)[D]
     return static_cast<const float *>(t.data)[off];   // state-only (prefix) terms
 }
 
+// same, J stored as IEEE half: two adjacent halves per 4-byte load
+typedef _Float16 h2u __attribute__((ext_vector_type(2), aligned(2)));
+template <int D>
+__device__ __forceinline__ void load_corners(const _Float16 *__restrict__ Jn, int b2, const int (&js)[D],
+                                             float (&v)[1 << D]) {
+    if constexpr (D >= 2) {
+#pragma unroll
+        for (int c = 0; c < (1 << D); c += 2) {
+            int off = b2;
+#pragma unroll
+            for (int a = 1; a < D; ++a)
+                if (c & (1 << a)) off += js[a];
+            const h2u p = *reinterpret_cast<const h2u *>(Jn + off);
+            v[c] = (float)p.x;
+            v[c + 1] = (float)p.y;
+        }
+    } else {
+        v[0] = (float)Jn[b2];
+        v[1] = (float)Jn[b2 + js[0]];
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void load_corners(const float *__restrict__ Jn, int b2, const int (&js)[D],
                                              float (&v)[1 << D]) {

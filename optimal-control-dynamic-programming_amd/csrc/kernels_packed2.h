@@ -14,10 +14,10 @@
 
 namespace hjb {
 
-template <int D>
+template <typename TJ, int D>
 __global__ void __launch_bounds__(256)
-k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const float *__restrict__ Jn,
-                 float *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
+                 TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const DAxis &axl = P->axis[D - 1];
@@ -339,7 +339,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 label = j0 + P->m[0] * (j1 + P->m[1] * best_j);
             }
             const int in_plane = ls % inner_sz, pl = ls / inner_sz;
-            Jout[in_plane + inner_sz * (pl + P->halo_lo)] = best;
+            Jout[in_plane + inner_sz * (pl + P->halo_lo)] = (TJ)best;
             if (idx_out) idx_out[ls] = label + P->index_base;
         }
     }

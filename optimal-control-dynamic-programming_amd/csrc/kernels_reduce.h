@@ -64,7 +64,9 @@ k_final_sums(const double *__restrict__ partials, double *__restrict__ sums) {
 
 inline int launch_monitor_sums(int dtype, const void *J, const int32_t *idx, int64_t n, double *partials, double *sums,
                                hipStream_t st) {
-    if (dtype == HJB_F32)
+    if (dtype == HJB_F16S)
+        hipLaunchKernelGGL((k_partial_sums<_Float16>), dim3(kReduceBlocks), dim3(kReduceThreads), 0, st, (const _Float16 *)J, idx, n, partials);
+    else if (dtype == HJB_F32)
         hipLaunchKernelGGL((k_partial_sums<float>), dim3(kReduceBlocks), dim3(kReduceThreads), 0, st, (const float *)J, idx, n, partials);
     else
         hipLaunchKernelGGL((k_partial_sums<double>), dim3(kReduceBlocks), dim3(kReduceThreads), 0, st, (const double *)J, idx, n, partials);

@@ -22,6 +22,7 @@ HJB_E_HALO = 5
 
 HJB_F32 = 0
 HJB_F64 = 1
+HJB_F16S = 2
 
 
 class hjb_term(C.Structure):

@@ -141,7 +141,7 @@ class Backup:
         """[J_k, idx] = min(g + F(x_next), [], ctrl): J_next/J_k in the (haloed)
         column-major J layout, idx int32 labels of the owned states."""
         inf = self.info()
-        dt = self.spec.dtype
+        dt = self.spec.j_dtype
         Jn = np.ascontiguousarray(np.asarray(J_next, dtype=dt).reshape(-1, order="F"))
         if Jn.size != inf["j_elems"]:
             raise ValueError("J_next has %d elements, the handle's J layout has %d" % (Jn.size, inf["j_elems"]))
@@ -169,7 +169,7 @@ class Backup:
         """Backward sweep of n_stages backups.  Returns a dict with J (final), idx
         (final), optional J_stages/idx_stages [nS, n_stages] with reference stage
         k_s at column k_s-1, stages_done, stopped_early, sweep_ms."""
-        nS, dt = self.spec.nS, self.spec.dtype
+        nS, dt = self.spec.nS, self.spec.j_dtype
         o = _abi.hjb_solve_opts()
         o.n_stages = int(n_stages)
         o.monitor_period = int(monitor_period)

@@ -42,10 +42,14 @@ class ProblemSpec:
     pass `single(linspace(..))`-rounded values to mirror test/Dynamic_Solver.m:69),
     m[C] control grid sizes, next_terms[D][*], cost_terms[*]."""
 
-    def __init__(self, knots, m, next_terms, cost_terms, dtype=np.float64, index_base=0):
+    def __init__(self, knots, m, next_terms, cost_terms, dtype=np.float64, index_base=0, j_storage=None):
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise ValueError("dtype must be float32 or float64")
+        # j_storage=np.float16: J buffers are IEEE half (float32 arithmetic) - HJB_F16S
+        self.j_dtype = self.dtype if j_storage is None else np.dtype(j_storage)
+        if self.j_dtype != self.dtype and not (self.j_dtype == np.float16 and self.dtype == np.float32):
+            raise ValueError("j_storage must be float16 with float32 arithmetic")
         self.knots = [np.ascontiguousarray(k, dtype=np.float64) for k in knots]
         self.D = len(self.knots)
         self.n = tuple(len(k) for k in self.knots)
@@ -90,7 +94,7 @@ class ProblemSpec:
                 keep.append(t.data)
         for c in range(self.C):
             p.m[c] = self.m[c]
-        p.dtype = _abi.HJB_F32 if self.dtype == np.float32 else _abi.HJB_F64
+        p.dtype = (_abi.HJB_F16S if self.j_dtype == np.float16 else _abi.HJB_F32) if self.dtype == np.float32 else _abi.HJB_F64
         p.index_base = self.index_base
         p.n_cost_terms = len(self.cost_terms)
         for k, t in enumerate(self.cost_terms):
@@ -123,7 +127,8 @@ def permute_state_axes(spec: ProblemSpec, order):
     knots = [spec.knots[a] for a in order]
     nxt = [[remap(t) for t in spec.next_terms[a]] for a in order]
     cost = [remap(t) for t in spec.cost_terms]
-    new = ProblemSpec(knots, spec.m, nxt, cost, dtype=spec.dtype, index_base=spec.index_base)
+    new = ProblemSpec(knots, spec.m, nxt, cost, dtype=spec.dtype, index_base=spec.index_base,
+                      j_storage=None if spec.j_dtype == spec.dtype else spec.j_dtype)
     inv = [order.index(a) for a in range(D)]
 
     def to_old(flat):

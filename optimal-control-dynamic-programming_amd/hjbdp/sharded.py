@@ -92,7 +92,8 @@ class ShardedSweep:
         self.inner = spec.nS // nl
         self.owned = self.end - self.begin
         self.nplanes = self.owned + self.halo_lo + self.halo_hi
-        tdt = torch.float32 if spec.dtype == np.float32 else torch.float64
+        tdt = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32,
+               np.dtype(np.float64): torch.float64}[np.dtype(spec.j_dtype)]
         # haloed J layout [plane, inner] (row-major torch view of column-major [inner, plane])
         self.J = [torch.zeros((self.nplanes, self.inner), dtype=tdt, device=self.device) for _ in range(2)]
         self.idx = torch.zeros((self.owned, self.inner), dtype=torch.int32, device=self.device)
@@ -118,7 +119,7 @@ class ShardedSweep:
         J = self.J[self.cur]
         J.zero_()
         if J_global is not None:
-            g = self.torch.as_tensor(np.asarray(J_global, dtype=self.spec.dtype).reshape(self.spec.n[-1], self.inner))
+            g = self.torch.as_tensor(np.asarray(J_global, dtype=self.spec.j_dtype).reshape(self.spec.n[-1], self.inner))
             J[self.halo_lo:self.halo_lo + self.owned] = g[self.begin:self.end].to(self.device)
 
     def exchange_halos(self):

@@ -10,7 +10,7 @@ from .problem import ProblemSpec, Term
 
 
 def position3d_spec(n=101, mu=21, h=0.005, mass=4.16, qx=6.0, r=0.1, x_lim=0.5, u_lim=0.26, dtype=np.float32,
-                    n_last=None):
+                    n_last=None, j_storage=None):
     """C2: 'Solver_position 3-DOF, 101^3 state x 21^3 control grid' - the joint 3-D
     generalisation of position-control/Solver_position.m (:49-72 ranges, Mass, Q, R;
     :84 thrust +-0.26).  D=3 affine chain x+ = (I + h*N) x + (h/Mass) u with N
@@ -34,4 +34,4 @@ def position3d_spec(n=101, mu=21, h=0.005, mass=4.16, qx=6.0, r=0.1, x_lim=0.5, 
         nxt.append(terms)
     cost = [Term((j,), f(qx) * knots[j] ** 2) for j in range(3)]
     cost += [Term((3 + c,), (r * u ** 2).astype(dtype)) for c in range(3)]
-    return ProblemSpec(knots, [mu, mu, mu], nxt, cost, dtype=dtype, index_base=1)
+    return ProblemSpec(knots, [mu, mu, mu], nxt, cost, dtype=dtype, index_base=1, j_storage=j_storage)

@@ -47,7 +47,7 @@ def backup_stage(abi, spec, J_next, slab=None, nthreads=0):
     """One canonical-arithmetic backup on the CPU.  Returns (J_out flat, idx)."""
     l = lib(abi)
     p, keep = spec.to_c(slab)
-    Jn = np.ascontiguousarray(np.asarray(J_next, dtype=spec.dtype).reshape(-1, order="F"))
+    Jn = np.ascontiguousarray(np.asarray(J_next, dtype=spec.j_dtype).reshape(-1, order="F"))
     Jo = Jn.copy()
     if slab is None:
         n_owned = spec.nS
@@ -65,7 +65,7 @@ def sweep(abi, spec, n_stages, terminal=None, keep_J=False, keep_idx=False, moni
           nthreads=0):
     l = lib(abi)
     p, keep = spec.to_c()
-    nS, dt = spec.nS, spec.dtype
+    nS, dt = spec.nS, spec.j_dtype
     o = abi.hjb_solve_opts()
     o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
     if terminal is not None:

@@ -26,6 +26,7 @@
  *           (= cascade min over dims D+C-1, ..., D of Solver_attitude.m:400-409)
  * Compile with -ffp-contract=off so only the explicit fma() contracts.
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -58,7 +59,7 @@ static void build_term(const hjb_problem *p, const hjb_term *t, term_t *out) {
 
 static int validate(const hjb_problem *p) {
     if (!p || p->D < 1 || p->D > HJB_MAX_D || p->C < 1 || p->C > HJB_MAX_C) return HJB_E_INVALID;
-    if (p->dtype != HJB_F32 && p->dtype != HJB_F64) return HJB_E_UNSUPPORTED;
+    if (p->dtype != HJB_F32 && p->dtype != HJB_F64 && p->dtype != HJB_F16S) return HJB_E_UNSUPPORTED;
     for (int a = 0; a < p->D; ++a) {
         if (p->n[a] < 2 || !p->knots[a]) return HJB_E_INVALID;
         if (p->n_next_terms[a] < 1 || p->n_next_terms[a] > HJB_MAX_TERMS) return HJB_E_INVALID;
@@ -188,9 +189,32 @@ DEFINE_BACKUP(double, backup_f64, fma)
 
 /* one backup.  J buffers are in the haloed slab layout of hjb_problem (whole
  * grid when the slab fields are zero); idx_out covers owned states only. */
+/* IEEE binary16 <-> float (F16C): widening is exact, narrowing rounds to nearest even - the same
+ * conversions the GPU performs for HJB_F16S storage. */
+static float h2f(uint16_t h) { return _cvtsh_ss(h); }
+static uint16_t f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+
+static int64_t j_elems_of(const hjb_problem *p) {
+    int D = p->D, sb = p->slab_begin, se = p->slab_end, hlo = p->halo_lo, hhi = p->halo_hi;
+    if (sb == 0 && se == 0) { se = p->n[D - 1]; hlo = hhi = 0; }
+    int64_t s = (se + hhi) - (sb - hlo);
+    for (int a = 0; a + 1 < D; ++a) s *= p->n[a];
+    return s;
+}
+
 int orc_backup_stage(const hjb_problem *p, const void *J_next, void *J_out, int32_t *idx_out, int nthreads) {
     int st = validate(p);
     if (st) return st;
+    if (p->dtype == HJB_F16S) {   /* float32 arithmetic on widened J, result narrowed on store */
+        int64_t ne = j_elems_of(p);
+        float *a = (float *)malloc(sizeof(float) * (ne > 0 ? ne : 1)), *b = (float *)malloc(sizeof(float) * (ne > 0 ? ne : 1));
+        if (!a || !b) { free(a); free(b); return HJB_E_NOMEM; }
+        for (int64_t i = 0; i < ne; ++i) { a[i] = h2f(((const uint16_t *)J_next)[i]); b[i] = h2f(((const uint16_t *)J_out)[i]); }
+        st = backup_f32(p, a, b, idx_out, nthreads);
+        for (int64_t i = 0; i < ne; ++i) ((uint16_t *)J_out)[i] = f2h(b[i]);
+        free(a); free(b);
+        return st;
+    }
     if (p->dtype == HJB_F32) return backup_f32(p, (const float *)J_next, (float *)J_out, idx_out, nthreads);
     return backup_f64(p, (const double *)J_next, (double *)J_out, idx_out, nthreads);
 }
@@ -202,7 +226,7 @@ int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, in
     if (p->slab_begin || p->slab_end) return HJB_E_UNSUPPORTED;
     int64_t nS = 1;
     for (int a = 0; a < p->D; ++a) nS *= p->n[a];
-    size_t es = p->dtype == HJB_F32 ? 4 : 8;
+    size_t es = p->dtype == HJB_F16S ? 2 : (p->dtype == HJB_F32 ? 4 : 8);
     char *A = (char *)calloc(nS, es), *B = (char *)calloc(nS, es);
     int32_t *idx = (int32_t *)calloc(nS, sizeof(int32_t));
     if (!A || !B || !idx) return HJB_E_NOMEM;
@@ -220,7 +244,8 @@ int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, in
         if (o->monitor_period > 0 && (k_s % o->monitor_period) == 0) {
             double fs = 0, is = 0;
             for (int64_t i = 0; i < nS; ++i) {
-                fs += p->dtype == HJB_F32 ? (double)((float *)A)[i] : ((double *)A)[i];
+                fs += p->dtype == HJB_F16S ? (double)h2f(((uint16_t *)A)[i])
+                                           : (p->dtype == HJB_F32 ? (double)((float *)A)[i] : ((double *)A)[i]);
                 is += (double)idx[i];
             }
             e = fs - fprev; e2 = is - iprev;

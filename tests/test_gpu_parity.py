@@ -459,3 +459,44 @@ def test_two_rank_sharded_bench_matches_single_rank(env):
     assert b["n_gpus"] == 2 and b["scaling"] == "weak" and "halo" in b["config"]["sharding"]
     assert abs(a["checksum_sum_J"] - b["checksum_sum_J"]) <= 1e-12 * abs(a["checksum_sum_J"])
     assert b["config"]["states_per_gpu"] * 2 == a["config"]["states_per_gpu"]
+
+
+F16 = [((9, 8), (3,), False), ((13, 11, 9), (4, 5), True), ((6, 5, 4, 5), (3, 4), False), ((7, 6), (70,), True)]
+
+
+@pytest.mark.parametrize("n,m,nonuniform", F16)
+def test_float16_j_storage_bit_exact(env, n, m, nonuniform):
+    """HJB_F16S (BASELINE config 'fp16 cost-to-go storage'): J buffers are IEEE half, arithmetic is
+    float32, the store rounds to nearest even.  Bit-exact against the oracle (F16C conversions) for
+    every kernel that supports it (0, 4, 5); halves really are half the bytes."""
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    s32 = nested_problem(31 + len(n), n, m, dtype=np.float32, nonuniform=nonuniform, spread=0.3)
+    s16 = hjbdp.ProblemSpec(s32.knots, s32.m, s32.next_terms, s32.cost_terms, dtype=np.float32, index_base=1,
+                            j_storage=np.float16)
+    term = random_terminal(s32, 2).astype(np.float16)
+    ref = c_oracle.sweep(_abi, s16, 4, terminal=term, keep_J=True, keep_idx=True)
+    assert ref["J"].dtype == np.float16
+    seen = set()
+    for v in (None, 0, 4, 5):
+        try:
+            bk = hjbdp.Backup(s16, variant=v)
+        except hjbdp.HjbError as e:
+            assert v == 4 and e.status == _abi.HJB_E_UNSUPPORTED
+            continue
+        with bk:
+            seen.add(bk.info()["kernel_variant"])
+            o = bk.solve(4, terminal=term, keep_J=True, keep_idx=True)
+        assert o["J"].dtype == np.float16
+        assert np.array_equal(o["J_stages"].view(np.uint16), ref["J_stages"].view(np.uint16)), v
+        assert np.array_equal(o["idx_stages"], ref["idx_stages"]), v
+    assert seen <= {0, 4, 5} and 0 in seen
+    with hjbdp.Backup(s16, variant=1) as bk:      # unsupported storage for this kernel: loud failure
+        with pytest.raises(hjbdp.HjbError) as ei:
+            bk.solve(1, terminal=term)
+        assert ei.value.status == _abi.HJB_E_UNSUPPORTED
+    # float16 storage tracks float32 storage to half precision
+    with hjbdp.Backup(s32) as bk:
+        o32 = bk.solve(4, terminal=term.astype(np.float32))
+    err = np.abs(o["J"].astype(np.float32) - o32["J"])
+    assert np.median(err) < 2e-3 * np.abs(o32["J"]).max() and err.max() < 5e-2 * np.abs(o32["J"]).max()
