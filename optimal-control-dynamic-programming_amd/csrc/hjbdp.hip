@@ -362,8 +362,16 @@ int build(Handle *h, const hjb_problem *p) {
         if (h->nested_lds > 64 * 1024) ok = false;
         h->nested_ok = ok;
         h->packed_mode = 0;
-        if (ok && h->nested_fast && p->dtype != HJB_F64 && h->j_elems < ((int64_t)1 << 31) && p->n[D - 1] >= 2) {
-            bool pk = (ax_kin == P.axis[D - 1].n_prefix) && N.m_in <= kPackedMaxIn;   // last axis: state part + b[u_in] only
+        // variants 2/4: cost inner term must be a control-only table; the last axis' inner term is either a
+        // control-only table b[u_in] (variants 2 and 4) or may also depend on the STATE (variant 4 only:
+        // e.g. Solver_attitude.m:425  h*((J1-J2)/J3*X1V.*X2V + U3V/J3)), never on the outer controls
+        const uint32_t outer_bits = ((1u << (D + C - 1)) - 1u) & ~((1u << D) - 1u);
+        const bool cost_fast = N.n_cost_in == 1 && N.in[kMaxInAx].lds_slot >= 0 && cost_kin > 0;
+        const bool ax_gen = N.n_ax_in == 1 && N.in[0].lds_slot < 0 && ax_kin > 0 &&
+                            (p->next_terms[D - 1][ax_kin].mask & outer_bits) == 0;
+        if (ok && cost_fast && (h->nested_fast || ax_gen) && p->dtype != HJB_F64 && h->j_elems < ((int64_t)1 << 31) &&
+            p->n[D - 1] >= 2) {
+            bool pk = (ax_kin == P.axis[D - 1].n_prefix) && N.m_in <= kPackedMaxIn;   // last axis: state part + inner term only
             // canonical shape: last axis = state part + b[u_in]; <= 1 cost term per outer loop level;
             // outer axes may have any terms (their cells/weights are precomputed below)
             for (int i = 0; i < HJB_MAX_D + 2; ++i) { memset(&N.ot[i], 0, sizeof N.ot[i]); N.ot[i].lds_off = -1; }
@@ -399,7 +407,7 @@ int build(Handle *h, const hjb_problem *p) {
                     }
                 }
             }
-            h->packed_mode = pk ? 1 : 0;
+            h->packed_mode = pk ? (h->nested_fast ? 1 : 2) : 0;   // 2: general inner term -> variant 4 only
             h->packed_lds = (size_t)(N.m_in + 1) * 256 * 8 + (size_t)(N.m_in + 1) * 8 + (size_t)2 * p->n[D - 1] * 4 +
                             (size_t)ot_floats * 4;
             {
@@ -920,7 +928,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             return fail(h, HJB_E_UNSUPPORTED, "variant 5 (tabled) needs per-axis tables that fit (see hjbdp.hip)");
         if (value == 4 && !h->packed_mode)
             return fail(h, HJB_E_UNSUPPORTED, "variant 4 (packed, control pairs) needs float32 and the canonical spacecraft structure");
-        if (value == 2 && !h->packed_mode)
+        if (value == 2 && h->packed_mode != 1)
             return fail(h, HJB_E_UNSUPPORTED, "variant 2 (packed) needs float32 and the canonical spacecraft structure (see kernels_packed.h)");
         if (value == 1 && !h->nested_ok)
             return fail(h, HJB_E_UNSUPPORTED, "variant 1 (control-nested) needs: only the last state axis depends on the innermost control dim");

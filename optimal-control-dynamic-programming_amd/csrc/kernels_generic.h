@@ -7,8 +7,9 @@
 // (L1/L2/MALL resident for every reference-sized grid) and keeps the first
 // minimum.  Arithmetic is the canonical order of oracle/hjb_oracle.c, so results
 // are bit-identical to the CPU twin.  Any D <= 6, C <= 3, uniform or non-uniform
-// knots, slabs with halos.  The fast kernels (kernels_inner.h) cover the shapes
-// that matter for throughput; this one is the safety net and the parity anchor.
+// knots, slabs with halos, float16 J storage.  The fast kernels (kernels_nested.h,
+// kernels_packed*.h, kernels_ctrlsplit.h, kernels_tabled.h) cover the shapes that matter
+// for throughput; this one is the safety net and the parity anchor.
 #pragma once
 #include "hjbdp_dev.h"
 

@@ -39,7 +39,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     {
         const DInnerTerm &tb = N->in[0];
         const DInnerTerm &tr = N->in[kMaxInAx];
-        for (int i = threadIdx.x; i < m_in; i += blockDim.x) s_b[i] = static_cast<const float *>(tb.data)[i * tb.stride_in];
+        if (tb.lds_slot >= 0)   // control-only inner table; a state-dependent one is read from global per state
+            for (int i = threadIdx.x; i < m_in; i += blockDim.x) s_b[i] = static_cast<const float *>(tb.data)[i * tb.stride_in];
         for (int p = threadIdx.x; p <= npairs; p += blockDim.x) {
             f2 x = {INFINITY, INFINITY};          // padding controls: infinite cost, never selected
             if (2 * p < m_in) x.x = static_cast<const float *>(tr.data)[(2 * p) * tr.stride_in];
@@ -80,6 +81,10 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     }
     const bool cl0_present = N->ot[CL0].present, cl1_present = N->ot[CL1].present;
     const bool cl0_first = N->ot[CL0].first, cl1_first = N->ot[CL1].first;
+    // last axis' inner term: control-only (LDS) or state-dependent (global, offset boff + j * stride)
+    const bool b_pure = N->in[0].lds_slot >= 0;
+    const float *b_data = static_cast<const float *>(N->in[0].data);
+    const int b_stride = N->in[0].stride_in;
 
     for (int blk = blockIdx.x * 256; blk < n_owned; blk += gridDim.x * 256) {
         int ls = blk + threadIdx.x;
@@ -87,6 +92,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         if (!valid) ls = n_owned - 1;         // harmless duplicate work, store skipped
 
         float ql, gpre;
+        int boff = 0;                         // state part of the inner term's table offset
         int aoff[DM], coff[2], cell[DM];
         float tw[DM];
         int lc0, lc1;
@@ -108,6 +114,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 q = (k == 0) ? x : q + x;
             }
             ql = q;
+            if (!b_pure) {
+                const DTerm &bt = axl.t[N->ax_kin];
+#pragma unroll
+                for (int a = 0; a < D; ++a) boff += bt.stride[a] * si[a];
+            }
             float g = 0.f;
             for (int k = 0; k < P->n_cost_prefix; ++k) {
                 float x = term_value32<D>(P->cost[k], si);
@@ -141,7 +152,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             track_reset(tl);
             f2 t = {0.f, 0.f};
             for (int j = 0; j < m_in; ++j) {
-                const float q = ql + s_b[j];
+                const float q = ql + (b_pure ? s_b[j] : b_data[boff + j * b_stride]);
                 const bool ch = track_update<float>(tl, s_k, s_r, nl, q, l_uniform, l_x0, l_invh);
                 if (j == 0) {
                     lc0 = lc1 = tl.cell - plane0;
@@ -249,7 +260,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         ne0 = e0b;
                         nde = deb;
                     } else {                             // later crossings: general path
-                        const float q = ql + s_b[j];
+                        const float q = ql + (b_pure ? s_b[j] : b_data[boff + j * b_stride]);
                         int lc = find_cell<float>(s_k, nl, q, l_uniform, l_x0, l_invh) - plane0;
                         if (lc < 0 || lc + 1 >= nplanes) {
                             *P->status = 1;

@@ -86,6 +86,9 @@ def nested_problem(seed, n, m, dtype=np.float32, nonuniform=False, spread=0.2, m
                 d = int(others[0])
                 dims = tuple(sorted((d, D + c)))
                 terms.append(Term(dims, spread * rng.standard_normal(tuple(g[x] for x in dims))))
+                if mixed_inner == "only" and c == C - 1:     # the inner term depends on a state dim AND the control
+                    nxt.append(terms)
+                    continue
             tab = spread * rng.standard_normal(g[D + c])
             if monotone and c == C - 1:       # monotone inner control table (what real actuator levels are)
                 tab = np.sort(tab) if monotone == "inc" else np.sort(tab)[::-1].copy()

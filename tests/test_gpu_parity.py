@@ -163,6 +163,23 @@ def test_packed_variant_bit_exact(env, n, m, nonuniform, mono):
         assert np.array_equal(o["J"], ref["J"]) and np.array_equal(o["idx"], ref["idx"]), v
 
 
+@pytest.mark.parametrize("n,m", [((9, 8), (3,)), ((9, 8, 7), (4, 5, 3)), ((4, 3, 4, 3, 3, 5), (3, 3, 3))])
+def test_packed_variant_state_dependent_inner_term(env, n, m):
+    """Variant 4 also takes a last-axis inner term that depends on the state (attitude:
+    h*((J1-J2)/J3*w1*w2 + u3/J3), Solver_attitude.m:425); variant 2 does not."""
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    spec = nested_problem(99 + len(n), n, m, dtype=np.float32, mixed_inner="only", spread=0.4)
+    term = random_terminal(spec, 5)
+    ref = c_oracle.sweep(_abi, spec, 4, terminal=term)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 4
+        o = bk.solve(4, terminal=term)
+        with pytest.raises(hjbdp.HjbError):
+            bk.set_option("variant", 2)
+    assert np.array_equal(o["J"], ref["J"]) and np.array_equal(o["idx"], ref["idx"])
+
+
 def test_packed_variant_slab(env):
     hjbdp, _abi, c_oracle = env
     from problems import nested_problem, random_terminal

@@ -66,7 +66,7 @@ def test_solver_attitude_relabelled_axes(env):
     hjbdp, _abi, c_oracle = env
     sa = hjbdp.Solver_attitude(n_mesh_w=5, n_mesh_q=4)
     sa.run(n_stages=6)
-    assert sa.kernel_variant == 1
+    assert sa.kernel_variant == 4      # packed kernel (state-dependent inner term on w3)
     spec = sa.build_spec_full()
     pspec, to_old = hjbdp.permute_state_axes(spec, sa.AXIS_ORDER)
     ref = c_oracle.sweep(_abi, pspec, 6)

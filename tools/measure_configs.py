@@ -54,6 +54,21 @@ spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Th
 out, v = solve_timed(spec, 1999, monitor_period=50, monitor_tol=1e-2)
 add("Solver_pos_att channel 30x30x20x15 x 9, <=1999 stages (monitor), f32", spec.nS * 9 * out["stages_done"],
     out["sweep_ms"], v, "stopped after %d stages" % out["stages_done"])
+# 6-D north-star figure: C3's attitude model on a 24^6 grid x 11^3 torques, w3 relabelled last
+import os
+if os.environ.get("HJB_MEASURE_6D", "1") == "1":
+    sa6 = hjbdp.Solver_attitude(n_mesh_w=24, n_mesh_q=24)
+    sa6.U_vector = np.linspace(-0.11, 0.11, 11)
+    t0 = time.time()
+    spec6 = sa6.build_spec_full()
+    pspec6, _ = hjbdp.permute_state_axes(spec6, sa6.AXIS_ORDER)
+    t_host = time.time() - t0
+    with hjbdp.Backup(pspec6) as bk:
+        v = bk.info()["kernel_variant"]
+        bk.solve(1)
+        out = bk.solve(2)
+    add("6-D attitude model 24^6 x 11^3, 2 stages, f32", pspec6.nS * pspec6.nU * 2, out["sweep_ms"], v,
+        "host table build %.0f s" % t_host)
 # C4: 120^4 x 9, terms cost mode
 pa.cost_mode = "terms"
 pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = 120
