@@ -61,6 +61,7 @@ struct Handle {
     bool use_graph = true;
     size_t packed_lds = 0;
     size_t packed2_lds = 0;       // variant 4 (two controls per packed op)
+    bool packed_hier = false;     // variant 4, D == 3: axis 0 level 0, axis 1 level 1 -> hierarchical contraction
     size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
     bool tabled_ok = false;       // variant 5: per-axis (cell, t) tables for every axis (built on first use)
     uint32_t dom_mask[HJB_MAX_D] = {0};
@@ -479,6 +480,7 @@ int build(Handle *h, const hjb_problem *p) {
             }
             HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipDeviceSynchronize());
+            h->packed_hier = D == 3 && N.at[0].level == 0 && N.at[1].level == 1;
         }
     }
     // ---- variant 5 eligibility: (cell, t) tables of EVERY axis over its own domain (built lazily) ---
@@ -596,7 +598,10 @@ int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t
             const size_t lds = h->packed2_lds + h->lds_pad;
 #define HJB_LAUNCH_PACKED2(DD)                                                                                       \
     case DD:                                                                                                         \
-        hipLaunchKernelGGL((k_backup_packed2<TJ, DD>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);                      \
+        if (DD == 3 && h->packed_hier)                                                                               \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, 3, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);         \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, DD, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);       \
         break;
             switch (D) {
                 HJB_LAUNCH_PACKED2(1) HJB_LAUNCH_PACKED2(2) HJB_LAUNCH_PACKED2(3) HJB_LAUNCH_PACKED2(4)

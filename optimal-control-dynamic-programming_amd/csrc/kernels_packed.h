@@ -84,6 +84,18 @@ __device__ __forceinline__ void load_corners(const float *__restrict__ Jn, int b
     }
 }
 
+// the two axis-0 neighbours at element offset off (axis 0 has stride 1)
+__device__ __forceinline__ void load_pair(const float *__restrict__ Jn, int off, float (&v)[2]) {
+    const f2u p = *reinterpret_cast<const f2u *>(Jn + off);
+    v[0] = p.x;
+    v[1] = p.y;
+}
+__device__ __forceinline__ void load_pair(const _Float16 *__restrict__ Jn, int off, float (&v)[2]) {
+    const h2u p = *reinterpret_cast<const h2u *>(Jn + off);
+    v[0] = (float)p.x;
+    v[1] = (float)p.y;
+}
+
 // contract axes 0..D-2 with weights tw[] in canonical order -> E0 and dE = E1 - E0
 template <int D>
 __device__ __forceinline__ void contract(float (&v)[1 << D], const float (&tw)[D > 1 ? D - 1 : 1], float &E0, float &dE) {

@@ -14,7 +14,9 @@
 
 namespace hjb {
 
-template <typename TJ, int D>
+// HIER (D == 3 only, chosen on the host when axis 0 is resolved per o0 step and axis 1 per (o0,o1) step -
+// the C2 shape): axis 0 is contracted once per o0 step, see below.
+template <typename TJ, int D, bool HIER>
 __global__ void __launch_bounds__(256)
 k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
                  TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
@@ -221,14 +223,63 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             int base, base_n;
             float twc[DM], twn[DM];
             float go, go_n;
-            float G[1 << D], H[1 << D];
-            prepare(0, base, twc, go);
-            load_corners<D>(Jn, base + js[D - 1] * lc0, js, G);
-            load_corners<D>(Jn, base + js[D - 1] * lc1, js, H);
+            float G[1 << D], H[1 << D];   // prefetched corners (unused, hence eliminated, when HIER)
+            // D == 3 with axis 0 resolved per o0 step and axis 1 per (o0,o1) step (the C2 shape): contract
+            // axis 0 ONCE per o0 step for the <= 3 axis-1 rows and the 4 last-axis planes the whole o1 sweep
+            // can touch; an o1 step is then 8 selects + 4 lerps instead of 16 loads + 13 lerps.  Same lerp
+            // order (axis 0, then 1, then the last axis) -> same bits.
+            float F[HIER ? 3 : 1][4];
+            int c1min = 0;
+            if constexpr (HIER) {
+                int cmin = 0x7fffffff;
+                for (int o1 = 0; o1 < m_o1; ++o1) {
+                    const int c = atab[1][aoff[1] + o0 * a_c0[1] + o1 * a_c1[1]].x;
+                    cmin = c < cmin ? c : cmin;
+                }
+                c1min = cmin;
+                const int n1 = P->axis[1].n;
+                const int rows[3] = {cmin, cmin + 1, cmin + 2 < n1 ? cmin + 2 : n1 - 1};
+                const int planes[4] = {lc0, lc0 + 1, lc1, lc1 + 1};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v2[2];
+                        load_pair(Jn, cell[0] + js[1] * rows[r] + js[2] * planes[q], v2);
+                        F[r][q] = __builtin_fmaf(tw[0], v2[1] - v2[0], v2[0]);
+                    }
+                }
+            } else {
+                prepare(0, base, twc, go);
+                load_corners<D>(Jn, base + js[D - 1] * lc0, js, G);
+                load_corners<D>(Jn, base + js[D - 1] * lc1, js, H);
+            }
             for (int o1 = 0; o1 < m_o1; ++o1, ++uo) {
-                // ---- level 1: contract the prefetched corners of this step -----------
+                // ---- level 1: (E0, dE) of the two last-axis cells this state visits ----------
                 float e0a, dea, e0b, deb;
-                {
+                if constexpr (HIER) {
+                    prepare(o1, base, twc, go);
+                    const int r = cell[1] - c1min;
+                    if (r == 0 || r == 1) {                              // inside the prepared 2-cell window
+                        const bool up = r != 0;
+                        const float t1 = tw[1];
+                        float X[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float f0 = up ? F[1][q] : F[0][q];
+                            const float f1 = up ? F[2][q] : F[1][q];
+                            X[q] = __builtin_fmaf(t1, f1 - f0, f0);
+                        }
+                        e0a = X[0]; dea = X[1] - X[0];
+                        e0b = X[2]; deb = X[3] - X[2];
+                    } else {                                             // rare: axis 1 spans > 2 cells in this sweep
+                        float va[1 << D], vb[1 << D];
+                        load_corners<D>(Jn, base + js[D - 1] * lc0, js, va);
+                        load_corners<D>(Jn, base + js[D - 1] * lc1, js, vb);
+                        contract<D>(va, twc, e0a, dea);
+                        contract<D>(vb, twc, e0b, deb);
+                    }
+                } else {
                     f2 v[1 << D];                                    // {first cell, second cell} contracted together
 #pragma unroll
                     for (int c = 0; c < (1 << D); ++c) v[c] = (f2){G[c], H[c]};
@@ -243,11 +294,13 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     e0a = v[0].x; e0b = v[0].y;
                     dea = d.x;    deb = d.y;
                 }
-                const bool has_next = o1 + 1 < m_o1;
-                if (has_next) {
-                    prepare(o1 + 1, base_n, twn, go_n);
-                    load_corners<D>(Jn, base_n + js[D - 1] * lc0, js, G);
-                    load_corners<D>(Jn, base_n + js[D - 1] * lc1, js, H);
+                const bool has_next = !HIER && o1 + 1 < m_o1;
+                if constexpr (!HIER) {
+                    if (has_next) {
+                        prepare(o1 + 1, base_n, twn, go_n);
+                        load_corners<D>(Jn, base_n + js[D - 1] * lc0, js, G);
+                        load_corners<D>(Jn, base_n + js[D - 1] * lc1, js, H);
+                    }
                 }
                 float e0 = e0a, de = dea;                            // (E0, dE) of the cell the query is in
                 const f2 go2 = {go, go};
