@@ -61,7 +61,7 @@ struct Handle {
     bool use_graph = true;
     size_t packed_lds = 0;
     size_t packed2_lds = 0;       // variant 4 (two controls per packed op)
-    bool packed_hier = false;     // variant 4, D == 3: axis 0 level 0, axis 1 level 1 -> hierarchical contraction
+    int packed_pre = 0;           // variant 4 contraction mode (kernels_packed2.h MODE): 0 plain, 1 C2 shape, 2 state-only axes first
     size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
     bool tabled_ok = false;       // variant 5: per-axis (cell, t) tables for every axis (built on first use)
     uint32_t dom_mask[HJB_MAX_D] = {0};
@@ -480,7 +480,16 @@ int build(Handle *h, const hjb_problem *p) {
             }
             HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipDeviceSynchronize());
-            h->packed_hier = D == 3 && N.at[0].level == 0 && N.at[1].level == 1;
+            h->packed_pre = 0;
+            if (C == 3 && D == 3 && N.at[0].level == 0 && N.at[1].level == 1) h->packed_pre = 1;
+            if (C == 3 && D >= 4 && N.at[D - 3].level == 0 && N.at[D - 2].level == 1) {
+                bool pre = true;
+                for (int a = 0; a < D - 3; ++a) pre = pre && N.at[a].level < 0;
+                if (pre && h->packed2_lds + 36 * 256 * 4 <= 64 * 1024) {
+                    h->packed_pre = 2;
+                    h->packed2_lds += 36 * 256 * 4;   // the per-state window
+                }
+            }
         }
     }
     // ---- variant 5 eligibility: (cell, t) tables of EVERY axis over its own domain (built lazily) ---
@@ -598,10 +607,12 @@ int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t
             const size_t lds = h->packed2_lds + h->lds_pad;
 #define HJB_LAUNCH_PACKED2(DD)                                                                                       \
     case DD:                                                                                                         \
-        if (DD == 3 && h->packed_hier)                                                                               \
-            hipLaunchKernelGGL((k_backup_packed2<TJ, 3, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);         \
+        if (DD == 3 && h->packed_pre == 1)                                                                           \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, 3, 1>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);            \
+        else if (DD >= 4 && h->packed_pre == 2)                                                                      \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, (DD >= 4 ? DD : 4), 2>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_backup_packed2<TJ, DD, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);       \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, DD, 0>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);           \
         break;
             switch (D) {
                 HJB_LAUNCH_PACKED2(1) HJB_LAUNCH_PACKED2(2) HJB_LAUNCH_PACKED2(3) HJB_LAUNCH_PACKED2(4)

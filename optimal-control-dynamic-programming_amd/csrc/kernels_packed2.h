@@ -14,13 +14,63 @@
 
 namespace hjb {
 
-// HIER (D == 3 only, chosen on the host when axis 0 is resolved per o0 step and axis 1 per (o0,o1) step -
-// the C2 shape): axis 0 is contracted once per o0 step, see below.
-template <typename TJ, int D, bool HIER>
+// Full 2^NP-corner gather + contraction of the NP leading axes at element offset `off` (lerp order: axis 0 first).
+template <typename TJ, int NP>
+__device__ __forceinline__ float gather_contract(const TJ *__restrict__ Jn, int off, const int (&js)[NP + 3],
+                                                 const float (&tw)[NP + 2]) {
+    float v[1 << NP];
+#pragma unroll
+    for (int c = 0; c < (1 << NP); ++c) {
+        int o = off;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) o += ((c >> a) & 1) ? js[a] : 0;
+        v[c] = (float)Jn[o];
+    }
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+#pragma unroll
+        for (int jj = 0; jj < (1 << (NP - 1 - a)); ++jj) v[jj] = __builtin_fmaf(tw[a], v[2 * jj + 1] - v[2 * jj], v[2 * jj]);
+    }
+    return v[0];
+}
+
+// Depth-first contraction of axes 0..A-1 at element offset `off` (axis 0 lerped first, like contract<>): the same
+// tree as the breadth-first form, hence the same bits, with O(A) live registers instead of 2^A.  For rare paths.
+template <typename TJ, int A, int DD>
+__device__ __forceinline__ float contract_df(const TJ *__restrict__ Jn, int off, const int (&js)[DD], const float *tw) {
+    if constexpr (A == 0) {
+        return (float)Jn[off];
+    } else if constexpr (A <= 3) {
+        const float v0 = contract_df<TJ, A - 1, DD>(Jn, off, js, tw);
+        const float v1 = contract_df<TJ, A - 1, DD>(Jn, off + js[A - 1], js, tw);
+        return __builtin_fmaf(tw[A - 1], v1 - v0, v0);
+    } else {                       // upper levels as real loops: 8 loads in flight, small code
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll 1
+        for (int hh = 0; hh < 2; ++hh) {
+            const float x = contract_df<TJ, A - 1, DD>(Jn, off + hh * js[A - 1], js, tw);
+            if (hh == 0) v0 = x; else v1 = x;
+        }
+        return __builtin_fmaf(tw[A - 1], v1 - v0, v0);
+    }
+}
+
+// MODE (chosen on the host from the axis levels; "level" = the outermost control loop an axis' cell depends on):
+//   0  plain: 2 x 2^D corner gathers + full contraction per (o0,o1) step
+//   1  D == 3, axis 0 level 0, axis 1 level 1 (the C2 shape): axis 0 contracted once per o0 step
+//   2  D >= 4, axes 0..D-4 state-only, axis D-3 level 0, axis D-2 level 1 (the attitude model with the angle axes
+//      first): the state-only axes are contracted ONCE PER STATE over the 3 x 3 x 4 window of (axis D-3 rows,
+//      axis D-2 rows, last-axis planes) the whole control sweep can touch; an o0 step is then 24 selects + 12
+//      lerps and an o1 step 8 selects + 4 lerps, whatever D is.
+// Same lerp order (axis 0 first ... last axis last) -> same bits in every mode.
+template <typename TJ, int D, int MODE>
 __global__ void __launch_bounds__(256)
 k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
                  TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
+    constexpr bool HIER = MODE != 0;
+    constexpr int AX_A = D >= 3 ? D - 3 : 0, AX_B = D >= 2 ? D - 2 : 0;   // the level-0 / level-1 axes of modes 1, 2
+    constexpr int NP = MODE == 2 ? D - 3 : 0;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const DAxis &axl = P->axis[D - 1];
     const int nl = axl.n;
@@ -28,7 +78,10 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     const int npairs = (m_in + 1) >> 1;
     // LDS: {t_2p, t_2p+1} per lane [npairs+1][256] float2 | {r_2p, r_2p+1} [npairs+1] | b[m_in] |
     //      knots, rdx of the last axis | control-only cost tables
-    f2 *s_t = reinterpret_cast<f2 *>(smem_raw);
+    // mode 2 only: the per-state window W[(ra*3+rb)*4+q][lane] in front of everything else
+    constexpr int kWin = MODE == 2 ? 36 : 0;
+    float *my_w = reinterpret_cast<float *>(smem_raw) + threadIdx.x;
+    f2 *s_t = reinterpret_cast<f2 *>(smem_raw + (size_t)kWin * 256 * sizeof(float));
     f2 *s_r2 = s_t + (size_t)(npairs + 1) * 256;
     float *s_b = reinterpret_cast<float *>(s_r2 + (npairs + 1));
     float *s_k = s_b + m_in;
@@ -175,9 +228,51 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             if ((U >> (2 * p)) & 3u) PU |= 1u << p;
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
+        int cAmin = 0, cBmin = 0;
+        if constexpr (MODE == 2) {
+            int ca = 0x7fffffff, cb = 0x7fffffff;
+            for (int o0 = 0; o0 < m_o0; ++o0) {
+                const int c = atab[AX_A][aoff[AX_A] + o0 * a_c0[AX_A]].x;
+                ca = c < ca ? c : ca;
+                for (int o1 = 0; o1 < m_o1; ++o1) {
+                    const int c2 = atab[AX_B][aoff[AX_B] + o0 * a_c0[AX_B] + o1 * a_c1[AX_B]].x;
+                    cb = c2 < cb ? c2 : cb;
+                }
+            }
+            cAmin = ca;
+            cBmin = cb;
+            const int nA = P->axis[AX_A].n, nB = P->axis[AX_B].n;
+            const int planes[4] = {lc0, lc0 + 1, lc1, lc1 + 1};
+            int pbase = 0;
+#pragma unroll
+            for (int a = 0; a < NP; ++a) pbase += js[a] * cell[a];
+#pragma unroll 1
+            for (int ra = 0; ra < 3; ++ra) {
+                const int rowA = ca + ra < nA ? ca + ra : nA - 1;
+#pragma unroll 1
+                for (int rb = 0; rb < 3; ++rb) {
+                    const int rowB = cb + rb < nB ? cb + rb : nB - 1;
+                    const int off = pbase + js[AX_A] * rowA + js[AX_B] * rowB;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        my_w[((ra * 3 + rb) * 4 + q) * 256] = gather_contract<TJ, NP>(Jn, off + js[D - 1] * planes[q], js, tw);
+                }
+            }
+        }
         float best = 0.f;
         int best_uo = 0, best_j = 0;
 
+        // (E0, dE) of one last-axis cell at element offset `off`: the rare synchronous path
+        auto cell_pair = [&](int off, const float (&twc)[DM], float &e0, float &de) {
+            if constexpr (MODE == 2) {
+                e0 = contract_df<TJ, D - 1, D>(Jn, off, js, twc);
+                de = contract_df<TJ, D - 1, D>(Jn, off + js[D - 1], js, twc) - e0;
+            } else {
+                float v[1 << D];
+                load_corners<D>(Jn, off, js, v);
+                contract<D>(v, twc, e0, de);
+            }
+        };
         auto cterm = [&](int slot, int o0, int o1) -> float {
             const auto &t = N->ot[slot];
             if (t.lds_off >= 0) return s_ot[t.lds_off + o0 * t.c0 + o1 * t.c1];
@@ -230,7 +325,22 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             // order (axis 0, then 1, then the last axis) -> same bits.
             float F[HIER ? 3 : 1][4];
             int c1min = 0;
-            if constexpr (HIER) {
+            bool slow_a = false;                                     // mode 2: axis D-3 left its 2-cell window
+            if constexpr (MODE == 2) {
+                c1min = cBmin;
+                const int r = cell[AX_A] - cAmin;
+                slow_a = !(r == 0 || r == 1);
+                const float *w0 = my_w + (r == 1 ? 12 * 256 : 0);          // rows {r, r+1} of the window
+                const float ta = tw[AX_A];
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float f0 = w0[(rb * 4 + q) * 256];
+                        const float f1 = w0[(12 + rb * 4 + q) * 256];
+                        F[rb][q] = __builtin_fmaf(ta, f1 - f0, f0);
+                    }
+            } else if constexpr (MODE == 1) {
                 int cmin = 0x7fffffff;
                 for (int o1 = 0; o1 < m_o1; ++o1) {
                     const int c = atab[1][aoff[1] + o0 * a_c0[1] + o1 * a_c1[1]].x;
@@ -259,10 +369,10 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 float e0a, dea, e0b, deb;
                 if constexpr (HIER) {
                     prepare(o1, base, twc, go);
-                    const int r = cell[1] - c1min;
-                    if (r == 0 || r == 1) {                              // inside the prepared 2-cell window
+                    const int r = cell[AX_B] - c1min;
+                    if ((r == 0 || r == 1) && !slow_a) {                 // inside the prepared 2-cell window
                         const bool up = r != 0;
-                        const float t1 = tw[1];
+                        const float t1 = tw[AX_B];
                         float X[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -273,11 +383,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         e0a = X[0]; dea = X[1] - X[0];
                         e0b = X[2]; deb = X[3] - X[2];
                     } else {                                             // rare: axis 1 spans > 2 cells in this sweep
-                        float va[1 << D], vb[1 << D];
-                        load_corners<D>(Jn, base + js[D - 1] * lc0, js, va);
-                        load_corners<D>(Jn, base + js[D - 1] * lc1, js, vb);
-                        contract<D>(va, twc, e0a, dea);
-                        contract<D>(vb, twc, e0b, deb);
+                        cell_pair(base + js[D - 1] * lc0, twc, e0a, dea);
+                        cell_pair(base + js[D - 1] * lc1, twc, e0b, deb);
                     }
                 } else {
                     f2 v[1 << D];                                    // {first cell, second cell} contracted together
@@ -319,9 +426,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                             *P->status = 1;
                             lc = lc < 0 ? 0 : nplanes - 2;
                         }
-                        float v[1 << D];
-                        load_corners<D>(Jn, base + js[D - 1] * lc, js, v);
-                        contract<D>(v, twc, ne0, nde);
+                        cell_pair(base + js[D - 1] * lc, twc, ne0, nde);
                     }
                 };
                 // ---- inner loop over control PAIRS: packed, no loads, no cell tests on the vector pipe.

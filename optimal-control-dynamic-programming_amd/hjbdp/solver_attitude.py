@@ -159,9 +159,11 @@ class Solver_attitude:
         nu = len(UV)
         return ProblemSpec(knots, [nu, nu, nu], nxt, cost, dtype=np.float32, index_base=1)
 
-    # state-axis labelling handed to the library: w3 (driven by the innermost torque U3) LAST, so the
-    # control-nested stage kernel applies; results are mapped back to the reference's dim order.
-    AXIS_ORDER = (0, 1, 3, 4, 5, 2)
+    # state-axis labelling handed to the library: the three angle axes (whose next value does not depend on
+    # the torques) FIRST, then w1, w2, w3 (driven by U1 outermost ... U3 innermost, w3 LAST): the stage kernel
+    # then contracts the angle axes once per state (variant 4, mode 2) instead of once per torque pair.
+    # Results are mapped back to the reference's dim order.
+    AXIS_ORDER = (3, 4, 5, 0, 1, 2)
 
     def run(self, n_stages=None, relabel=True):
         spec = self.build_spec_full()

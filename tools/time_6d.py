@@ -1,0 +1,25 @@
+"""Time the 6-D attitude model (Solver_attitude.run semantics) on an n^6 grid x nu^3 torques.
+usage: python tools/time_6d.py [n=24] [nu=11] [stages=2] [variant=-1]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
+import hjbdp
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+nu = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+stages = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+variant = int(sys.argv[4]) if len(sys.argv) > 4 else -1
+sa = hjbdp.Solver_attitude(n_mesh_w=n, n_mesh_q=n)
+sa.U_vector = np.linspace(-0.11, 0.11, nu)
+t0 = time.time()
+spec = sa.build_spec_full()
+pspec, _ = hjbdp.permute_state_axes(spec, sa.AXIS_ORDER)
+print("host table build %.1f s" % (time.time() - t0), flush=True)
+with hjbdp.Backup(pspec) as bk:
+    if variant >= 0:
+        bk.set_option("variant", variant)
+    print(bk.info(), flush=True)
+    bk.solve(1)
+    out = bk.solve(stages)
+b = pspec.nS * pspec.nU * stages
+print("n=%d nu=%d: %.2f ms/stage, %.3e backups/s" % (n, nu, out["sweep_ms"] / stages, b / (out["sweep_ms"] * 1e-3)))
