@@ -89,7 +89,23 @@ typedef struct hjb_problem {
        whole grid).  The handle owns planes [slab_begin, slab_end) and every J
        buffer it is given covers planes [slab_begin-halo_lo, slab_end+halo_hi). */
     int32_t slab_begin, slab_end, halo_lo, halo_hi;
+    /* Optional on-the-fly model of the LEADING state axes (those whose next value does not depend on the
+       control).  HJB_MODEL_NONE: every axis is described by next_terms.  HJB_MODEL_QUAT_EULER321 (D == 6, C == 3):
+       axes 0,1,2 = (yaw, pitch, roll), axes 3,4,5 = (w1, w2, w3); n_next_terms[0..2] must be 0 and the next angles
+       are computed per state as attitude-control/Solver_attitude.m:449-489 does (Euler step of the quaternion
+       kinematics with step model_h, renormalise, back to Euler angles) from model_tables[0..3] = the quaternion
+       components x4,x5,x6,x7 of the grid angles (Solver_attitude.m:419-421; arrays over (n[0],n[1],n[2]),
+       column-major, problem dtype HJB_F32/HJB_F16S) and the knots of axes 3..5.  This replaces the three
+       nS-sized next-angle tables, which do not fit at 51^6.  atan2/asin use the library's own
+       fixed polynomial forms, so that results are reproducible bit for bit across CPUs/GPUs. */
+    int32_t model;
+    int32_t reserved1;
+    double model_h;
+    const void *model_tables[4];
 } hjb_problem;
+
+#define HJB_MODEL_NONE 0
+#define HJB_MODEL_QUAT_EULER321 1
 
 typedef struct hjb_handle_s *hjb_handle;
 

@@ -276,6 +276,18 @@ int build(Handle *h, const hjb_problem *p) {
             if (st) return st;
         }
     }
+    P.model = p->model;
+    P.model_h = (float)p->model_h;
+    if (p->model == HJB_MODEL_QUAT_EULER321) {
+        const size_t ne = (size_t)p->n[0] * p->n[1] * p->n[2];
+        for (int i = 0; i < 4; ++i) {
+            std::vector<float> v((const float *)p->model_tables[i], (const float *)p->model_tables[i] + ne);
+            void *d = nullptr;
+            int st = upload(h, v, &d);
+            if (st) return st;
+            P.model_tab[i] = d;
+        }
+    }
     // conservative halo implied by the tables of the last axis
     {
         const int a = D - 1, n = p->n[a];
@@ -370,7 +382,7 @@ int build(Handle *h, const hjb_problem *p) {
         const bool cost_fast = N.n_cost_in == 1 && N.in[kMaxInAx].lds_slot >= 0 && cost_kin > 0;
         const bool ax_gen = N.n_ax_in == 1 && N.in[0].lds_slot < 0 && ax_kin > 0 &&
                             (p->next_terms[D - 1][ax_kin].mask & outer_bits) == 0;
-        if (ok && cost_fast && (h->nested_fast || ax_gen) && p->dtype != HJB_F64 && h->j_elems < ((int64_t)1 << 31) &&
+        if (ok && cost_fast && (h->nested_fast || ax_gen) && p->dtype != HJB_F64 && (h->j_elems < ((int64_t)1 << 31) || p->model) &&
             p->n[D - 1] >= 2) {
             bool pk = (ax_kin == P.axis[D - 1].n_prefix) && N.m_in <= kPackedMaxIn;   // last axis: state part + inner term only
             // canonical shape: last axis = state part + b[u_in]; <= 1 cost term per outer loop level;
@@ -469,6 +481,7 @@ int build(Handle *h, const hjb_problem *p) {
                 const bool has_o1 = (C >= 2) && (dom[a] & (1u << (D + C - 2)));
                 const bool has_o0 = (C == 3) && (dom[a] & (1u << D));
                 A.level = has_o1 ? 1 : (has_o0 ? 0 : -1);
+                if (p->n_next_terms[a] == 0) continue;     // model axis: evaluated in the stage kernel
                 void *dsz_d = nullptr, *tab = nullptr;
                 int st3 = upload(h, dsz, &dsz_d);
                 if (st3) return st3;
@@ -486,7 +499,7 @@ int build(Handle *h, const hjb_problem *p) {
                 bool pre = true;
                 for (int a = 0; a < D - 3; ++a) pre = pre && N.at[a].level < 0;
                 if (pre && h->packed2_lds + 36 * 256 * 4 <= 64 * 1024) {
-                    h->packed_pre = 2;
+                    h->packed_pre = p->model ? 3 : 2;
                     h->packed2_lds += 36 * 256 * 4;   // the per-state window
                 }
             }
@@ -511,6 +524,14 @@ int build(Handle *h, const hjb_problem *p) {
         // worth it only when the tables are small next to the per-stage work (nS * nU backups)
         const bool small = total <= ((size_t)512 << 20) || (double)total <= 0.5 * (double)h->n_owned * (double)h->nU;
         h->tabled_ok = fits && small && total <= ((size_t)16 << 30);
+    }
+    if (p->model) {
+        if (!(h->packed_mode && h->packed_pre == 3))
+            return fail(h, HJB_E_UNSUPPORTED,
+                        "HJB_MODEL_QUAT_EULER321 needs the canonical attitude structure: axis 3 driven by control dim 0, "
+                        "axis 4 by control dim 1, axis 5 by control dim 2 (kernels_packed2.h mode 3)");
+        h->tabled_ok = false;     // the other stage kernels do not evaluate the model
+        h->nested_fast = false;
     }
     if (h->nested_ok) {
         void *dnn = nullptr;
@@ -571,6 +592,7 @@ void choose_launch(Handle *h) {
     const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
     h->variant = h->forced_variant >= 0 ? h->forced_variant
                                         : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : (h->tabled_ok ? 5 : 0))));
+    if (h->hp.model) h->variant = 4;
     if (h->dtype == HJB_F16S && h->variant >= 1 && h->variant <= 3)     // float16 J storage: variants 0, 4, 5 only
         h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->tabled_ok ? 5 : 0);
     // build variant 5's tables now (never inside a launch: launches may be under graph capture)
@@ -609,6 +631,8 @@ int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t
     case DD:                                                                                                         \
         if (DD == 3 && h->packed_pre == 1)                                                                           \
             hipLaunchKernelGGL((k_backup_packed2<TJ, 3, 1>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);            \
+        else if (DD == 6 && h->packed_pre == 3)                                                                      \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, 6, 3>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);            \
         else if (DD >= 4 && h->packed_pre == 2)                                                                      \
             hipLaunchKernelGGL((k_backup_packed2<TJ, (DD >= 4 ? DD : 4), 2>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); \
         else                                                                                                         \
@@ -837,6 +861,13 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
     if (p->C < 1 || p->C > HJB_MAX_C) return fail(nullptr, HJB_E_UNSUPPORTED, "C=%d not in 1..%d", p->C, HJB_MAX_C);
     if (p->dtype != HJB_F32 && p->dtype != HJB_F64 && p->dtype != HJB_F16S) return fail(nullptr, HJB_E_UNSUPPORTED, "dtype %d", p->dtype);
     if (p->index_base != 0 && p->index_base != 1) return fail(nullptr, HJB_E_INVALID, "index_base must be 0 or 1");
+    if (p->model != HJB_MODEL_NONE && p->model != HJB_MODEL_QUAT_EULER321) return fail(nullptr, HJB_E_INVALID, "model %d", p->model);
+    if (p->model == HJB_MODEL_QUAT_EULER321) {
+        if (p->D != 6 || p->C != 3 || p->dtype == HJB_F64)
+            return fail(nullptr, HJB_E_UNSUPPORTED, "HJB_MODEL_QUAT_EULER321 needs D=6, C=3, float32 arithmetic");
+        for (int i = 0; i < 4; ++i)
+            if (!p->model_tables[i]) return fail(nullptr, HJB_E_INVALID, "model_tables[%d] is null", i);
+    }
     const int G = p->D + p->C;
     int64_t nS = 1, nU = 1;
     for (int a = 0; a < p->D; ++a) {
@@ -845,7 +876,8 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
         for (int i = 0; i + 1 < p->n[a]; ++i)
             if (!(p->knots[a][i + 1] > p->knots[a][i]))
                 return fail(nullptr, HJB_E_INVALID, "knots[%d] not strictly increasing at %d", a, i);
-        if (p->n_next_terms[a] < 1 || p->n_next_terms[a] > HJB_MAX_TERMS)
+        const bool model_axis = p->model == HJB_MODEL_QUAT_EULER321 && a < 3;
+        if (model_axis ? p->n_next_terms[a] != 0 : (p->n_next_terms[a] < 1 || p->n_next_terms[a] > HJB_MAX_TERMS))
             return fail(nullptr, HJB_E_INVALID, "n_next_terms[%d]=%d", a, p->n_next_terms[a]);
         for (int k = 0; k < p->n_next_terms[a]; ++k) {
             const hjb_term &t = p->next_terms[a][k];
@@ -940,6 +972,8 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) {
         if (value < -1 || value > 5) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (h->hp.model && value != -1 && value != 4)
+            return fail(h, HJB_E_UNSUPPORTED, "a problem with a state model runs on variant 4 only");
         if (value == 5 && !h->tabled_ok)
             return fail(h, HJB_E_UNSUPPORTED, "variant 5 (tabled) needs per-axis tables that fit (see hjbdp.hip)");
         if (value == 4 && !h->packed_mode)

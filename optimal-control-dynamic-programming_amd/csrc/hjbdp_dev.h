@@ -45,6 +45,10 @@ struct DParams {
     int32_t *status;          // device word, set to 1 when a query leaves the slab
     DAxis axis[HJB_MAX_D];
     DTerm cost[HJB_MAX_TERMS];
+    // hjb_problem.model (HJB_MODEL_QUAT_EULER321): quaternion tables x4,x5,x6,x7 over (n0,n1,n2), step h
+    int32_t model;
+    float model_h;
+    const void *model_tab[4];
 };
 
 // J storage type helpers: J may be stored narrower than the arithmetic type (HJB_F16S: IEEE binary16

@@ -8,6 +8,7 @@
 // changes only the upper half of (E0, dE); the halves are re-synchronised after the
 // pair.  Arithmetic per backup is the canonical order: bit-identical results.
 #pragma once
+#include <type_traits>
 #include "hjbdp_dev.h"
 #include "kernels_nested.h"
 #include "kernels_packed.h"
@@ -32,6 +33,70 @@ __device__ __forceinline__ float gather_contract(const TJ *__restrict__ Jn, int 
         for (int jj = 0; jj < (1 << (NP - 1 - a)); ++jj) v[jj] = __builtin_fmaf(tw[a], v[2 * jj + 1] - v[2 * jj], v[2 * jj]);
     }
     return v[0];
+}
+
+// ---- HJB_MODEL_QUAT_EULER321 (hjbdp.h): next (yaw, pitch, roll) of one state ---------------------------------
+// attitude-control/Solver_attitude.m:449-489 in single precision, operation by operation.  atan2/asin are fixed
+// polynomial forms made of +,-,*,/ and sqrt (all correctly rounded on gfx950 - NB __builtin_sqrtf, not __fsqrt_rn,
+// which lowers to the bare 1-ulp v_sqrt_f32 - and contraction off), so the result is
+// reproducible bit for bit on any IEEE machine - the checker (oracle/hjb_oracle.c) restates the same forms.
+__device__ __forceinline__ float canon_atan2f(float y, float x) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const bool swap = ay > ax;
+    const float num = swap ? ax : ay, den = swap ? ay : ax;
+    float r = den == 0.0f ? 0.0f : __fdiv_rn(num, den);
+    float off = 0.0f;
+    if (r > 0.4142135623730950f) {
+        r = __fdiv_rn(r - 1.0f, r + 1.0f);
+        off = 0.78539816339744831f;
+    }
+    const float z = r * r;
+    float pz = 8.05374449538e-2f;
+    pz = pz * z - 1.38776856032e-1f;
+    pz = pz * z + 1.99777106478e-1f;
+    pz = pz * z - 3.33329491539e-1f;
+    float a = off + (pz * z * r + r);
+    if (swap) a = 1.57079632679489662f - a;
+    if (x < 0.0f) a = 3.14159265358979324f - a;
+    return y < 0.0f ? -a : a;
+}
+
+__device__ __forceinline__ float canon_asinf(float x) {
+    const float a = __builtin_fabsf(x);
+    const bool big = a > 0.5f;
+    float z, r;
+    if (big) {
+        z = 0.5f * (1.0f - a);
+        r = __builtin_sqrtf(z);
+    } else {
+        r = a;
+        z = a * a;
+    }
+    float pz = 4.2163199048e-2f;
+    pz = pz * z + 2.4181311049e-2f;
+    pz = pz * z + 4.5470025998e-2f;
+    pz = pz * z + 7.4953002686e-2f;
+    pz = pz * z + 1.6666752422e-1f;
+    float v = pz * z * r + r;
+    if (big) v = 1.57079632679489662f - (v + v);
+    return x < 0.0f ? -v : v;
+}
+
+__device__ __forceinline__ void model_quat_next(const DParams *__restrict__ P, const int *si, float w1, float w2, float w3,
+                                                float (&out)[3]) {
+    const int ti = si[0] + P->axis[0].n * (si[1] + P->axis[1].n * si[2]);
+    const float q1 = static_cast<const float *>(P->model_tab[0])[ti], q2 = static_cast<const float *>(P->model_tab[1])[ti];
+    const float q3 = static_cast<const float *>(P->model_tab[2])[ti], q7 = static_cast<const float *>(P->model_tab[3])[ti];
+    const float h = P->model_h, half = 0.5f;
+    float x4 = q1 + h * (half * ((w3 * q2 - w2 * q3) + w1 * q7));       // :449-452
+    float x5 = q2 + h * (half * ((-w3 * q1 + w1 * q3) + w2 * q7));      // :454-457
+    float x6 = q3 + h * (half * ((w2 * q1 - w1 * q2) + w3 * q7));       // :459-462
+    float x7 = q7 + h * (half * ((-w1 * q1 - w2 * q2) - w3 * q3));      // :465-467
+    const float nrm = __builtin_sqrtf(((x4 * x4 + x5 * x5) + x6 * x6) + x7 * x7);   // :477
+    x4 = __fdiv_rn(x4, nrm); x5 = __fdiv_rn(x5, nrm); x6 = __fdiv_rn(x6, nrm); x7 = __fdiv_rn(x7, nrm);   // :480-483
+    out[0] = canon_atan2f(2.0f * (x6 * x5 + x7 * x4), ((x7 * x7 + x6 * x6) - x5 * x5) - x4 * x4);   // :485-486
+    out[1] = canon_asinf(-2.0f * (x6 * x4 - x7 * x5));                                              // :487
+    out[2] = canon_atan2f(2.0f * (x5 * x4 + x7 * x6), ((x7 * x7 - x6 * x6) - x5 * x5) + x4 * x4);   // :488-489
 }
 
 // Depth-first contraction of axes 0..A-1 at element offset `off` (axis 0 lerped first, like contract<>): the same
@@ -62,6 +127,8 @@ __device__ __forceinline__ float contract_df(const TJ *__restrict__ Jn, int off,
 //      first): the state-only axes are contracted ONCE PER STATE over the 3 x 3 x 4 window of (axis D-3 rows,
 //      axis D-2 rows, last-axis planes) the whole control sweep can touch; an o0 step is then 24 selects + 12
 //      lerps and an o1 step 8 selects + 4 lerps, whatever D is.
+//   3  mode 2 with D == 6 and the three leading axes driven by HJB_MODEL_QUAT_EULER321 (their next value is
+//      computed per state instead of read from nS-sized tables) and 64-bit state indexing: C3, 51^6 states.
 // Same lerp order (axis 0 first ... last axis last) -> same bits in every mode.
 template <typename TJ, int D, int MODE>
 __global__ void __launch_bounds__(256)
@@ -70,7 +137,9 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     constexpr int DM = D > 1 ? D - 1 : 1;
     constexpr bool HIER = MODE != 0;
     constexpr int AX_A = D >= 3 ? D - 3 : 0, AX_B = D >= 2 ? D - 2 : 0;   // the level-0 / level-1 axes of modes 1, 2
-    constexpr int NP = MODE == 2 ? D - 3 : 0;
+    constexpr bool PRE = MODE >= 2, QMODEL = MODE == 3;
+    constexpr int NP = PRE ? D - 3 : 0;
+    using sidx_t = typename std::conditional<QMODEL, int64_t, int>::type;   // linear state index
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const DAxis &axl = P->axis[D - 1];
     const int nl = axl.n;
@@ -79,7 +148,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     // LDS: {t_2p, t_2p+1} per lane [npairs+1][256] float2 | {r_2p, r_2p+1} [npairs+1] | b[m_in] |
     //      knots, rdx of the last axis | control-only cost tables
     // mode 2 only: the per-state window W[(ra*3+rb)*4+q][lane] in front of everything else
-    constexpr int kWin = MODE == 2 ? 36 : 0;
+    constexpr int kWin = PRE ? 36 : 0;
     float *my_w = reinterpret_cast<float *>(smem_raw) + threadIdx.x;
     f2 *s_t = reinterpret_cast<f2 *>(smem_raw + (size_t)kWin * 256 * sizeof(float));
     f2 *s_r2 = s_t + (size_t)(npairs + 1) * 256;
@@ -115,7 +184,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     __syncthreads();
 
     const int C = P->C;
-    const int n_owned = (int)P->n_owned;
+    const sidx_t n_owned = (sidx_t)P->n_owned;
     const int l_uniform = axl.uniform;
     const float l_x0 = (float)axl.x0, l_invh = (float)axl.inv_h;
     const int plane0 = P->plane0, nplanes = P->nplanes;
@@ -141,8 +210,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     const float *b_data = static_cast<const float *>(N->in[0].data);
     const int b_stride = N->in[0].stride_in;
 
-    for (int blk = blockIdx.x * 256; blk < n_owned; blk += gridDim.x * 256) {
-        int ls = blk + threadIdx.x;
+    for (sidx_t blk = (sidx_t)blockIdx.x * 256; blk < n_owned; blk += (sidx_t)gridDim.x * 256) {
+        sidx_t ls = blk + threadIdx.x;
         const bool valid = ls < n_owned;
         if (!valid) ls = n_owned - 1;         // harmless duplicate work, store skipped
 
@@ -154,11 +223,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         unsigned int cm = 0u;                 // bit j: the last-axis cell changes at control j
         {
             int si[D];
-            int r = ls;
+            sidx_t r = ls;
 #pragma unroll
             for (int a = 0; a < D; ++a) {
                 int na = P->n[a];
-                si[a] = r % na;
+                si[a] = (int)(r % na);
                 r /= na;
             }
             const int last_local = si[D - 1];
@@ -186,10 +255,23 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
                 for (int d = 0; d < D; ++d) off += N->at[a].sstride[d] * (d == D - 1 ? last_local : si[d]);
                 aoff[a] = off;
-                if (a_lvl[a] < 0) {
+                if (a_lvl[a] < 0 && !(QMODEL && a < 3)) {
                     const int2 e = atab[a][off];
                     cell[a] = e.x;
                     tw[a] = __int_as_float(e.y);
+                }
+            }
+            if constexpr (QMODEL) {
+                float qn[3];
+                model_quat_next(P, si, static_cast<const float *>(P->axis[3].knots)[si[3]],
+                                static_cast<const float *>(P->axis[4].knots)[si[4]], s_k[si[5]], qn);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const DAxis &ax = P->axis[a];
+                    const float *kk = static_cast<const float *>(ax.knots);
+                    const int c = find_cell<float>(kk, ax.n, qn[a], ax.uniform, (float)ax.x0, (float)ax.inv_h);
+                    cell[a] = c;
+                    tw[a] = (qn[a] - kk[c]) * static_cast<const float *>(ax.rdx)[c];
                 }
             }
 #pragma unroll
@@ -229,7 +311,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
         int cAmin = 0, cBmin = 0;
-        if constexpr (MODE == 2) {
+        if constexpr (PRE) {
             int ca = 0x7fffffff, cb = 0x7fffffff;
             for (int o0 = 0; o0 < m_o0; ++o0) {
                 const int c = atab[AX_A][aoff[AX_A] + o0 * a_c0[AX_A]].x;
@@ -252,10 +334,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll 1
                 for (int rb = 0; rb < 3; ++rb) {
                     const int rowB = cb + rb < nB ? cb + rb : nB - 1;
-                    const int off = pbase + js[AX_A] * rowA + js[AX_B] * rowB;
+                    const int off = pbase + js[AX_A] * rowA + js[AX_B] * rowB;      // < one plane: fits 32 bits
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        my_w[((ra * 3 + rb) * 4 + q) * 256] = gather_contract<TJ, NP>(Jn, off + js[D - 1] * planes[q], js, tw);
+                        my_w[((ra * 3 + rb) * 4 + q) * 256] =
+                            gather_contract<TJ, NP>(Jn + (int64_t)js[D - 1] * planes[q], off, js, tw);
                 }
             }
         }
@@ -263,13 +346,14 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         int best_uo = 0, best_j = 0;
 
         // (E0, dE) of one last-axis cell at element offset `off`: the rare synchronous path
-        auto cell_pair = [&](int off, const float (&twc)[DM], float &e0, float &de) {
-            if constexpr (MODE == 2) {
-                e0 = contract_df<TJ, D - 1, D>(Jn, off, js, twc);
-                de = contract_df<TJ, D - 1, D>(Jn, off + js[D - 1], js, twc) - e0;
+        auto cell_pair = [&](int base, int lc, const float (&twc)[DM], float &e0, float &de) {
+            if constexpr (PRE) {
+                const TJ *Jp = Jn + (int64_t)js[D - 1] * lc;
+                e0 = contract_df<TJ, D - 1, D>(Jp, base, js, twc);
+                de = contract_df<TJ, D - 1, D>(Jp + js[D - 1], base, js, twc) - e0;
             } else {
                 float v[1 << D];
-                load_corners<D>(Jn, off, js, v);
+                load_corners<D>(Jn, base + js[D - 1] * lc, js, v);
                 contract<D>(v, twc, e0, de);
             }
         };
@@ -326,7 +410,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             float F[HIER ? 3 : 1][4];
             int c1min = 0;
             bool slow_a = false;                                     // mode 2: axis D-3 left its 2-cell window
-            if constexpr (MODE == 2) {
+            if constexpr (PRE) {
                 c1min = cBmin;
                 const int r = cell[AX_A] - cAmin;
                 slow_a = !(r == 0 || r == 1);
@@ -383,8 +467,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         e0a = X[0]; dea = X[1] - X[0];
                         e0b = X[2]; deb = X[3] - X[2];
                     } else {                                             // rare: axis 1 spans > 2 cells in this sweep
-                        cell_pair(base + js[D - 1] * lc0, twc, e0a, dea);
-                        cell_pair(base + js[D - 1] * lc1, twc, e0b, deb);
+                        cell_pair(base, lc0, twc, e0a, dea);
+                        cell_pair(base, lc1, twc, e0b, deb);
                     }
                 } else {
                     f2 v[1 << D];                                    // {first cell, second cell} contracted together
@@ -426,7 +510,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                             *P->status = 1;
                             lc = lc < 0 ? 0 : nplanes - 2;
                         }
-                        cell_pair(base + js[D - 1] * lc, twc, ne0, nde);
+                        cell_pair(base, lc, twc, ne0, nde);
                     }
                 };
                 // ---- inner loop over control PAIRS: packed, no loads, no cell tests on the vector pipe.
@@ -507,8 +591,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 const int j1 = best_uo % P->m[1], j0 = best_uo / P->m[1];
                 label = j0 + P->m[0] * (j1 + P->m[1] * best_j);
             }
-            const int in_plane = ls % inner_sz, pl = ls / inner_sz;
-            Jout[in_plane + inner_sz * (pl + P->halo_lo)] = (TJ)best;
+            const sidx_t in_plane = ls % inner_sz, pl = ls / inner_sz;
+            Jout[in_plane + (sidx_t)inner_sz * (pl + P->halo_lo)] = (TJ)best;
             if (idx_out) idx_out[ls] = label + P->index_base;
         }
     }

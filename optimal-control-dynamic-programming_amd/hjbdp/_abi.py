@@ -24,6 +24,9 @@ HJB_F32 = 0
 HJB_F64 = 1
 HJB_F16S = 2
 
+HJB_MODEL_NONE = 0
+HJB_MODEL_QUAT_EULER321 = 1
+
 
 class hjb_term(C.Structure):
     _fields_ = [("mask", C.c_uint32), ("reserved", C.c_uint32), ("data", C.c_void_p)]
@@ -47,6 +50,10 @@ class hjb_problem(C.Structure):
         ("slab_end", C.c_int32),
         ("halo_lo", C.c_int32),
         ("halo_hi", C.c_int32),
+        ("model", C.c_int32),
+        ("reserved1", C.c_int32),
+        ("model_h", C.c_double),
+        ("model_tables", C.c_void_p * 4),
     ]
 
 

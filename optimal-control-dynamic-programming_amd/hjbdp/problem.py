@@ -42,7 +42,7 @@ class ProblemSpec:
     pass `single(linspace(..))`-rounded values to mirror test/Dynamic_Solver.m:69),
     m[C] control grid sizes, next_terms[D][*], cost_terms[*]."""
 
-    def __init__(self, knots, m, next_terms, cost_terms, dtype=np.float64, index_base=0, j_storage=None):
+    def __init__(self, knots, m, next_terms, cost_terms, dtype=np.float64, index_base=0, j_storage=None, model=None):
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise ValueError("dtype must be float32 or float64")
@@ -65,9 +65,24 @@ class ProblemSpec:
         self.cost_terms = [self._check(t, g) for t in cost_terms]
         if len(self.next_terms) != self.D:
             raise ValueError("need one term list per state axis")
-        for ts in self.next_terms + [self.cost_terms]:
-            if not (1 <= len(ts) <= _abi.HJB_MAX_TERMS):
-                raise ValueError("1..%d terms per quantity" % _abi.HJB_MAX_TERMS)
+        # model = {"kind": "quat_euler321", "h": step, "tables": [x4, x5, x6, x7] over (n0, n1, n2)}: the next
+        # value of axes 0..2 is computed inside the library (hjbdp.h HJB_MODEL_QUAT_EULER321), no terms for them
+        self.model = None
+        model_axes = ()
+        if model is not None:
+            if model.get("kind") != "quat_euler321":
+                raise ValueError("unknown model kind %r" % (model.get("kind"),))
+            if self.D != 6 or self.C != 3 or self.dtype != np.float32:
+                raise ValueError("quat_euler321 needs D=6, C=3, float32")
+            tabs = [np.asfortranarray(t, dtype=np.float32) for t in model["tables"]]
+            if len(tabs) != 4 or any(t.shape != self.n[:3] for t in tabs):
+                raise ValueError("model tables must be 4 arrays over the first three axes")
+            self.model = {"kind": "quat_euler321", "h": float(model["h"]), "tables": tabs}
+            model_axes = (0, 1, 2)
+        for a, ts in enumerate(self.next_terms + [self.cost_terms]):
+            lo = 0 if a in model_axes else 1
+            if not (lo <= len(ts) <= (0 if a in model_axes else _abi.HJB_MAX_TERMS)):
+                raise ValueError("1..%d terms per quantity (none for model axes)" % _abi.HJB_MAX_TERMS)
         self.index_base = int(index_base)
         self.nS = int(np.prod(self.n))
         self.nU = int(np.prod(self.m))
@@ -103,6 +118,12 @@ class ProblemSpec:
             keep.append(t.data)
         if slab is not None:
             p.slab_begin, p.slab_end, p.halo_lo, p.halo_hi = (int(x) for x in slab)
+        if self.model is not None:
+            p.model = _abi.HJB_MODEL_QUAT_EULER321
+            p.model_h = self.model["h"]
+            for i, t in enumerate(self.model["tables"]):
+                p.model_tables[i] = t.ctypes.data
+                keep.append(t)
         keep.append(self.knots)
         return p, keep
 
@@ -114,6 +135,8 @@ def permute_state_axes(spec: ProblemSpec, order):
     the new grid back to the old grid's column-major order."""
     order = tuple(int(a) for a in order)
     D, C = spec.D, spec.C
+    if spec.model is not None:
+        raise ValueError("a spec with a state model has a fixed axis labelling")
     if sorted(order) != list(range(D)):
         raise ValueError("order must be a permutation of the state axes")
     new_of_old = {old: new for new, old in enumerate(order)}

@@ -159,21 +159,76 @@ class Solver_attitude:
         nu = len(UV)
         return ProblemSpec(knots, [nu, nu, nu], nxt, cost, dtype=np.float32, index_base=1)
 
+    def build_spec_model(self, j_storage=None):
+        """The same problem as `permute_state_axes(build_spec_full(), AXIS_ORDER)` - axes (yaw, pitch, roll, w1, w2,
+        w3) - but WITHOUT the three nS-sized next-angle tables: the quaternion kinematics :449-489 are evaluated
+        inside the library per state (hjbdp.h HJB_MODEL_QUAT_EULER321) from the four nq^3 quaternion tables.
+        This is what makes 51^6 possible: every table below is O(n^3).  The next angles
+        then come from the library's fixed polynomial atan2/asin instead of numpy's libm, so results agree with
+        the table form to rounding (a few ulp in x_next), not bit for bit."""
+        nw, nq = self.n_mesh_w, self.n_mesh_q
+        sr = [linspace(self.w_min, self.w_max, nw)] * 3
+        s_yaw = linspace(float(deg2rad(self.yaw_min)), float(deg2rad(self.yaw_max)), nq)
+        s_pitch = linspace(float(deg2rad(self.pitch_min)), float(deg2rad(self.pitch_max)), nq)
+        s_roll = linspace(float(deg2rad(self.roll_min)), float(deg2rad(self.roll_max)), nq)
+        X1V, X2V, X3V = (s.astype(f32) for s in sr)
+        c4, s4 = np.cos(s_yaw / 2).astype(f32), np.sin(s_yaw / 2).astype(f32)
+        c5, s5 = np.cos(s_pitch / 2).astype(f32), np.sin(s_pitch / 2).astype(f32)
+        c6, s6 = np.cos(s_roll / 2).astype(f32), np.sin(s_roll / 2).astype(f32)
+        UV = self.U_vector.astype(f32)
+        h, J1, J2, J3 = f32(self.h), self.J1, self.J2, self.J3
+        C4, S4 = c4[:, None, None], s4[:, None, None]
+        C5, S5 = c5[None, :, None], s5[None, :, None]
+        C6, S6 = c6[None, None, :], s6[None, None, :]
+        q1 = S4 * C5 * C6 - C4 * S5 * S6
+        q2 = C4 * S5 * C6 + S4 * C5 * S6
+        q3 = C4 * C5 * S6 - S4 * S5 * C6
+        x7 = (f32(1) - (q1 ** 2 + q2 ** 2 + q3 ** 2)) ** f32(0.5)
+
+        def wnext(c, Xb, Xc, JJ):
+            inner = f32(c) * Xb[:, None, None] * Xc[None, :, None] + (UV / f32(JJ))[None, None, :]
+            return (h * inner).astype(f32)
+        t1 = wnext((J2 - J3) / J1, X2V, X3V, J1)                                        # (w2, w3, U1) = dims (4,5,6)
+        t2 = np.ascontiguousarray(np.transpose(wnext((J3 - J1) / J2, X3V, X1V, J2), (1, 0, 2)))   # (w1, w3, U2) = (3,5,7)
+        t3 = wnext((J1 - J2) / J3, X1V, X2V, J3)                                        # (w1, w2, U3) = (3,4,8)
+        nxt = [[], [], [],
+               [Term((3,), X1V), Term((4, 5, 6), t1)],
+               [Term((4,), X2V), Term((3, 5, 7), t2)],
+               [Term((5,), X3V), Term((3, 4, 8), t3)]]
+        cost = [Term((3,), f32(self.Q1) * X1V ** 2), Term((4,), f32(self.Q2) * X2V ** 2), Term((5,), f32(self.Q3) * X3V ** 2),
+                Term((0, 1, 2), f32(self.Q4) * q1 ** 2), Term((0, 1, 2), f32(self.Q5) * q2 ** 2),
+                Term((0, 1, 2), f32(self.Q6) * q3 ** 2),
+                Term((6,), f32(self.R1) * UV ** 2), Term((7,), f32(self.R2) * UV ** 2), Term((8,), f32(self.R3) * UV ** 2)]
+        knots = [s_yaw, s_pitch, s_roll, sr[0], sr[1], sr[2]]
+        knots = [k.astype(f32).astype(np.float64) for k in knots]
+        nu = len(UV)
+        return ProblemSpec(knots, [nu, nu, nu], nxt, cost, dtype=np.float32, index_base=1, j_storage=j_storage,
+                           model={"kind": "quat_euler321", "h": float(h), "tables": [q1, q2, q3, x7]})
+
     # state-axis labelling handed to the library: the three angle axes (whose next value does not depend on
     # the torques) FIRST, then w1, w2, w3 (driven by U1 outermost ... U3 innermost, w3 LAST): the stage kernel
     # then contracts the angle axes once per state (variant 4, mode 2) instead of once per torque pair.
     # Results are mapped back to the reference's dim order.
     AXIS_ORDER = (3, 4, 5, 0, 1, 2)
 
-    def run(self, n_stages=None, relabel=True):
-        spec = self.build_spec_full()
+    def run(self, n_stages=None, relabel=True, on_the_fly=False):
+        """on_the_fly=True: the next angles are computed inside the library (build_spec_model) instead of being
+        tabulated over the whole 6-D grid - the form that scales to 51^6."""
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
-        shape = spec.n
-        if relabel:
-            from .problem import permute_state_axes
-            pspec, to_old = permute_state_axes(spec, self.AXIS_ORDER)
+        if on_the_fly:
+            pspec = self.build_spec_model()
+            shape = tuple(pspec.n[a] for a in (3, 4, 5, 0, 1, 2))
+
+            def to_old(flat):
+                return np.transpose(np.asarray(flat).reshape(pspec.n, order="F"), (3, 4, 5, 0, 1, 2)).reshape(-1, order="F")
         else:
-            pspec, to_old = spec, (lambda x: x)
+            spec = self.build_spec_full()
+            shape = spec.n
+            if relabel:
+                from .problem import permute_state_axes
+                pspec, to_old = permute_state_axes(spec, self.AXIS_ORDER)
+            else:
+                pspec, to_old = spec, (lambda x: x)
         with Backup(pspec, device=self.device) as bk:
             out = bk.solve(n_st)
             self.kernel_variant = bk.info()["kernel_variant"]

@@ -39,8 +39,40 @@ def lib(abi):
         l.orc_lookup.restype = C.c_int
         l.orc_lookup.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_double)), C.c_void_p,
                                  C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        l.orc_backup_states.restype = C.c_int
+        l.orc_backup_states.argtypes = [C.POINTER(abi.hjb_problem), C.POINTER(C.c_void_p), C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+        l.orc_canon_eval.restype = None
+        l.orc_canon_eval.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
+
+
+def backup_states(abi, spec, jsep, states, nthreads=0):
+    """Backup of the listed whole-grid states with J_next(i) = ((jsep[0][i0] + jsep[1][i1]) + ...)
+    (float32): the checker for grids whose J does not fit in host memory.  -> (J[k], idx[k])."""
+    l = lib(abi)
+    p, keep = spec.to_c()
+    vecs = [np.ascontiguousarray(v, dtype=np.float32) for v in jsep]
+    ptrs = (C.c_void_p * len(vecs))(*[v.ctypes.data for v in vecs])
+    st_ = np.ascontiguousarray(states, dtype=np.int64)
+    J = np.empty(len(st_), dtype=np.float32)
+    idx = np.empty(len(st_), dtype=np.int32)
+    st = l.orc_backup_states(C.byref(p), ptrs, st_.ctypes.data, len(st_), J.ctypes.data, idx.ctypes.data,
+                             nthreads or l.orc_max_threads())
+    if st != 0:
+        raise RuntimeError("orc_backup_states status %d" % st)
+    return J, idx
+
+
+def canon_eval(abi, kind, a, b=None):
+    """The fixed polynomial atan2 (kind 'atan2': a = y, b = x) / asin (kind 'asin') of the quaternion model."""
+    l = lib(abi)
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float32)
+    out = np.empty_like(a)
+    l.orc_canon_eval({"atan2": 0, "asin": 1}[kind], a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    return out
 
 
 def backup_stage(abi, spec, J_next, slab=None, nthreads=0):

@@ -62,7 +62,15 @@ static int validate(const hjb_problem *p) {
     if (p->dtype != HJB_F32 && p->dtype != HJB_F64 && p->dtype != HJB_F16S) return HJB_E_UNSUPPORTED;
     for (int a = 0; a < p->D; ++a) {
         if (p->n[a] < 2 || !p->knots[a]) return HJB_E_INVALID;
-        if (p->n_next_terms[a] < 1 || p->n_next_terms[a] > HJB_MAX_TERMS) return HJB_E_INVALID;
+        const int model_axis = p->model == HJB_MODEL_QUAT_EULER321 && a < 3;
+        if (model_axis ? p->n_next_terms[a] != 0 : (p->n_next_terms[a] < 1 || p->n_next_terms[a] > HJB_MAX_TERMS))
+            return HJB_E_INVALID;
+    }
+    if (p->model != HJB_MODEL_NONE && p->model != HJB_MODEL_QUAT_EULER321) return HJB_E_INVALID;
+    if (p->model == HJB_MODEL_QUAT_EULER321) {
+        if (p->D != 6 || p->C != 3 || p->dtype == HJB_F64) return HJB_E_UNSUPPORTED;
+        for (int i = 0; i < 4; ++i)
+            if (!p->model_tables[i]) return HJB_E_INVALID;
     }
     for (int c = 0; c < p->C; ++c)
         if (p->m[c] < 1) return HJB_E_INVALID;
@@ -70,8 +78,80 @@ static int validate(const hjb_problem *p) {
     return HJB_OK;
 }
 
+/* ---- HJB_MODEL_QUAT_EULER321: next (yaw, pitch, roll) of one state ------------------------------
+ * attitude-control/Solver_attitude.m:449-489 in single precision, operation by operation: Euler step of
+ * the quaternion kinematics (:449-467), renormalisation (:477-483), back to Euler angles (:485-489).
+ * MATLAB's atan2/asin are closed source; the library (and therefore this restatement) uses fixed
+ * polynomial forms built from +,-,*,/ and sqrt only, so that CPU and GPU agree bit for bit.  They are
+ * within a few ulp of libm (tests/test_oracle_golden.py checks that). */
+static float canon_atan2f(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const int swap = ay > ax;
+    const float num = swap ? ax : ay, den = swap ? ay : ax;
+    float r = den == 0.0f ? 0.0f : num / den;               /* in [0, 1] */
+    float off = 0.0f;
+    if (r > 0.4142135623730950f) {                           /* tan(pi/8) */
+        r = (r - 1.0f) / (r + 1.0f);
+        off = 0.78539816339744831f;
+    }
+    const float z = r * r;
+    float pz = 8.05374449538e-2f;
+    pz = pz * z - 1.38776856032e-1f;
+    pz = pz * z + 1.99777106478e-1f;
+    pz = pz * z - 3.33329491539e-1f;
+    float a = off + (pz * z * r + r);
+    if (swap) a = 1.57079632679489662f - a;
+    if (x < 0.0f) a = 3.14159265358979324f - a;
+    return y < 0.0f ? -a : a;
+}
+
+static float canon_asinf(float x) {
+    const float a = fabsf(x);
+    const int big = a > 0.5f;
+    float z, r;
+    if (big) {
+        z = 0.5f * (1.0f - a);
+        r = sqrtf(z);
+    } else {
+        r = a;
+        z = a * a;
+    }
+    float pz = 4.2163199048e-2f;
+    pz = pz * z + 2.4181311049e-2f;
+    pz = pz * z + 4.5470025998e-2f;
+    pz = pz * z + 7.4953002686e-2f;
+    pz = pz * z + 1.6666752422e-1f;
+    float v = pz * z * r + r;
+    if (big) v = 1.57079632679489662f - (v + v);
+    return x < 0.0f ? -v : v;
+}
+
+void orc_canon_eval(int kind, int64_t n, const float *a, const float *b, float *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = kind == 0 ? canon_atan2f(a[i], b[i]) : canon_asinf(a[i]);
+}
+
+/* gi: grid indices of the state; W = knots of axes 3..5 (single) */
+static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float w2, float w3, float *out3) {
+    const int64_t ti = gi[0] + (int64_t)p->n[0] * (gi[1] + (int64_t)p->n[1] * gi[2]);
+    const float q1 = ((const float *)p->model_tables[0])[ti], q2 = ((const float *)p->model_tables[1])[ti];
+    const float q3 = ((const float *)p->model_tables[2])[ti], q7 = ((const float *)p->model_tables[3])[ti];
+    const float h = (float)p->model_h, half = 0.5f;
+    float x4 = q1 + h * (half * ((w3 * q2 - w2 * q3) + w1 * q7));       /* :449-452 */
+    float x5 = q2 + h * (half * ((-w3 * q1 + w1 * q3) + w2 * q7));      /* :454-457 */
+    float x6 = q3 + h * (half * ((w2 * q1 - w1 * q2) + w3 * q7));       /* :459-462 */
+    float x7 = q7 + h * (half * ((-w1 * q1 - w2 * q2) - w3 * q3));      /* :465-467 */
+    const float nrm = sqrtf(((x4 * x4 + x5 * x5) + x6 * x6) + x7 * x7); /* :477 */
+    x4 = x4 / nrm; x5 = x5 / nrm; x6 = x6 / nrm; x7 = x7 / nrm;         /* :480-483 */
+    out3[0] = canon_atan2f(2.0f * (x6 * x5 + x7 * x4), ((x7 * x7 + x6 * x6) - x5 * x5) - x4 * x4);   /* :485-486 */
+    out3[1] = canon_asinf(-2.0f * (x6 * x4 - x7 * x5));                                              /* :487 */
+    out3[2] = canon_atan2f(2.0f * (x5 * x4 + x7 * x6), ((x7 * x7 - x6 * x6) - x5 * x5) + x4 * x4);   /* :488-489 */
+}
+
 #define DEFINE_BACKUP(T, NAME, FMA)                                                                   \
-    static int NAME(const hjb_problem *p, const T *Jn, T *Jout, int32_t *idx_out, int nthreads) {      \
+    static int NAME(const hjb_problem *p, const T *Jn, T *Jout, int32_t *idx_out, int nthreads,        \
+                    const int64_t *sel, int64_t nsel, const T *const *jsep) {                          \
+        /* sel != NULL: only the listed (whole-grid) states, outputs compact [nsel];                  \
+           jsep != NULL: J_next(i) = ((jsep[0][i0] + jsep[1][i1]) + ...) instead of an array */        \
         const int D = p->D, C = p->C;                                                                  \
         T *knots[HJB_MAX_D], *rdx[HJB_MAX_D];                                                          \
         term_t nt[HJB_MAX_D][HJB_MAX_TERMS], ct[HJB_MAX_TERMS];                                        \
@@ -100,7 +180,8 @@ static int validate(const hjb_problem *p) {
         int err = 0;                                                                                   \
         (void)nthreads;                                                                                \
         _Pragma("omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)")         \
-        for (int64_t ls = 0; ls < n_owned; ++ls) {                                                     \
+        for (int64_t it = 0; it < (sel ? nsel : n_owned); ++it) {                                      \
+            const int64_t ls = sel ? sel[it] : it;                                                     \
             int gi[HJB_MAX_G];                                                                         \
             int64_t r = ls;                                                                            \
             for (int a = 0; a < D; ++a) {                                                              \
@@ -113,12 +194,15 @@ static int validate(const hjb_problem *p) {
             int64_t best_label = 0;                                                                    \
             int first = 1;                                                                             \
             for (int c = 0; c < C; ++c) gi[D + c] = 0;                                                 \
+            float mq[3] = {0.f, 0.f, 0.f};                                                             \
+            if (p->model == HJB_MODEL_QUAT_EULER321)                                                   \
+                model_quat_next(p, gi, (float)knots[3][gi[3]], (float)knots[4][gi[4]], (float)knots[5][gi[5]], mq); \
             for (int64_t u = 0; u < nU; ++u) {                                                         \
                 T v[1 << HJB_MAX_D];                                                                   \
                 T tw[HJB_MAX_D];                                                                       \
                 int64_t base = 0;                                                                      \
                 for (int a = 0; a < D; ++a) {                                                          \
-                    T q = 0;                                                                           \
+                    T q = (p->model == HJB_MODEL_QUAT_EULER321 && a < 3) ? (T)mq[a] : (T)0;           \
                     for (int k = 0; k < p->n_next_terms[a]; ++k) {                                     \
                         int64_t off = 0;                                                               \
                         for (int d = 0; d < D + C; ++d) off += nt[a][k].stride[d] * gi[d];             \
@@ -148,7 +232,13 @@ static int validate(const hjb_problem *p) {
                     int64_t off = base;                                                                \
                     for (int a = 0; a < D; ++a)                                                        \
                         if (c & (1 << a)) off += jstride[a];                                           \
-                    v[c] = Jn[off];                                                                    \
+                    if (!jsep) { v[c] = Jn[off]; continue; }                                           \
+                    T sv = 0;                                                                          \
+                    for (int a = 0; a < D; ++a) {                                                      \
+                        const T x = jsep[a][(off / jstride[a]) % (a == D - 1 ? nplanes : p->n[a])];    \
+                        sv = a == 0 ? x : (T)(sv + x);                                                 \
+                    }                                                                                  \
+                    v[c] = sv;                                                                         \
                 }                                                                                      \
                 for (int a = 0; a < D; ++a) {                                                          \
                     int half = 1 << (D - 1 - a);                                                       \
@@ -177,8 +267,8 @@ static int validate(const hjb_problem *p) {
             }                                                                                          \
             /* owned state -> position in the haloed J layout */                                       \
             int64_t in_plane = ls % inner, pl = ls / inner;                                            \
-            Jout[in_plane + inner * (pl + hlo)] = best;                                                \
-            if (idx_out) idx_out[ls] = (int32_t)(best_label + p->index_base);                          \
+            Jout[sel ? it : in_plane + inner * (pl + hlo)] = best;                                     \
+            if (idx_out) idx_out[sel ? it : ls] = (int32_t)(best_label + p->index_base);               \
         }                                                                                              \
         for (int a = 0; a < D; ++a) { free(knots[a]); free(rdx[a]); }                                  \
         return err ? HJB_E_HALO : HJB_OK;                                                              \
@@ -210,13 +300,24 @@ int orc_backup_stage(const hjb_problem *p, const void *J_next, void *J_out, int3
         float *a = (float *)malloc(sizeof(float) * (ne > 0 ? ne : 1)), *b = (float *)malloc(sizeof(float) * (ne > 0 ? ne : 1));
         if (!a || !b) { free(a); free(b); return HJB_E_NOMEM; }
         for (int64_t i = 0; i < ne; ++i) { a[i] = h2f(((const uint16_t *)J_next)[i]); b[i] = h2f(((const uint16_t *)J_out)[i]); }
-        st = backup_f32(p, a, b, idx_out, nthreads);
+        st = backup_f32(p, a, b, idx_out, nthreads, NULL, 0, NULL);
         for (int64_t i = 0; i < ne; ++i) ((uint16_t *)J_out)[i] = f2h(b[i]);
         free(a); free(b);
         return st;
     }
-    if (p->dtype == HJB_F32) return backup_f32(p, (const float *)J_next, (float *)J_out, idx_out, nthreads);
-    return backup_f64(p, (const double *)J_next, (double *)J_out, idx_out, nthreads);
+    if (p->dtype == HJB_F32) return backup_f32(p, (const float *)J_next, (float *)J_out, idx_out, nthreads, NULL, 0, NULL);
+    return backup_f64(p, (const double *)J_next, (double *)J_out, idx_out, nthreads, NULL, 0, NULL);
+}
+
+/* Backup of a LIST of states of the whole grid (no slab) with J_next given in separable form
+ * J_next(i) = ((jsep[0][i0] + jsep[1][i1]) + ...) - lets the checker sample grids whose J does not fit in
+ * host memory (C3: 51^6).  HJB_F32 only.  Outputs are compact: J_out[k], idx_out[k] for states[k]. */
+int orc_backup_states(const hjb_problem *p, const float *const *jsep, const int64_t *states, int64_t nstates,
+                      float *J_out, int32_t *idx_out, int nthreads) {
+    int st = validate(p);
+    if (st) return st;
+    if (p->dtype != HJB_F32 || p->slab_begin || p->slab_end) return HJB_E_UNSUPPORTED;
+    return backup_f32(p, NULL, J_out, idx_out, nthreads, states, nstates, jsep);
 }
 
 /* whole-grid backward sweep with the same outputs as hjb_solve. */

@@ -38,6 +38,7 @@ def test_struct_layout_matches_header(lib):
     assert C.sizeof(_abi.hjb_term) == 16
     expect = 4 * 2 + 4 * 6 + 4 * 3 + 4 * 2  # D,C,n,m,dtype,index_base = 52 -> pad to 56
     expect = 56 + 8 * 6 + 4 * 6 + 16 * 12 * 6 + 8 + 16 * 12 + 16
+    expect += 4 + 4 + 8 + 8 * 4             # model, reserved1, model_h, model_tables[4]
     assert C.sizeof(_abi.hjb_problem) == expect
     assert C.sizeof(_abi.hjb_solve_opts) == 4 + 4 + 8 + 8 * 5 + 8 + 8
     assert C.sizeof(_abi.hjb_result) == 32

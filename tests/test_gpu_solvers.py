@@ -75,6 +75,96 @@ def test_solver_attitude_relabelled_axes(env):
     assert np.max(np.abs(sa.F_values.reshape(-1, order="F") - plain["J"]) / np.maximum(1e-3, np.abs(plain["J"]))) < 2e-5
 
 
+def test_solver_attitude_on_the_fly_model(env):
+    """HJB_MODEL_QUAT_EULER321: next angles computed in the stage kernel (variant 4 mode 3).  Bit-exact against
+    the oracle's restatement of the same model; equal to the tabulated form up to the few-ulp difference
+    between the fixed polynomial atan2/asin and numpy's."""
+    hjbdp, _abi, c_oracle = env
+    for nw, nq, st in ((5, 4, 5), (7, 6, 3)):
+        sa = hjbdp.Solver_attitude(n_mesh_w=nw, n_mesh_q=nq)
+        sa.U_vector = np.linspace(-0.11, 0.11, 4)
+        mspec = sa.build_spec_model()
+        with hjbdp.Backup(mspec) as bk:
+            assert bk.info()["kernel_variant"] == 4
+            with pytest.raises(hjbdp.HjbError):
+                bk.set_option("variant", 0)
+            out = bk.solve(st)
+        ref = c_oracle.sweep(_abi, mspec, st)
+        assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+        rng = np.random.default_rng(nw)
+        J0 = (rng.random(mspec.nS) * 3).astype(np.float32)            # rough J: exercises the window fallbacks
+        with hjbdp.Backup(mspec) as bk:
+            Jg, ig = bk.backup_stage(J0)
+        Jr, ir = c_oracle.backup_stage(_abi, mspec, J0)
+        assert np.array_equal(Jg, Jr) and np.array_equal(ig, ir)
+        pspec, _ = hjbdp.permute_state_axes(sa.build_spec_full(), sa.AXIS_ORDER)
+        tab = c_oracle.sweep(_abi, pspec, st)
+        assert np.max(np.abs(tab["J"] - ref["J"])) <= 1e-5 * np.max(np.abs(tab["J"]))
+        assert np.mean(tab["idx"] == ref["idx"]) > 0.999
+    sa.run(n_stages=3, on_the_fly=True)
+    assert np.array_equal(np.transpose(sa.F_values, (3, 4, 5, 0, 1, 2)).reshape(-1, order="F"), ref["J"])
+    # float16 J storage goes through the same kernel
+    hspec = sa.build_spec_model(j_storage=np.float16)
+    with hjbdp.Backup(hspec) as bk:
+        out = bk.solve(3)
+    refh = c_oracle.sweep(_abi, hspec, 3)
+    assert np.array_equal(out["J"], refh["J"]) and np.array_equal(out["idx"], refh["idx"])
+
+
+def test_c3_full_size_51_pow_6(env):
+    """BASELINE C3: 51^6 = 1.76e10 states x 11^3 torques, one backup on one GPU.  J_k+1, J_k and
+    the argmin table are 70.4 GB each (211 GB of the 288 GB HBM).  J_k+1 is a separable sum of per-axis vectors
+    (built on the device with broadcast adds) so that the CPU checker can evaluate any state without holding
+    the grid: a sample of states must agree with the oracle bit for bit."""
+    import torch
+    hjbdp, _abi, c_oracle = env
+    free, total = torch.cuda.mem_get_info()
+    if free < 225 * 2 ** 30:
+        pytest.skip("needs 225 GB of free HBM, have %.0f GB" % (free / 2 ** 30))
+    sa = hjbdp.Solver_attitude(n_mesh_w=51, n_mesh_q=51)
+    sa.U_vector = np.linspace(-0.11, 0.11, 11)
+    spec = sa.build_spec_model()
+    assert spec.nS == 51 ** 6 and spec.nU == 1331
+    rng = np.random.default_rng(51)
+    vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
+    dev = torch.device("cuda:0")
+    J = torch.empty(spec.nS, dtype=torch.float32, device=dev)
+    Jv = J.view(*reversed(spec.n))                      # torch dim 5-a <-> state axis a (axis 0 fastest)
+    for a, v in enumerate(vecs):
+        shape = [1] * 6
+        shape[5 - a] = -1
+        t = torch.from_numpy(v).to(dev).view(*shape)
+        if a == 0:
+            Jv.copy_(t.expand_as(Jv))
+        else:
+            Jv.add_(t)                                  # one float32 add per element, like the checker
+    Jo = torch.empty_like(J)
+    idx = torch.empty(spec.nS, dtype=torch.int32, device=dev)
+    with hjbdp.Backup(spec) as bk:
+        info = bk.info()
+        assert info["kernel_variant"] == 4 and info["n_states"] == 51 ** 6
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        bk.backup_stage_device(J, Jo, idx, stream=stream)
+        t1.record()
+        torch.cuda.synchronize()
+        bk.check_device_status(stream)
+        ms = t0.elapsed_time(t1)
+    print("C3 51^6 x 11^3: %.1f s per stage, %.3e backups/s" % (ms * 1e-3, spec.nS * spec.nU / (ms * 1e-3)))
+    n = np.array(spec.n, dtype=np.int64)
+    sel = rng.integers(0, spec.nS, 300)
+    # plus grid corners / edges and the very last state (64-bit indexing)
+    corners = [sum(int(c) * int(np.prod(n[:a])) for a, c in enumerate(cs))
+               for cs in ((0,) * 6, (50,) * 6, (50, 0, 50, 0, 50, 0), (0, 50, 0, 50, 0, 50), (25,) * 6, (50, 50, 50, 0, 0, 50))]
+    sel = np.unique(np.concatenate([sel, np.array(corners, dtype=np.int64), [spec.nS - 1, 2 ** 31 - 1, 2 ** 31, 2 ** 32 + 5]]))
+    Jr, ir = c_oracle.backup_states(_abi, spec, vecs, sel)
+    ts = torch.from_numpy(sel).to(dev)
+    assert np.array_equal(Jo[ts].cpu().numpy(), Jr)
+    assert np.array_equal(idx[ts].cpu().numpy(), ir)
+
+
 def test_solver_attitude_full_6d(env):
     """Solver_attitude.run semantics (6-D x 3-D, single) at a reduced size."""
     hjbdp, _abi, c_oracle = env

@@ -134,3 +134,44 @@ def test_permute_state_axes_is_a_relabelling(orc):
     assert np.mean(to_old(b["idx"]) == a["idx"]) > 0.99
     with pytest.raises(ValueError):
         hjbdp.permute_state_axes(spec, (0, 0, 1))
+
+
+def test_quaternion_model_restatement(orc):
+    """HJB_MODEL_QUAT_EULER321 in the checker: (1) its fixed polynomial atan2/asin stay within 4 ulp of libm;
+    (2) the on-the-fly form of Solver_attitude.run agrees with the tabulated form (numpy restatement of
+    Solver_attitude.m:449-489) to rounding; (3) the state-list / separable-J entry point used for the 51^6
+    check equals the whole-grid backup."""
+    import hjbdp
+    _abi, c_oracle, hjb_oracle = orc
+    rng = np.random.default_rng(0)
+    y, x = rng.standard_normal(200000).astype(np.float32), rng.standard_normal(200000).astype(np.float32)
+    a = c_oracle.canon_eval(_abi, "atan2", y, x)
+    ref = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    assert np.max(np.abs(a - ref) / np.spacing(np.abs(ref).astype(np.float32))) < 4
+    assert c_oracle.canon_eval(_abi, "atan2", np.float32([0, 0, 1, -1]), np.float32([1, -1, 0, 0])).tolist() == \
+        pytest.approx([0.0, np.pi, np.pi / 2, -np.pi / 2], rel=1e-7)
+    v = rng.uniform(-1, 1, 200000).astype(np.float32)
+    s = c_oracle.canon_eval(_abi, "asin", v)
+    ref = np.arcsin(v.astype(np.float64))
+    assert np.max(np.abs(s - ref) / np.spacing(np.abs(ref).astype(np.float32))) < 4
+
+    sa = hjbdp.Solver_attitude(n_mesh_w=6, n_mesh_q=5)
+    pspec, _ = hjbdp.permute_state_axes(sa.build_spec_full(), sa.AXIS_ORDER)
+    mspec = sa.build_spec_model()
+    assert mspec.n == pspec.n == (5, 5, 5, 6, 6, 6) and [len(t) for t in mspec.next_terms] == [0, 0, 0, 2, 2, 2]
+    t, m = c_oracle.sweep(_abi, pspec, 4), c_oracle.sweep(_abi, mspec, 4)
+    assert np.max(np.abs(t["J"] - m["J"])) <= 1e-5 * np.max(np.abs(t["J"]))
+    assert np.mean(t["idx"] == m["idx"]) > 0.999
+
+    vecs = [rng.random(n).astype(np.float32) for n in mspec.n]
+    J = np.zeros(mspec.n, dtype=np.float32)
+    for ax, vv in enumerate(vecs):
+        sh = [1] * 6
+        sh[ax] = -1
+        J = (J + vv.reshape(sh)).astype(np.float32) if ax else np.broadcast_to(vv.reshape(sh), mspec.n).astype(np.float32)
+    Jf, If = c_oracle.backup_stage(_abi, mspec, np.asfortranarray(J))
+    sel = rng.choice(mspec.nS, 300, replace=False)
+    Js, Is = c_oracle.backup_states(_abi, mspec, vecs, sel)
+    assert np.array_equal(Js, Jf[sel]) and np.array_equal(Is, If[sel])
+    with pytest.raises(ValueError):
+        hjbdp.permute_state_axes(mspec, (1, 0, 2, 3, 4, 5))

@@ -1,0 +1,35 @@
+"""C3 (BASELINE configs[2]): the 6-D attitude model on n^6 states x nu^3 torques with the on-the-fly quaternion
+model (no nS-sized tables), J resident in HBM.  usage: python tools/time_c3.py [n=51] [nu=11] [stages=1] [f16=0]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
+import hjbdp
+import torch
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 51
+nu = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+stages = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+f16 = len(sys.argv) > 4 and sys.argv[4] == "1"
+sa = hjbdp.Solver_attitude(n_mesh_w=n, n_mesh_q=n)
+sa.U_vector = np.linspace(-0.11, 0.11, nu)
+spec = sa.build_spec_model(j_storage=np.float16 if f16 else None)
+dev = torch.device("cuda:0")
+tdt = torch.float16 if f16 else torch.float32
+J = [torch.zeros(spec.nS, dtype=tdt, device=dev) for _ in range(2)]
+idx = torch.empty(spec.nS, dtype=torch.int32, device=dev)
+print("J buffers 2 x %.1f GB + argmin %.1f GB" % (J[0].numel() * J[0].element_size() / 1e9, idx.numel() * 4 / 1e9), flush=True)
+with hjbdp.Backup(spec) as bk:
+    print(bk.info(), flush=True)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(stages + 1)]
+    ev[0].record()
+    for k in range(stages):
+        bk.backup_stage_device(J[k & 1], J[1 - (k & 1)], idx, stream=stream)
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    bk.check_device_status(stream)
+for k in range(stages):
+    ms = ev[k].elapsed_time(ev[k + 1])
+    print("stage %d: %.2f s, %.3e backups/s" % (k, ms * 1e-3, spec.nS * spec.nU / (ms * 1e-3)), flush=True)
+Jf = J[stages & 1]
+print("J range", float(Jf.min()), float(Jf.max()), "idx range", int(idx.min()), int(idx.max()))
