@@ -310,19 +310,39 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             if ((U >> (2 * p)) & 3u) PU |= 1u << p;
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
-        int cAmin = 0, cBmin = 0;
-        if constexpr (PRE) {
-            int ca = 0x7fffffff, cb = 0x7fffffff;
-            for (int o0 = 0; o0 < m_o0; ++o0) {
-                const int c = atab[AX_A][aoff[AX_A] + o0 * a_c0[AX_A]].x;
-                ca = c < ca ? c : ca;
-                for (int o1 = 0; o1 < m_o1; ++o1) {
-                    const int c2 = atab[AX_B][aoff[AX_B] + o0 * a_c0[AX_B] + o1 * a_c1[AX_B]].x;
-                    cb = c2 < cb ? c2 : cb;
-                }
+        // smallest cell over `cnt` table entries `step` apart: four independent loads in flight per trip
+        auto min_cell = [&](const int2 *__restrict__ tb, int cnt, int step) {
+            int cm = 0x7fffffff, o = 0;
+            for (; o + 4 <= cnt; o += 4) {
+                const int x0 = tb[o * step].x, x1 = tb[(o + 1) * step].x, x2 = tb[(o + 2) * step].x, x3 = tb[(o + 3) * step].x;
+                const int lo01 = x0 < x1 ? x0 : x1, lo23 = x2 < x3 ? x2 : x3;
+                const int lo = lo01 < lo23 ? lo01 : lo23;
+                cm = lo < cm ? lo : cm;
             }
+            for (; o < cnt; ++o) {
+                const int x = tb[o * step].x;
+                cm = x < cm ? x : cm;
+            }
+            return cm;
+        };
+        // modes 1-3: does the level-1 axis' table depend on o0 as well?  (wave-uniform; usually not)
+        const bool b_o0dep = HIER && a_c0[AX_B] != 0;
+        int cAmin = 0, cBmin = 0;
+        if constexpr (HIER) {
+            if (!b_o0dep) cBmin = min_cell(atab[AX_B] + aoff[AX_B], m_o1, a_c1[AX_B]);
+        }
+        if constexpr (PRE) {
+            const int ca = min_cell(atab[AX_A] + aoff[AX_A], m_o0, a_c0[AX_A]);
+            if (b_o0dep) {
+                int cbm = 0x7fffffff;
+                for (int o0 = 0; o0 < m_o0; ++o0) {
+                    const int c2 = min_cell(atab[AX_B] + aoff[AX_B] + o0 * a_c0[AX_B], m_o1, a_c1[AX_B]);
+                    cbm = c2 < cbm ? c2 : cbm;
+                }
+                cBmin = cbm;
+            }
+            const int cb = cBmin;
             cAmin = ca;
-            cBmin = cb;
             const int nA = P->axis[AX_A].n, nB = P->axis[AX_B].n;
             const int planes[4] = {lc0, lc0 + 1, lc1, lc1 + 1};
             int pbase = 0;
@@ -331,7 +351,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll 1
             for (int ra = 0; ra < 3; ++ra) {
                 const int rowA = ca + ra < nA ? ca + ra : nA - 1;
-#pragma unroll 1
+#pragma unroll
                 for (int rb = 0; rb < 3; ++rb) {
                     const int rowB = cb + rb < nB ? cb + rb : nB - 1;
                     const int off = pbase + js[AX_A] * rowA + js[AX_B] * rowB;      // < one plane: fits 32 bits
@@ -425,11 +445,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         F[rb][q] = __builtin_fmaf(ta, f1 - f0, f0);
                     }
             } else if constexpr (MODE == 1) {
-                int cmin = 0x7fffffff;
-                for (int o1 = 0; o1 < m_o1; ++o1) {
-                    const int c = atab[1][aoff[1] + o0 * a_c0[1] + o1 * a_c1[1]].x;
-                    cmin = c < cmin ? c : cmin;
-                }
+                const int cmin = b_o0dep ? min_cell(atab[1] + aoff[1] + o0 * a_c0[1], m_o1, a_c1[1]) : cBmin;
                 c1min = cmin;
                 const int n1 = P->axis[1].n;
                 const int rows[3] = {cmin, cmin + 1, cmin + 2 < n1 ? cmin + 2 : n1 - 1};
@@ -448,11 +464,39 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 load_corners<D>(Jn, base + js[D - 1] * lc0, js, G);
                 load_corners<D>(Jn, base + js[D - 1] * lc1, js, H);
             }
+            // modes 1-3: the level-1 axis' (cell, t) entry and the level-1 cost term are fetched ONE STEP AHEAD
+            // (a dependent global load per o1 step would otherwise stall every step)
+            const int2 *tb1 = atab[AX_B] + aoff[AX_B] + o0 * a_c0[AX_B];
+            const int tb1_step = a_c1[AX_B];
+            int2 e_nx = {0, 0};
+            float g_nx = 0.f;
+            auto level1_cost = [&](int o1) -> float {
+                if (!cl1_present) return go0;
+                const float x = cterm(CL1, o0, o1);
+                return cl1_first ? x : go0 + x;
+            };
+            if constexpr (HIER) {
+                e_nx = tb1[0];
+                g_nx = level1_cost(0);
+            }
+            // base offset of the outer axes' cells: modes 1-3 need it on the rare paths only
+            auto outer_base = [&]() {
+                int b = 0;
+#pragma unroll
+                for (int a = 0; a < D - 1; ++a) b += js[a] * cell[a];
+                return b;
+            };
             for (int o1 = 0; o1 < m_o1; ++o1, ++uo) {
                 // ---- level 1: (E0, dE) of the two last-axis cells this state visits ----------
                 float e0a, dea, e0b, deb;
                 if constexpr (HIER) {
-                    prepare(o1, base, twc, go);
+                    cell[AX_B] = e_nx.x;
+                    tw[AX_B] = __int_as_float(e_nx.y);
+                    go = g_nx;
+                    if (o1 + 1 < m_o1) {
+                        e_nx = tb1[(o1 + 1) * tb1_step];
+                        g_nx = level1_cost(o1 + 1);
+                    }
                     const int r = cell[AX_B] - c1min;
                     if ((r == 0 || r == 1) && !slow_a) {                 // inside the prepared 2-cell window
                         const bool up = r != 0;
@@ -467,8 +511,9 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         e0a = X[0]; dea = X[1] - X[0];
                         e0b = X[2]; deb = X[3] - X[2];
                     } else {                                             // rare: axis 1 spans > 2 cells in this sweep
-                        cell_pair(base, lc0, twc, e0a, dea);
-                        cell_pair(base, lc1, twc, e0b, deb);
+                        const int ob = outer_base();
+                        cell_pair(ob, lc0, tw, e0a, dea);
+                        cell_pair(ob, lc1, tw, e0b, deb);
                     }
                 } else {
                     f2 v[1 << D];                                    // {first cell, second cell} contracted together
@@ -510,7 +555,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                             *P->status = 1;
                             lc = lc < 0 ? 0 : nplanes - 2;
                         }
-                        cell_pair(base, lc, twc, ne0, nde);
+                        if constexpr (HIER) cell_pair(outer_base(), lc, tw, ne0, nde);
+                        else cell_pair(base, lc, twc, ne0, nde);
                     }
                 };
                 // ---- inner loop over control PAIRS: packed, no loads, no cell tests on the vector pipe.
