@@ -494,8 +494,11 @@ int build(Handle *h, const hjb_problem *p) {
             HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipDeviceSynchronize());
             h->packed_pre = 0;
-            if (C == 3 && D == 3 && N.at[0].level == 0 && N.at[1].level == 1) h->packed_pre = 1;
-            if (C == 3 && D >= 4 && N.at[D - 3].level == 0 && N.at[D - 2].level == 1) {
+            // modes 1-3 read the level cost terms from LDS only
+            const bool cl_lds = (!N.ot[HJB_MAX_D].present || N.ot[HJB_MAX_D].lds_off >= 0) &&
+                                (!N.ot[HJB_MAX_D + 1].present || N.ot[HJB_MAX_D + 1].lds_off >= 0);
+            if (cl_lds && C == 3 && D == 3 && N.at[0].level == 0 && N.at[1].level == 1) h->packed_pre = 1;
+            if (cl_lds && C == 3 && D >= 4 && N.at[D - 3].level == 0 && N.at[D - 2].level == 1) {
                 bool pre = true;
                 for (int a = 0; a < D - 3; ++a) pre = pre && N.at[a].level < 0;
                 if (pre && h->packed2_lds + 36 * 256 * 4 <= 64 * 1024) {

@@ -51,6 +51,13 @@ struct DParams {
     const void *model_tab[4];
 };
 
+// Pointers read out of the parameter structs are generic ("flat") to the compiler.  Everything this library uploads
+// lives in global memory; saying so turns flat_load (which also occupies the LDS counter and forces
+// s_waitcnt lgkmcnt) into global_load.  Table entries are read as builtin vectors (loadable from any address space).
+template <typename T> using gptr = const __attribute__((address_space(1))) T *;
+template <typename T> __device__ __forceinline__ gptr<T> as_global(const void *p) { return (gptr<T>)p; }
+typedef int i2v __attribute__((ext_vector_type(2)));
+
 // J storage type helpers: J may be stored narrower than the arithmetic type (HJB_F16S: IEEE binary16
 // storage, float32 arithmetic; conversion to half rounds to nearest even, widening is exact).
 typedef _Float16 half_t;

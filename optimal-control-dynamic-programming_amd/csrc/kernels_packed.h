@@ -39,7 +39,7 @@ __device__ __forceinline__ float term_value32(const DTerm &t, const int (&si)[D]
     int off = 0;
 #pragma unroll
     for (int a = 0; a < D; ++a) off += t.stride[a] * si[a];
-    return static_cast<const float *>(t.data)[off];   // state-only (prefix) terms
+    return as_global<float>(t.data)[off];   // state-only (prefix) terms
 }
 
 // same, J stored as IEEE half: two adjacent halves per 4-byte load

@@ -85,8 +85,8 @@ __device__ __forceinline__ float canon_asinf(float x) {
 __device__ __forceinline__ void model_quat_next(const DParams *__restrict__ P, const int *si, float w1, float w2, float w3,
                                                 float (&out)[3]) {
     const int ti = si[0] + P->axis[0].n * (si[1] + P->axis[1].n * si[2]);
-    const float q1 = static_cast<const float *>(P->model_tab[0])[ti], q2 = static_cast<const float *>(P->model_tab[1])[ti];
-    const float q3 = static_cast<const float *>(P->model_tab[2])[ti], q7 = static_cast<const float *>(P->model_tab[3])[ti];
+    const float q1 = as_global<float>(P->model_tab[0])[ti], q2 = as_global<float>(P->model_tab[1])[ti];
+    const float q3 = as_global<float>(P->model_tab[2])[ti], q7 = as_global<float>(P->model_tab[3])[ti];
     const float h = P->model_h, half = 0.5f;
     float x4 = q1 + h * (half * ((w3 * q2 - w2 * q3) + w1 * q7));       // :449-452
     float x5 = q2 + h * (half * ((-w3 * q1 + w1 * q3) + w2 * q7));      // :454-457
@@ -97,6 +97,28 @@ __device__ __forceinline__ void model_quat_next(const DParams *__restrict__ P, c
     out[0] = canon_atan2f(2.0f * (x6 * x5 + x7 * x4), ((x7 * x7 + x6 * x6) - x5 * x5) - x4 * x4);   // :485-486
     out[1] = canon_asinf(-2.0f * (x6 * x4 - x7 * x5));                                              // :487
     out[2] = canon_atan2f(2.0f * (x5 * x4 + x7 * x6), ((x7 * x7 - x6 * x6) - x5 * x5) + x4 * x4);   // :488-489
+}
+
+// find_cell (kernels_generic.h) on a global-address-space knot vector: the same exact search
+__device__ __forceinline__ int find_cell_g(gptr<float> k, int n, float q, int uniform, float x0, float inv_h) {
+    int i;
+    if (uniform) {
+        float f = (q - x0) * inv_h;
+        const float hi = (float)(n - 2);
+        f = f > 0.f ? f : 0.f;
+        f = f < hi ? f : hi;
+        i = (int)f;
+        while (i > 0 && q < k[i]) --i;
+        while (i < n - 2 && q >= k[i + 1]) ++i;
+    } else {
+        int lo = 0, hi = n - 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (k[mid] <= q) lo = mid; else hi = mid;
+        }
+        i = lo;
+    }
+    return i;
 }
 
 // Depth-first contraction of axes 0..A-1 at element offset `off` (axis 0 lerped first, like contract<>): the same
@@ -194,20 +216,22 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     for (int a = 0; a < D; ++a) js[a] = (int)P->jstride[a];
     const int inner_sz = (int)P->inner;
     f2 *my_t = s_t + threadIdx.x;
-    const int2 *atab[DM];
+    gptr<i2v> atab[DM];
     int a_c0[DM], a_c1[DM], a_lvl[DM];
 #pragma unroll
     for (int a = 0; a < D - 1; ++a) {
-        atab[a] = static_cast<const int2 *>(N->at[a].tab);
+        atab[a] = as_global<i2v>(N->at[a].tab);
         a_c0[a] = N->at[a].c0;
         a_c1[a] = N->at[a].c1;
         a_lvl[a] = N->at[a].level;
     }
     const bool cl0_present = N->ot[CL0].present, cl1_present = N->ot[CL1].present;
     const bool cl0_first = N->ot[CL0].first, cl1_first = N->ot[CL1].first;
+    const int cl_off[2] = {N->ot[CL0].lds_off, N->ot[CL1].lds_off};
+    const int cl_c0[2] = {N->ot[CL0].c0, N->ot[CL1].c0}, cl_c1[2] = {N->ot[CL0].c1, N->ot[CL1].c1};
     // last axis' inner term: control-only (LDS) or state-dependent (global, offset boff + j * stride)
     const bool b_pure = N->in[0].lds_slot >= 0;
-    const float *b_data = static_cast<const float *>(N->in[0].data);
+    gptr<float> b_data = as_global<float>(N->in[0].data);
     const int b_stride = N->in[0].stride_in;
 
     for (sidx_t blk = (sidx_t)blockIdx.x * 256; blk < n_owned; blk += (sidx_t)gridDim.x * 256) {
@@ -256,22 +280,22 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 for (int d = 0; d < D; ++d) off += N->at[a].sstride[d] * (d == D - 1 ? last_local : si[d]);
                 aoff[a] = off;
                 if (a_lvl[a] < 0 && !(QMODEL && a < 3)) {
-                    const int2 e = atab[a][off];
+                    const i2v e = atab[a][off];
                     cell[a] = e.x;
                     tw[a] = __int_as_float(e.y);
                 }
             }
             if constexpr (QMODEL) {
                 float qn[3];
-                model_quat_next(P, si, static_cast<const float *>(P->axis[3].knots)[si[3]],
-                                static_cast<const float *>(P->axis[4].knots)[si[4]], s_k[si[5]], qn);
+                model_quat_next(P, si, as_global<float>(P->axis[3].knots)[si[3]],
+                                as_global<float>(P->axis[4].knots)[si[4]], s_k[si[5]], qn);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     const DAxis &ax = P->axis[a];
-                    const float *kk = static_cast<const float *>(ax.knots);
-                    const int c = find_cell<float>(kk, ax.n, qn[a], ax.uniform, (float)ax.x0, (float)ax.inv_h);
+                    gptr<float> kk = as_global<float>(ax.knots);
+                    const int c = find_cell_g(kk, ax.n, qn[a], ax.uniform, (float)ax.x0, (float)ax.inv_h);
                     cell[a] = c;
-                    tw[a] = (qn[a] - kk[c]) * static_cast<const float *>(ax.rdx)[c];
+                    tw[a] = (qn[a] - kk[c]) * as_global<float>(ax.rdx)[c];
                 }
             }
 #pragma unroll
@@ -311,7 +335,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
         // smallest cell over `cnt` table entries `step` apart: four independent loads in flight per trip
-        auto min_cell = [&](const int2 *__restrict__ tb, int cnt, int step) {
+        auto min_cell = [&](gptr<i2v> tb, int cnt, int step) {
             int cm = 0x7fffffff, o = 0;
             for (; o + 4 <= cnt; o += 4) {
                 const int x0 = tb[o * step].x, x1 = tb[(o + 1) * step].x, x2 = tb[(o + 2) * step].x, x3 = tb[(o + 3) * step].x;
@@ -378,9 +402,14 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             }
         };
         auto cterm = [&](int slot, int o0, int o1) -> float {
-            const auto &t = N->ot[slot];
-            if (t.lds_off >= 0) return s_ot[t.lds_off + o0 * t.c0 + o1 * t.c1];
-            return static_cast<const float *>(t.data)[coff[slot - CL0] + o0 * t.c0 + o1 * t.c1];
+            if constexpr (HIER) {      // modes 1-3 are only chosen when the level cost terms are control-only: LDS
+                const int i = slot - CL0;
+                return s_ot[cl_off[i] + o0 * cl_c0[i] + o1 * cl_c1[i]];
+            } else {
+                const auto &t = N->ot[slot];
+                if (t.lds_off >= 0) return s_ot[t.lds_off + o0 * t.c0 + o1 * t.c1];
+                return as_global<float>(t.data)[coff[slot - CL0] + o0 * t.c0 + o1 * t.c1];
+            }
         };
 
         int uo = 0;
@@ -389,7 +418,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
             for (int a = 0; a < D - 1; ++a) {
                 if (a_lvl[a] == 0) {
-                    const int2 e = atab[a][aoff[a] + o0 * a_c0[a]];
+                    const i2v e = atab[a][aoff[a] + o0 * a_c0[a]];
                     cell[a] = e.x;
                     tw[a] = __int_as_float(e.y);
                 }
@@ -404,7 +433,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
                 for (int a = 0; a < D - 1; ++a) {
                     if (a_lvl[a] == 1) {
-                        const int2 e = atab[a][aoff[a] + o0 * a_c0[a] + o1 * a_c1[a]];
+                        const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + o1 * a_c1[a]];
                         cell[a] = e.x;
                         tw[a] = __int_as_float(e.y);
                     }
@@ -466,9 +495,9 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             }
             // modes 1-3: the level-1 axis' (cell, t) entry and the level-1 cost term are fetched ONE STEP AHEAD
             // (a dependent global load per o1 step would otherwise stall every step)
-            const int2 *tb1 = atab[AX_B] + aoff[AX_B] + o0 * a_c0[AX_B];
+            gptr<i2v> tb1 = atab[AX_B] + aoff[AX_B] + o0 * a_c0[AX_B];
             const int tb1_step = a_c1[AX_B];
-            int2 e_nx = {0, 0};
+            i2v e_nx = {0, 0};
             float g_nx = 0.f;
             auto level1_cost = [&](int o1) -> float {
                 if (!cl1_present) return go0;
