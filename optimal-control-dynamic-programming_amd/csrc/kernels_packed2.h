@@ -599,6 +599,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     const unsigned int rest = PU >> p;
                     const int pstop = rest ? p + __builtin_ctz(rest) : npairs;   // next pair with a crossing
                     const f2 e0v = {e0, e0}, dev = {de, de};
+#pragma unroll 2
                     for (; p < pstop; ++p) {
                         const f2 tot = (go2 + r2) + __builtin_elementwise_fma(t, dev, e0v);
                         t = my_t[(p + 1) * 256];                     // next pair's rows (row npairs is padding)
