@@ -152,13 +152,14 @@ def main():
     alg_bytes = (2 * spec.j_dtype.itemsize + 4) * states_per_rank   # read J_{k+1}, write J_k + int32 argmin
     tflops = alg_flops / (launch_ms * 1e-3) / 1e12
     gbs = alg_bytes / (launch_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = valu_util = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"                    # written from rocprofv3 --pmc passes
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            pj = json.loads(pmc.read_text())
+            traffic, valu_util = pj.get("hbm_bytes_per_launch"), pj.get("valu_busy_frac")
         except Exception:
-            traffic = None
+            traffic = valu_util = None
     J_final = sw.owned_J()
     cs = J_final.double().sum().reshape(1)
     if world > 1:
@@ -179,10 +180,12 @@ def main():
         "roofline": {"bound": "mfma", "pipe": "valu (v_pk_fma_f32; no MFMA applies: interpolation is a gather, K = D <= 6)",
                      "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                     "kernel": {4: "k_backup_packed2<3>", 2: "k_backup_packed<3>", 1: "k_backup_nested<float,3,true>"}.get(info["kernel_variant"], "k_backup_generic<float,3>"),
-                     "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(D),
+                     "kernel": {4: "k_backup_packed2<float, 3, 1>", 2: "k_backup_packed<3>", 1: "k_backup_nested<float,3,true>"}.get(info["kernel_variant"], "k_backup_generic<float,3>"),
+                     "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(D), "valu_issue_util_pmc": valu_util,
                      "note": "compute roofline binds (SURVEY 8d), HBM does not; peak = dense f32 MFMA peak = fp32 vector peak "
-                             "(157.3 TFLOP/s); achieved = ALGORITHMIC flops (41 per backup) / launch time",
+                             "(157.3 TFLOP/s); achieved = ALGORITHMIC flops (41 per backup, SURVEY 8d) / launch time.  The kernel EXECUTES "
+                             "fewer flops than that (axis-0/axis-1 lerps are shared between controls), so frac can exceed 1; "
+                             "valu_issue_util_pmc (SQ_INSTS_VALU x 4 / SIMD-cycles, profiles/pmc_traffic.json) is the executed-instruction view",
                      "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                              "alg_bytes_per_state": 2 * spec.j_dtype.itemsize + 4}},
         "checksum_sum_J": checksum,

@@ -47,14 +47,14 @@ out, v = solve_timed(spec, 19)
 add("Solver_attitude.run 11^3x10^3 x 27, 19 stages, f32 (reference axis order)", spec.nS * 27 * 19, out["sweep_ms"], v)
 pspec, _ = hjbdp.permute_state_axes(spec, sa.AXIS_ORDER)
 out, v = solve_timed(pspec, 19)
-add("Solver_attitude.run, same, w3 relabelled last", spec.nS * 27 * 19, out["sweep_ms"], v)
+add("Solver_attitude.run, same, axes relabelled (angles first, w3 last)", spec.nS * 27 * 19, out["sweep_ms"], v)
 pa = hjbdp.Solver_pos_att()
 sx, sv, st, sw = pa.grids()
 spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
 out, v = solve_timed(spec, 1999, monitor_period=50, monitor_tol=1e-2)
 add("Solver_pos_att channel 30x30x20x15 x 9, <=1999 stages (monitor), f32", spec.nS * 9 * out["stages_done"],
     out["sweep_ms"], v, "stopped after %d stages" % out["stages_done"])
-# 6-D north-star figure: C3's attitude model on a 24^6 grid x 11^3 torques, w3 relabelled last
+# 6-D north-star figure: the attitude model on a 24^6 grid x 11^3 torques, tabulated next angles
 import os
 if os.environ.get("HJB_MEASURE_6D", "1") == "1":
     sa6 = hjbdp.Solver_attitude(n_mesh_w=24, n_mesh_q=24)

@@ -1,0 +1,30 @@
+"""Time one pos-att channel (Solver_pos_att) per stage kernel variant.
+usage: python tools/time_posatt.py [n=0 (reference grid 30,30,20,15) | n (n^4 grid)] [stages] [variants...]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
+import hjbdp
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+stages = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+variants = [int(v) for v in sys.argv[3:]] or [5, 0]
+pa = hjbdp.Solver_pos_att()
+pa.cost_mode = "terms"
+if n:
+    pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = n
+sx, sv, st, sw = pa.grids()
+spec0, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1,
+                                 pa.Qw1, pa.R1, pa.J2)
+for label, spec in (("(x,v,theta,w)", spec0),):
+    for v in variants:
+        try:
+            with hjbdp.Backup(spec, variant=v) as bk:
+                info = bk.info()
+                bk.solve(2)
+                out = bk.solve(stages)
+        except hjbdp.HjbError as e:
+            print(label, "variant", v, "refused:", e)
+            continue
+        b = spec.nS * spec.nU * out["stages_done"]
+        print("%s variant %d: %.3f ms/stage, %.3e backups/s (halo %d/%d)" % (
+            label, v, out["sweep_ms"] / out["stages_done"], b / (out["sweep_ms"] * 1e-3), info["halo_needed_lo"], info["halo_needed_hi"]), flush=True)
