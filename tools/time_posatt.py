@@ -7,7 +7,7 @@ import hjbdp
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 stages = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-variants = [int(v) for v in sys.argv[3:]] or [5, 0]
+variants = [int(v) for v in sys.argv[3:]] or [5]
 pa = hjbdp.Solver_pos_att()
 pa.cost_mode = "terms"
 if n:
