@@ -196,6 +196,39 @@ def test_packed_variant_slab(env):
         assert np.array_equal(io, iw.reshape(72, 14, order="F")[:, b:e].reshape(-1, order="F"))
 
 
+def test_packed_modes_2_and_3_slab(env):
+    """Slabs (multi-GPU decomposition of the last axis) through variant 4's state-window modes: a 5-D nested
+    problem (mode 2) and the attitude problem with the on-the-fly quaternion model (mode 3); the owned planes of
+    the slab must equal the same planes of the whole-grid oracle result."""
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    spec = nested_problem(91, (4, 3, 5, 4, 12), (3, 4, 3), dtype=np.float32, monotone="inc", spread=0.15)
+    sa = hjbdp.Solver_attitude(n_mesh_w=9, n_mesh_q=4)
+    sa.U_vector = np.linspace(-0.11, 0.11, 5)
+    for sp in (spec, sa.build_spec_model()):
+        nl = sp.n[-1]
+        inner = sp.nS // nl
+        term = random_terminal(sp, 7)
+        Jw, iw = c_oracle.backup_stage(_abi, sp, term)
+        T2 = term.reshape(inner, nl, order="F")
+        with hjbdp.Backup(sp) as bk:
+            need = bk.info()
+            assert need["kernel_variant"] == 4
+        b, e = 3, 7
+        lo, hi = min(need["halo_needed_lo"], b), min(need["halo_needed_hi"], nl - e)
+        with hjbdp.Backup(sp, slab=(b, e, lo, hi)) as bk:
+            assert bk.info()["kernel_variant"] == 4
+            Jo, io = bk.backup_stage(np.asfortranarray(T2[:, b - lo:e + hi]).reshape(-1, order="F"))
+        assert np.array_equal(Jo.reshape(inner, -1, order="F")[:, lo:lo + e - b], Jw.reshape(inner, nl, order="F")[:, b:e])
+        assert np.array_equal(io, iw.reshape(inner, nl, order="F")[:, b:e].reshape(-1, order="F"))
+        # too small a halo is reported, never silently wrong
+        if lo > 0:
+            with hjbdp.Backup(sp, slab=(b, e, lo - 1, hi)) as bk:
+                with pytest.raises(hjbdp.HjbError) as ei:
+                    bk.backup_stage(np.asfortranarray(T2[:, b - lo + 1:e + hi]).reshape(-1, order="F"))
+                assert ei.value.status == _abi.HJB_E_HALO
+
+
 EDGE = [
     # (n, m, dtype): minimum axis sizes, single-control dims, inner dim of 1/2/odd size, nU == 64
     ((2, 2), (1,), np.float32),
