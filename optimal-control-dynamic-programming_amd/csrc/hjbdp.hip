@@ -22,6 +22,7 @@
 #include "kernels_ctrlsplit.h"
 #include "kernels_lookup.h"
 #include "kernels_tabled.h"
+#include "kernels_rowwise.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -61,6 +62,8 @@ struct Handle {
     bool use_graph = true;
     size_t packed_lds = 0;
     size_t packed2_lds = 0;       // variant 4 (two controls per packed op)
+    bool row_ok = false;          // variant 6 (one wave per grid row) applies
+    bool row_auto = false;        // ... and is chosen automatically
     int packed_pre = 0;           // variant 4 contraction mode (kernels_packed2.h MODE): 0 plain, 1 C2 shape, 2 state-only axes first
     size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
     bool tabled_ok = false;       // variant 5: per-axis (cell, t) tables for every axis (built on first use)
@@ -527,6 +530,13 @@ int build(Handle *h, const hjb_problem *p) {
         // worth it only when the tables are small next to the per-stage work (nS * nU backups)
         const bool small = total <= ((size_t)512 << 20) || (double)total <= 0.5 * (double)h->n_owned * (double)h->nU;
         h->tabled_ok = fits && small && total <= ((size_t)16 << 30);
+        // variant 6: no axis other than axis 0 may depend on state dim 0 (its cells are then uniform along a row)
+        bool rw = h->tabled_ok && D >= 2 && !p->model;
+        for (int a = 1; a < D; ++a) rw = rw && (h->dom_mask[a] & 1u) == 0;
+        h->row_ok = rw;
+        // worth it when a 64-lane wave is mostly filled by a row and the grid is large (C4: +10 %); small grids
+        // have too few rows to fill the chip with one wave per row
+        h->row_auto = rw && p->n[0] >= 96 && h->n_owned >= ((int64_t)1 << 22);
     }
     if (p->model) {
         if (!(h->packed_mode && h->packed_pre == 3))
@@ -594,17 +604,22 @@ void choose_launch(Handle *h) {
     // few states x many controls (Kirk): one wave per state, controls across lanes
     const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
     h->variant = h->forced_variant >= 0 ? h->forced_variant
-                                        : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : (h->tabled_ok ? 5 : 0))));
+                                        : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0)))));
     if (h->hp.model) h->variant = 4;
     if (h->dtype == HJB_F16S && h->variant >= 1 && h->variant <= 3)     // float16 J storage: variants 0, 4, 5 only
-        h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->tabled_ok ? 5 : 0);
-    // build variant 5's tables now (never inside a launch: launches may be under graph capture)
-    if (h->variant == 5 && ensure_tabled(h) != HJB_OK) h->variant = 0;
+        h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0));
+    // build the variant 5/6 tables now (never inside a launch: launches may be under graph capture)
+    if ((h->variant == 5 || h->variant == 6) && ensure_tabled(h) != HJB_OK) h->variant = 0;
     h->block = 256;
     h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
     const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass (variant 4: 256)
     int64_t blocks = (h->n_owned + per_block - 1) / per_block;
     h->grid = (int)std::min<int64_t>(blocks, h->variant == 3 ? 1024 : 256 * 16);
+    if (h->variant == 6) {       // one wave per (64-state chunk of a) grid row, four waves per workgroup
+        const int64_t n0 = h->hp.n[0];
+        const int64_t items = (h->n_owned / n0) * ((n0 + 63) / 64);
+        h->grid = (int)std::min<int64_t>((items + 3) / 4, 256 * 16);
+    }
     if (h->grid < 1) h->grid = 1;
 }
 
@@ -613,6 +628,19 @@ int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t
     constexpr bool same = std::is_same<T, TJ>::value;   // variants 1-3 exist for J stored in the arithmetic type only
     const int D = h->hp.D;
     dim3 g(h->grid), b(h->block);
+    if (h->variant == 6) {
+        if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 6 tables missing");
+        switch (D) {
+            case 2: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 2>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 3: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 3>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 4: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 4>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 5: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 5>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            case 6: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 6>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            default: return fail(h, HJB_E_UNSUPPORTED, "variant 6 with D=%d", D);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return HJB_OK;
+    }
     if (h->variant == 5) {
         if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 5 tables missing");
         switch (D) {
@@ -974,7 +1002,10 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     Handle *h = (Handle *)hh;
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) {
-        if (value < -1 || value > 5) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value < -1 || value > 6) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value == 6 && !h->row_ok)
+            return fail(h, HJB_E_UNSUPPORTED, "variant 6 (one wave per grid row) needs D >= 2, per-axis tables that fit, and "
+                        "no axis other than axis 0 depending on state dim 0");
         if (h->hp.model && value != -1 && value != 4)
             return fail(h, HJB_E_UNSUPPORTED, "a problem with a state model runs on variant 4 only");
         if (value == 5 && !h->tabled_ok)

@@ -131,6 +131,80 @@ def test_nested_variant_bit_exact(env, n, m, dtype, nonuniform, mixed):
         assert np.array_equal(o["idx_stages"], ref["idx_stages"])
 
 
+ROWWISE = [
+    # n, m, dtype, nonuniform, spread
+    ((70, 8), (3,), np.float64, False, 0.3),
+    ((130, 5, 4), (5,), np.float32, True, 0.4),
+    ((9, 8, 7), (3, 2), np.float32, False, 0.2),
+    ((66, 5, 4, 5), (9,), np.float32, True, 0.5),
+    ((6, 5, 4, 5), (3, 4), np.float64, False, 0.3),
+    ((4, 3, 4, 3, 5), (2, 3, 2), np.float32, False, 0.3),
+    ((5, 3, 4, 3, 3, 4), (4,), np.float32, True, 0.2),
+]
+
+
+def _row_problem(n, m, dtype, nonuniform, spread):
+    """nested_problem with the coupling to state dim 0 removed from axes >= 1 (variant 6's applicability rule)."""
+    import hjbdp
+    from problems import nested_problem
+    spec = nested_problem(300 + len(n), n, m, dtype=dtype, nonuniform=nonuniform, spread=spread)
+    nxt = [spec.next_terms[0]] + [[t for t in spec.next_terms[a] if 0 not in t.dims] for a in range(1, spec.D)]
+    return hjbdp.ProblemSpec(spec.knots, spec.m, nxt, spec.cost_terms, dtype=dtype, index_base=1)
+
+
+@pytest.mark.parametrize("n,m,dtype,nonuniform,spread", ROWWISE)
+def test_rowwise_variant_bit_exact(env, n, m, dtype, nonuniform, spread):
+    """Variant 6 (one wavefront per grid row, scalar cells/weights for axes 1..D-1)."""
+    hjbdp, _abi, c_oracle = env
+    from problems import random_terminal
+    spec = _row_problem(n, m, dtype, nonuniform, spread)
+    term = random_terminal(spec, 5)
+    with hjbdp.Backup(spec, variant=6) as bk:
+        assert bk.info()["kernel_variant"] == 6
+        out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
+    ref = c_oracle.sweep(_abi, spec, 3, terminal=term, keep_J=True, keep_idx=True)
+    assert np.array_equal(out["J_stages"], ref["J_stages"])
+    assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+
+
+def test_rowwise_variant_pos_att_slab_and_f16(env):
+    """pos-att is the shape variant 6 exists for (chosen automatically at C4 size, see test_gpu_solvers); here
+    forced on a small grid: whole grid, a slab with halos, float16 J storage; refused for Kirk (x2+ depends on x1)."""
+    hjbdp, _abi, c_oracle = env
+    from problems import random_terminal
+    pa = hjbdp.Solver_pos_att()
+    pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 70, 6, 5, 10
+    sx, sv, st, sw = pa.grids()
+    spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                    pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    with hjbdp.Backup(_kirk(hjbdp, "double", 5, 8, 9).build_spec()) as bk:
+        with pytest.raises(hjbdp.HjbError):
+            bk.set_option("variant", 6)
+    term = random_terminal(spec, 3)
+    ref = c_oracle.sweep(_abi, spec, 4, terminal=term)
+    with hjbdp.Backup(spec, variant=6) as bk:
+        need = bk.info()
+        assert need["kernel_variant"] == 6
+        out = bk.solve(4, terminal=term)
+    assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+    b, e = 3, 7
+    hl, hh = min(need["halo_needed_lo"], b), min(need["halo_needed_hi"], spec.n[-1] - e)
+    inner = spec.nS // spec.n[-1]
+    sub = np.asfortranarray(term.reshape(inner, -1, order="F")[:, b - hl:e + hh]).reshape(-1, order="F")
+    Jr, ir = c_oracle.backup_stage(_abi, spec, sub, slab=(b, e, hl, hh))
+    with hjbdp.Backup(spec, slab=(b, e, hl, hh), variant=6) as bk:
+        assert bk.info()["kernel_variant"] == 6
+        Jg, ig = bk.backup_stage(sub)
+    assert np.array_equal(Jg, Jr) and np.array_equal(ig, ir)
+    hspec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=1,
+                              j_storage=np.float16)
+    with hjbdp.Backup(hspec, variant=6) as bk:
+        assert bk.info()["kernel_variant"] == 6
+        oh = bk.solve(4)
+    rh = c_oracle.sweep(_abi, hspec, 4)
+    assert np.array_equal(oh["J"], rh["J"]) and np.array_equal(oh["idx"], rh["idx"])
+
+
 PACKED = [
     ((9, 8), (3,), False, "inc"),
     ((40, 37), (7,), True, "dec"),                 # > 512 states, odd tail
@@ -251,11 +325,11 @@ def test_edge_shapes_all_variants(env, n, m, dtype):
     term = random_terminal(spec, 1)
     ref = c_oracle.sweep(_abi, spec, 3, terminal=term)
     seen = set()
-    for v in (None, 0, 1, 2, 3, 4, 5):
+    for v in (None, 0, 1, 2, 3, 4, 5, 6):
         try:
             bk = hjbdp.Backup(spec, variant=v)
         except hjbdp.HjbError as e:
-            assert e.status == _abi.HJB_E_UNSUPPORTED and v in (1, 2, 4)
+            assert e.status == _abi.HJB_E_UNSUPPORTED and v in (1, 2, 4, 6)
             continue
         with bk:
             seen.add(bk.info()["kernel_variant"])

@@ -246,6 +246,7 @@ def test_c4_full_size_plane_vs_oracle(env):
     term = (inner[:, None] * (1.0 + 10.0 * sw[None, :] ** 2).astype(np.float32)).astype(np.float32)   # [120^3, 120]
     with hjbdp.Backup(spec) as bk:
         need = bk.info()
+        assert need["kernel_variant"] == 6              # one wave per grid row (long rows, large grid)
         J, idx = bk.backup_stage(term.reshape(-1, order="F"))
     hl, hh = need["halo_needed_lo"], need["halo_needed_hi"]
     assert 6 <= hl <= 9 and 6 <= hh <= 9            # w moves up to ~7.5 cells per stage on this fine grid
