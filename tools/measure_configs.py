@@ -76,6 +76,10 @@ sx, sv, st, sw = pa.grids()
 spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
 out, v = solve_timed(spec, 5)
 add("C4 pos-att 120^4 x 9, 5 stages, f32", spec.nS * 9 * 5, out["sweep_ms"], v)
+spec16 = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=1,
+                           j_storage=np.float16)
+out, v = solve_timed(spec16, 5)
+add("C5 = C4 with float16 cost-to-go storage, 5 stages", spec.nS * 9 * 5, out["sweep_ms"], v)
 print("| config | backups | sweep ms | backups/s | kernel variant | note |")
 print("|---|---|---|---|---|---|")
 for r in rows:
