@@ -98,7 +98,27 @@ class Dynamic_Solver:
         self.u_star[:, :, : n_st] = U_mesh[idx - 1].astype(dt)               # u_star(:,:,k_s) = U_mesh(u_star_idx)
         self.u_star_idx = idx[:, :, 0].copy()      # value left in obj.u_star_idx after the loop (k_s = 1)
         self.F_values = self.J_star[:, :, 0].copy()
+        self._debug_taps(spec, n_st)
         return self
+
+    def _debug_taps(self, spec, n_st):
+        """Dynamic_Solver.m:212-219 (`checkstagesXJF`, default 1): per stage k the reference copies the fixed
+        sub-block (50:55, 52:57, 105) of J_current_state, X_next_M1 and X_next_M2 - all three are stage-invariant
+        tables, so every plane holds the same 6x6 block.  Evaluated here from the broadcast terms in MATLAB's
+        left-to-right order.  MATLAB raises an index error when dx < 57 or du < 105; the mirror leaves the taps
+        None instead (the fixture revision test/test_coder.m has no taps and runs at dx = 35)."""
+        self.J_current_state_check = self.X_next_M1_check = self.X_next_M2_check = None
+        if not self.checkstagesXJF or self.dx < 57 or self.du < 105:
+            return
+        i, j, u = slice(49, 55), slice(51, 57), 104
+
+        def block(terms):
+            t0, t1, t2 = (t.data for t in terms)
+            return ((t0[i, None] + t1[None, j]).astype(spec.dtype) + t2[u]).astype(spec.dtype)
+        rep = lambda b: np.repeat(b[:, :, None], n_st, axis=2)
+        self.J_current_state_check = rep(block(spec.cost_terms))
+        self.X_next_M1_check = rep(block(spec.next_terms[0]))
+        self.X_next_M2_check = rep(block(spec.next_terms[1]))
 
     # ------------------------------------------------------------------
     def a_D(self, X1, X2, Ui):
