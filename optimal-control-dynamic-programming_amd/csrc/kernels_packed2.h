@@ -332,6 +332,18 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         unsigned int PU = 0u;                 // bit p: some lane changes cell at control 2p or 2p+1
         for (int p = 0; p < npairs; ++p)
             if ((U >> (2 * p)) & 3u) PU |= 1u << p;
+        // UA bit j: EVERY lane of the wave makes its first cell change at control j (e.g. C2: the whole wave
+        // crosses where the control changes sign) - then the switch to the prefetched second cell is scalar
+        // control flow, no per-lane test.  UX bit j: some lane changes cell at j in any other way.
+        unsigned int UA = 0u;
+        {
+            const unsigned int cm_first = cm & (0u - cm);
+            const unsigned long long all = __ballot(1);
+            for (int j = 1; j < m_in; ++j)
+                if ((U >> j) & 1u)
+                    if (__ballot((cm_first >> j) & 1u) == all) UA |= 1u << j;
+        }
+        const unsigned int UX = U & ~UA;
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
         // smallest cell over `cnt` table entries `step` apart: four independent loads in flight per trip
@@ -610,9 +622,18 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     }
                     if (p < npairs) {                                // a pair in which some lane changes cell
                         const int jb = 2 * p;
-                        if ((cm >> jb) & 1u) crossed(jb, e0, de);
-                        float e0y = e0, dey = de;
-                        if ((cm >> (jb + 1)) & 1u) crossed(jb + 1, e0y, dey);
+                        float e0y, dey;
+                        if (((UX >> jb) & 3u) == 0u) {               // wave-uniform first crossings only: scalar
+                            if ((UA >> jb) & 1u) { e0 = e0b; de = deb; }
+                            e0y = e0;
+                            dey = de;
+                            if ((UA >> (jb + 1)) & 1u) { e0y = e0b; dey = deb; }
+                        } else {
+                            if ((cm >> jb) & 1u) crossed(jb, e0, de);
+                            e0y = e0;
+                            dey = de;
+                            if ((cm >> (jb + 1)) & 1u) crossed(jb + 1, e0y, dey);
+                        }
                         const f2 tot = (go2 + r2) + __builtin_elementwise_fma(t, (f2){de, dey}, (f2){e0, e0y});
                         e0 = e0y;
                         de = dey;
