@@ -399,7 +399,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             }
         }
         float best = 0.f;
-        int best_uo = 0, best_j = 0;
+        int best_uo = 0, best_ip = 0;
 
         // (E0, dE) of one last-axis cell at element offset `off`: the rare synchronous path
         auto cell_pair = [&](int base, int lc, const float (&twc)[DM], float &e0, float &de) {
@@ -645,30 +645,10 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         ++p;
                     }
                 }
-                // which half of pair ip holds the minimum?  Re-evaluate its FIRST control exactly as the loop
-                // did; if that reproduces ibest the first control wins (first-minimum rule), else the second.
-                int ij;
-                {
-                    const int j0 = 2 * ip;
-                    float xe0 = e0a, xde = dea;
-                    if (cm != 0u && (cm & ((2u << j0) - 1u)) != 0u) {        // some crossing at a control <= j0
-                        const unsigned int upto = cm & ((2u << j0) - 1u);
-                        if ((upto & (upto - 1u)) == 0u) {                     // exactly one: the prefetched cell
-                            xe0 = e0b;
-                            xde = deb;
-                        } else {                                              // several: general path at the last one
-                            const int jl = 31 - __builtin_clz(upto);
-                            crossed(jl, xe0, xde);
-                        }
-                    }
-                    const float tx = my_t[ip * 256].x;
-                    const float tot0 = (go + s_r2[ip].x) + __builtin_fmaf(tx, xde, xe0);
-                    ij = (tot0 == ibest) ? j0 : j0 + 1;
-                }
-                if (uo == 0 || ibest < best) {
+                if (uo == 0 || ibest < best) {                       // which half of the pair: resolved after the sweep
                     best = ibest;
                     best_uo = uo;
-                    best_j = ij;
+                    best_ip = ip;
                 }
                 if (has_next) {
                     base = base_n;
@@ -678,6 +658,74 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 }
             }  // o1
         }      // o0
+        // ---- which control of the winning pair?  Re-evaluate the pair's FIRST control exactly as the sweep did
+        // (same cells, same weights, same lerp order, same sums): if that reproduces `best`, the first control
+        // wins (first-minimum rule), else the second.  Once per state instead of once per (o0, o1) step.
+        int best_j;
+        {
+            const int o0 = best_uo / m_o1, o1 = best_uo - o0 * m_o1;
+            int ob = 0;
+#pragma unroll
+            for (int a = 0; a < D - 1; ++a) {
+                if (a_lvl[a] >= 0) {
+                    const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + (a_lvl[a] == 1 ? o1 * a_c1[a] : 0)];
+                    cell[a] = e.x;
+                    tw[a] = __int_as_float(e.y);
+                }
+                ob += js[a] * cell[a];
+            }
+            float g = gpre;
+            if (cl0_present) {
+                const float x = cterm(CL0, o0, 0);
+                g = cl0_first ? x : g + x;
+            }
+            if (cl1_present) {
+                const float x = cterm(CL1, o0, o1);
+                g = cl1_first ? x : g + x;
+            }
+            const int j0 = 2 * best_ip;
+            const unsigned int upto = cm & ((2u << j0) - 1u);        // cell changes at controls <= j0
+            int lc = lc0;
+            if (upto != 0u) {
+                if ((upto & (upto - 1u)) == 0u) {
+                    lc = lc1;                                        // exactly one: the second prefetched cell
+                } else {                                             // several: the cell entered at the last one
+                    const int jl = 31 - __builtin_clz(upto);
+                    const float q = ql + (b_pure ? s_b[jl] : b_data[boff + jl * b_stride]);
+                    lc = find_cell<float>(s_k, nl, q, l_uniform, l_x0, l_invh) - plane0;
+                    if (lc < 0 || lc + 1 >= nplanes) {
+                        *P->status = 1;
+                        lc = lc < 0 ? 0 : nplanes - 2;
+                    }
+                }
+            }
+            float xe0, xde;
+            bool from_window = false;
+            if constexpr (PRE) {                                     // the state's LDS window usually covers it
+                const int ra = cell[AX_A] - cAmin, rb = cell[AX_B] - cBmin;
+                if ((ra == 0 || ra == 1) && (rb == 0 || rb == 1) && (lc == lc0 || lc == lc1)) {
+                    from_window = true;
+                    const int q0 = lc == lc0 ? 0 : 2;
+                    float X[2];
+#pragma unroll
+                    for (int dq = 0; dq < 2; ++dq) {
+                        float Fr[2];
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const float w0 = my_w[((ra * 3 + rb + db) * 4 + q0 + dq) * 256];
+                            const float w1 = my_w[(((ra + 1) * 3 + rb + db) * 4 + q0 + dq) * 256];
+                            Fr[db] = __builtin_fmaf(tw[AX_A], w1 - w0, w0);
+                        }
+                        X[dq] = __builtin_fmaf(tw[AX_B], Fr[1] - Fr[0], Fr[0]);
+                    }
+                    xe0 = X[0];
+                    xde = X[1] - X[0];
+                }
+            }
+            if (!from_window) cell_pair(ob, lc, tw, xe0, xde);
+            const float tot0 = (g + s_r2[best_ip].x) + __builtin_fmaf(my_t[best_ip * 256].x, xde, xe0);
+            best_j = (tot0 == best) ? j0 : j0 + 1;
+        }
         if (valid) {
             int label;
             if (C == 1) {
