@@ -152,7 +152,12 @@ const char *hjb_status_string(int32_t status);
 /* number of visible HIP devices, or 0 */
 int32_t hjb_device_count(void);
 
-/* Validate the problem, copy tables and knots to `device`, pick a kernel. */
+/* Threading: a handle is not thread-safe - drive each handle from one host thread.  DIFFERENT handles may be
+ * driven from different threads at the same time (each hjb_solve runs on its handle's own HIP stream): this is how
+ * the independent channels of the spacecraft solvers run side by side.  The library serialises only what HIP
+ * cannot overlap safely (stream capture against allocation / synchronous copies).
+ *
+ * Validate the problem, copy tables and knots to `device`, pick a kernel. */
 int32_t hjb_create(const hjb_problem *problem, int32_t device, hjb_handle *out);
 int32_t hjb_destroy(hjb_handle h);
 /* text of the last error on this handle (h may be NULL: last create error) */

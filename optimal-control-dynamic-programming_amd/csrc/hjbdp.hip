@@ -11,6 +11,8 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "../../include/hjbdp.h"
@@ -32,6 +34,11 @@ namespace {
 constexpr int kGraphStages = 32;   // even: a replay starts and ends in dJ[0]
 
 thread_local std::string g_last_error;
+// Handles may be driven from different host threads (one thread per handle).  HIP stream capture is fragile
+// against "unsafe" calls made elsewhere in the process while it records (device-wide synchronisation, synchronous
+// copies, allocation): a capture takes this lock exclusively, every such call takes it shared.  Kernel launches,
+// graph launches and waits on a handle's own stream need no lock and overlap freely.
+static std::shared_mutex g_capture_mu;
 
 struct Handle {
     hjb_problem prob{};  // scalar fields only (pointers are not kept)
@@ -951,6 +958,7 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
         delete h;
         return st;
     }
+    std::shared_lock<std::shared_mutex> create_lk(g_capture_mu);
     int st = p->dtype != HJB_F64 ? build<float>(h, p) : build<double>(h, p);
     if (st) {
         g_last_error = h->err;
@@ -972,6 +980,7 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
 int32_t hjb_destroy(hjb_handle hh) {
     Handle *h = (Handle *)hh;
     if (!h) return HJB_OK;
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
@@ -1001,6 +1010,7 @@ int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
 int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     Handle *h = (Handle *)hh;
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);     // may build tables (allocation, device sync)
     if (!strcmp(key, "variant")) {
         if (value < -1 || value > 6) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
         if (value == 6 && !h->row_ok)
@@ -1050,6 +1060,7 @@ int32_t hjb_check_device_status(hjb_handle hh, void *stream) {
 int32_t hjb_backup_stage(hjb_handle hh, const void *J_next, void *J_out, int32_t *idx_out) {
     Handle *h = (Handle *)hh;
     if (!h || !J_next || !J_out) return fail(h, HJB_E_INVALID, "null argument");
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
     HIP_TRY(h, hipSetDevice(h->device));
     int st = ensure_work(h);
     if (st) return st;
@@ -1073,6 +1084,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     if (h->j_elems != h->n_owned)
         return fail(h, HJB_E_UNSUPPORTED, "hjb_solve runs whole grids; drive slabs with hjb_backup_stage_device + a halo exchange");
     HIP_TRY(h, hipSetDevice(h->device));
+    std::shared_lock<std::shared_mutex> unsafe_lk(g_capture_mu);    // allocation, synchronous copies, device sync
     int st = ensure_work(h);
     if (st) return st;
     const int64_t nS = h->n_owned;
@@ -1114,7 +1126,9 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     SOLVE_TRY(hipDeviceSynchronize());   // the sweep runs on the handle's own stream from here
     // launch-bound sweeps: replay kGraphStages ping-pong launches per hipGraphLaunch
     const bool graph_ok = h->use_graph && !dJst && !dIst && o->n_stages >= 2 * kGraphStages;
+    unsafe_lk.unlock();
     if (graph_ok && !h->gexec) {
+        std::unique_lock<std::shared_mutex> capture_lk(g_capture_mu);
         hipGraph_t graph = nullptr;
         SOLVE_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         int cst = HJB_OK;
@@ -1174,8 +1188,11 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
             st = launch_monitor_sums(h->dtype, cur, cur_idx, nS, h->d_partials, h->d_sums, stream);
             if (st != HJB_OK) { cleanup(); return fail(h, HJB_E_DEVICE, "monitor reduction launch failed"); }
             double sums[2];
-            SOLVE_TRY(hipMemcpyAsync(sums, h->d_sums, sizeof sums, hipMemcpyDeviceToHost, stream));
-            SOLVE_TRY(hipStreamSynchronize(stream));
+            {
+                std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+                SOLVE_TRY(hipMemcpyAsync(sums, h->d_sums, sizeof sums, hipMemcpyDeviceToHost, stream));
+                SOLVE_TRY(hipStreamSynchronize(stream));
+            }
             e = sums[0] - fprev;
             e2 = sums[1] - iprev;
             fprev = sums[0];
@@ -1196,6 +1213,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     SOLVE_TRY(hipEventElapsedTime(&ms, ev0, ev1));
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
+    unsafe_lk.lock();
     st = check_status(h, stream);
     if (st) { cleanup(); return st; }
     if (o->J_final) SOLVE_TRY(hipMemcpy(o->J_final, cur, jb, hipMemcpyDeviceToHost));
@@ -1227,6 +1245,7 @@ int32_t hjb_policy_lookup(int32_t device, int32_t dtype, int32_t D, const int32_
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, HJB_E_DEVICE, "no HIP device visible (libhjbdp has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(nullptr, HJB_E_INVALID, "device %d", device);
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hipSetDevice failed");
     if (nq == 0) return HJB_OK;
     return dtype == HJB_F32 ? policy_lookup_t<float>(D, n, knots, values, nq, queries, method, out)

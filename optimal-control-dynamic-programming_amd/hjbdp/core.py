@@ -201,3 +201,28 @@ class Backup:
         return {"J": J, "idx": idx, "J_stages": Js, "idx_stages": Is, "stages_done": res.stages_done,
                 "stopped_early": bool(res.stopped_early), "sweep_ms": res.sweep_ms, "last_e": res.last_e,
                 "last_e2": res.last_e2}
+
+
+def solve_many(specs, n_stages, device=0, **solve_kw):
+    """Independent sweeps (the three axis channels of Solver_position / Solver_attitude.simplified_run, the four
+    runs of Solver_pos_att.simplified_run) in flight together: one handle and one host thread per sweep, each on
+    its handle's own HIP stream.  A channel's stage kernel fills a few percent of the chip and the sweep is a
+    chain of thousands of dependent launches, so running channels side by side costs nothing and divides the
+    wall time.  `solve_kw` values may be lists (one entry per spec).  Returns (outs, wall_ms, variants)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        kw = {k: (v[i] if isinstance(v, (list, tuple)) else v) for k, v in solve_kw.items()}
+        with Backup(specs[i], device=device) as bk:
+            out = bk.solve(n_stages, **kw)
+            return out, bk.info()["kernel_variant"]
+    t0 = time.perf_counter()
+    if len(specs) == 1:
+        res = [one(0)]
+    else:
+        with ThreadPoolExecutor(max_workers=len(specs)) as ex:
+            res = list(ex.map(one, range(len(specs))))
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    return [r[0] for r in res], wall_ms, [r[1] for r in res]
+

@@ -17,7 +17,7 @@ import math
 
 import numpy as np
 
-from .core import Backup
+from .core import Backup, solve_many
 from .matlab_compat import deg2rad, linspace
 from .problem import ProblemSpec, Term
 from .solver_position import NearestPolicy
@@ -85,10 +85,11 @@ class Solver_attitude:
     def simplified_run(self, n_stages=None):
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
         self.F_values, self.U_idx, self.sweep_ms = [None] * 3, [None] * 3, [None] * 3
+        built = [self.build_spec_simplified(ch) for ch in range(3)]
+        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device)   # channels side by side
         for ch in range(3):
-            spec, s_w, s_t = self.build_spec_simplified(ch)
-            with Backup(spec, device=self.device) as bk:
-                out = bk.solve(n_st)
+            spec, s_w, s_t = built[ch]
+            out = outs[ch]
             shape = (len(s_w), len(s_t))
             self.F_values[ch] = out["J"].reshape(shape, order="F")
             self.U_idx[ch] = out["idx"].reshape(shape, order="F")

@@ -24,7 +24,7 @@ import math
 
 import numpy as np
 
-from .core import Backup
+from .core import Backup, solve_many
 from .matlab_compat import deg2rad, sym_linspace_pos_att
 from .problem import ProblemSpec, Term
 
@@ -120,9 +120,11 @@ class Solver_pos_att:
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
         with Backup(spec, device=self.device) as bk:
             out = bk.solve(n_st, monitor_period=self.monitor_period, monitor_tol=self.monitor_tol, progress=progress)
-        shape = spec.n
+        return self._store_controller(file_name, (s_x, s_v, s_t, s_w), spec.n, combos, out)
+
+    def _store_controller(self, file_name, grids, shape, combos, out):
         self.controllers[file_name] = {                                  # save(file_name, ...) :289
-            "GridVectors": [s_x, s_v, s_t, s_w],
+            "GridVectors": list(grids),
             "F_gI_Values": out["J"].reshape(shape, order="F"),
             "U_Optimal_id": out["idx"].reshape(shape, order="F"),
             "f0_allcomb": combos[0], "f1_allcomb": combos[1], "f6_allcomb": combos[2], "f7_allcomb": combos[3],
@@ -170,14 +172,25 @@ class Solver_pos_att:
         return pols
 
     def simplified_run(self, n_stages=None, progress=None):
+        """Solver_pos_att.m:197-242: the x, y, z channels and the thruster-failure variant of the x channel.  The
+        four sweeps are independent, so they are in flight together (hjbdp.core.solve_many); results are stored
+        per channel exactly as calculate_one_channel_U_Opt stores them."""
         sx, sv, st, sw = self.grids()
-        ch = self.calculate_one_channel_U_Opt
-        ch(sx, sv, st[0], sw, self.F_Thr0, self.F_Thr1, self.F_Thr6, self.F_Thr7,
-           self.Qx1, self.Qv1, self.Qt1, self.Qw1, self.R1, self.J2, "channel_x_controller_1", n_stages, progress)     # :217-221
-        ch(sx, sv, st[1], sw, self.F_Thr2, self.F_Thr3, self.F_Thr8, self.F_Thr9,
-           self.Qx2, self.Qv2, self.Qt2, self.Qw2, self.R2, self.J3, "channel_y_controller_1", n_stages, progress)     # :223-227
-        ch(sx, sv, st[2], sw, self.F_Thr4, self.F_Thr5, self.F_Thr10, self.F_Thr11,
-           self.Qx3, self.Qv3, self.Qt3, self.Qw3, self.R3, self.J1, "channel_z_controller_1", n_stages, progress)     # :229-233
-        ch(sx, sv, st[0], sw, [0.0], self.F_Thr1, self.F_Thr6, self.F_Thr7,
-           self.Qx1, self.Qv1, self.Qt1, self.Qw1, self.R1, self.J2, "channel_x_controller_1_failure", n_stages, progress)  # :236-240
+        jobs = [
+            ((sx, sv, st[0], sw, self.F_Thr0, self.F_Thr1, self.F_Thr6, self.F_Thr7,
+              self.Qx1, self.Qv1, self.Qt1, self.Qw1, self.R1, self.J2), "channel_x_controller_1"),          # :217-221
+            ((sx, sv, st[1], sw, self.F_Thr2, self.F_Thr3, self.F_Thr8, self.F_Thr9,
+              self.Qx2, self.Qv2, self.Qt2, self.Qw2, self.R2, self.J3), "channel_y_controller_1"),          # :223-227
+            ((sx, sv, st[2], sw, self.F_Thr4, self.F_Thr5, self.F_Thr10, self.F_Thr11,
+              self.Qx3, self.Qv3, self.Qt3, self.Qw3, self.R3, self.J1), "channel_z_controller_1"),          # :229-233
+            ((sx, sv, st[0], sw, [0.0], self.F_Thr1, self.F_Thr6, self.F_Thr7,
+              self.Qx1, self.Qv1, self.Qt1, self.Qw1, self.R1, self.J2), "channel_x_controller_1_failure"),  # :236-240
+        ]
+        built = [self.build_channel_spec(*args) for args, _ in jobs]
+        n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
+        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device,
+                                           monitor_period=self.monitor_period, monitor_tol=self.monitor_tol,
+                                           progress=progress)
+        for (args, name), (spec, combos), out in zip(jobs, built, outs):
+            self._store_controller(name, args[:4], spec.n, combos, out)
         return self

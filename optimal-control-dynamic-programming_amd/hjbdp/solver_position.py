@@ -16,7 +16,7 @@ import math
 
 import numpy as np
 
-from .core import Backup
+from .core import Backup, solve_many
 from .matlab_compat import interp_nearest_point, sym_linspace_position
 from .problem import ProblemSpec, Term
 
@@ -92,10 +92,12 @@ class Solver_position:
     def simplified_run(self, n_stages=None):
         """n_stages overrides N_stage-1 (tests)."""
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
+        built = [self.build_spec(ch) for ch in range(3)]
+        # the three channels are independent sweeps (:132-141 runs them in one loop body): in flight together
+        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device)
         for ch in range(3):
-            spec, s_x, s_v = self.build_spec(ch)
-            with Backup(spec, device=self.device) as bk:
-                out = bk.solve(n_st)
+            spec, s_x, s_v = built[ch]
+            out = outs[ch]
             shape = (len(s_x), len(s_v))
             self.F_values[ch] = out["J"].reshape(shape, order="F")
             self.U_idx[ch] = out["idx"].reshape(shape, order="F")
