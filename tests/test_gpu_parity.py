@@ -624,3 +624,20 @@ def test_float16_j_storage_bit_exact(env, n, m, nonuniform):
         o32 = bk.solve(4, terminal=term.astype(np.float32))
     err = np.abs(o["J"].astype(np.float32) - o32["J"])
     assert np.median(err) < 2e-3 * np.abs(o32["J"]).max() and err.max() < 5e-2 * np.abs(o32["J"]).max()
+
+
+def test_handles_on_different_threads_overlap_safely(env):
+    """include/hjbdp.h threading contract: different handles may be driven from different host threads at once
+    (graph capture, monitor read-backs, allocation and synchronous copies all in flight).  Six sweeps with
+    graph replay and the early-stop monitor, twice; every result equals the oracle's."""
+    hjbdp, _abi, c_oracle = env
+    from problems import nested_problem, random_terminal
+    specs = [nested_problem(500 + i, (9 + i, 8, 6), (3, 4), dtype=np.float32, spread=0.1) for i in range(6)]
+    terms = [random_terminal(sp, i) for i, sp in enumerate(specs)]
+    refs = [c_oracle.sweep(_abi, sp, 150, terminal=t, monitor_period=10, monitor_tol=1e-9, nthreads=4)
+            for sp, t in zip(specs, terms)]        # tiny problems: a 128-thread OpenMP team costs more than the work
+    for _ in range(2):
+        outs, wall_ms, variants = hjbdp.solve_many(specs, 150, terminal=terms, monitor_period=10, monitor_tol=1e-9)
+        for o, r in zip(outs, refs):
+            assert o["stages_done"] == r["stages_done"]
+            assert np.array_equal(o["J"], r["J"]) and np.array_equal(o["idx"], r["idx"])
