@@ -106,3 +106,39 @@ class Solver_position:
             setattr(self, "U%d_Opt" % (ch + 1), pol)
         self.n_mesh_x, self.n_mesh_v = len(s_x), len(s_v)                     # :100,:104
         return self
+
+    # ------------------------------------------------------------------ closed-loop rollout
+    def get_target_R0V0(self):
+        """Solver_position.m:313-331: the target's initial state on its reference orbit (perigee altitude 300 km,
+        e = 0.1, equatorial, at perigee)."""
+        from .orbit import MU_EARTH, R_EARTH, state_from_elements
+        rp, e = R_EARTH + 300.0, 0.1
+        ra = rp * (1.0 + e) / (1.0 - e)
+        h_ = math.sqrt(2.0 * MU_EARTH * rp * ra / (ra + rp))
+        return state_from_elements(h_, e, 0.0, 0.0, 0.0, 0.0, MU_EARTH)
+
+    def get_optimal_path(self, n_steps=None, y0=None):
+        """Solver_position.m:189-311 without the plots: from the chaser's initial relative state (default
+        dr0 = [-1 0 0] km, dv0 = 0, :195-197) step N-1 times: look the three accelerations up in the
+        'nearest' policies left by simplified_run (:215-217), hold them over [t_k, t_k + h] and integrate the
+        relative-motion equations with RKF4(5) (:222).  Returns (T [N], X [6, N], F_Opt_history [3, N]);
+        n_steps limits the number of steps (tests)."""
+        from .orbit import relative_motion_rates, rkf45
+        if self.U_idx[0] is None:
+            raise RuntimeError("simplified_run() first")
+        y = np.array([-1.0, 0.0, 0.0, 0.0, 0.0, 0.0]) if y0 is None else np.asarray(y0, dtype=np.float64).reshape(6)
+        R0, V0 = self.get_target_R0V0()
+        N = int(math.ceil(self.T_final / self.h))
+        if n_steps is not None:
+            N = min(N, int(n_steps) + 1)
+        X = np.zeros((6, N))
+        F = np.zeros((3, N))
+        X[:, 0] = y
+        for k in range(N - 1):
+            xs = X[:, k]
+            a = (float(self.U1_Opt(xs[0], xs[3])), float(self.U2_Opt(xs[1], xs[4])), float(self.U3_Opt(xs[2], xs[5])))
+            F[:, k] = a
+            X[:, k + 1] = rkf45(lambda t, yy: relative_motion_rates(t, yy, R0, V0, a), k * self.h, (k + 1) * self.h, xs)
+        self.X_path, self.F_Opt_history = X, F
+        return np.arange(N) * self.h, X, F
+

@@ -256,3 +256,18 @@ def test_c4_full_size_plane_vs_oracle(env):
     n3 = 120 ** 3
     assert np.array_equal(Jo.reshape(n3, -1, order="F")[:, hl], J.reshape(n3, 120, order="F")[:, p])
     assert np.array_equal(io, idx.reshape(n3, 120, order="F")[:, p])
+
+
+def test_solver_position_closed_loop_rollout(env):
+    """Solver_position.get_optimal_path (:189-311): the policies of simplified_run fly the chaser from 1 km behind
+    the target towards it: full positive thrust first (x = -1 lies below the grid: 'nearest' clamps to its edge),
+    the gap closes monotonically while the thrust is on, the out-of-plane axes stay at rest."""
+    hjbdp, _abi, c_oracle = env
+    sp = hjbdp.Solver_position()
+    sp.simplified_run(n_stages=400)
+    T, X, F = sp.get_optimal_path(n_steps=300)
+    assert X.shape == (6, 301) and F.shape == (3, 301)
+    assert F[0, 0] == pytest.approx(0.26) and np.all(F[0, :100] == pytest.approx(0.26))
+    assert np.all(np.diff(X[0, :100]) > 0) and X[0, 300] > X[0, 0]
+    assert X[3, 100] == pytest.approx(0.26 * 100 * sp.h, rel=1e-2)           # dv ~ a*t while the thrust is constant
+    assert np.max(np.abs(X[2])) < 1e-12 and np.max(np.abs(F[2])) == 0.0      # z stays at the origin

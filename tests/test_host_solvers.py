@@ -194,3 +194,58 @@ def test_dynamic_solver_debug_taps():
     ds.dx = 35
     ds._debug_taps(ds.build_spec(), 4)
     assert ds.J_current_state_check is None
+
+
+def test_orbit_routines_against_closed_forms():
+    """hjbdp/orbit.py (position-control/private/*.m restated): one orbital period returns the state,
+    energy and angular momentum are conserved, perigee/apogee radii match the elements, and the relative-motion
+    equations (Solver_position.m:261-309) agree with the difference of two independently propagated orbits."""
+    import math
+    from hjbdp import orbit
+    mu = orbit.MU_EARTH
+    rp, e = orbit.R_EARTH + 300.0, 0.1
+    ra = rp * (1 + e) / (1 - e)
+    h = math.sqrt(2 * mu * rp * ra / (ra + rp))
+    a = (rp + ra) / 2
+    T = 2 * math.pi / math.sqrt(mu) * a ** 1.5
+    R0, V0 = orbit.state_from_elements(h, e, 0.0, 0.0, 0.0, 0.0)
+    assert np.allclose(R0, [rp, 0, 0]) and np.isclose(V0[1], h / rp)
+    R, V = orbit.propagate_kepler(R0, V0, T)
+    assert np.max(np.abs(R - R0)) < 1e-8 and np.max(np.abs(V - V0)) < 1e-11
+    Rh, Vh = orbit.propagate_kepler(R0, V0, T / 2)
+    assert abs(np.linalg.norm(Rh) - ra) < 1e-7                        # apogee after half a period
+    for t in (100.0, 1234.5, 4000.0):
+        Rt, Vt = orbit.propagate_kepler(R0, V0, t)
+        assert abs((Vt @ Vt) / 2 - mu / np.linalg.norm(Rt) - ((V0 @ V0) / 2 - mu / rp)) < 1e-9
+        assert np.allclose(np.cross(Rt, Vt), np.cross(R0, V0), rtol=1e-12)
+    assert orbit.stumpff_c(0.0) == 0.5 and abs(orbit.stumpff_s(0.01) - (1 / 6 - 0.01 / 120 + 1e-4 / 5040)) < 1e-10
+    assert abs(orbit.stumpff_c(-0.01) - (0.5 + 0.01 / 24 + 1e-4 / 720)) < 1e-10
+    # the integrator on y'' = -y.  The reference clips an accepted step to the end of the interval AFTER forming
+    # its stage derivatives with the unclipped step (rkf45.m:100-104), so the last step of every interval is only
+    # first-order consistent: over one 0.005 s hold the error is ~ h_last * |y''| * h_unclipped / 2 ~ 5e-6, not
+    # the 1e-8 tolerance.  Restated as is.
+    y = orbit.rkf45(lambda t, y: np.array([y[1], -y[0]]), 0.0, 0.005, [1.0, 0.0])
+    assert abs(y[0] - math.cos(0.005)) < 1e-5 and abs(y[1] + math.sin(0.005)) < 1e-5
+
+    def lvlh(R, V):
+        i = R / np.linalg.norm(R)
+        k = np.cross(R, V)
+        k = k / np.linalg.norm(k)
+        return np.array([i, np.cross(k, i), k])
+    Q = lvlh(R0, V0)
+    om = np.cross(R0, V0) / (R0 @ R0)
+    dr, dv = np.array([-0.1, 0.02, 0.01]), np.array([1e-4, -2e-4, 5e-5])
+    Rc0, Vc0 = R0 + Q.T @ dr, V0 + Q.T @ dv + np.cross(om, Q.T @ dr)
+    y = np.concatenate([dr, dv])
+    for k in range(200):                                              # 60 s in 0.3 s holds, no thrust
+        y = orbit.rkf45(lambda t, yy: orbit.relative_motion_rates(t, yy, R0, V0, (0.0, 0.0, 0.0)), 0.3 * k, 0.3 * (k + 1), y)
+    Rt, Vt = orbit.propagate_kepler(R0, V0, 60.0)
+    Rc, _ = orbit.propagate_kepler(Rc0, Vc0, 60.0)
+    assert np.max(np.abs(y[:3] - lvlh(Rt, Vt) @ (Rc - Rt))) < 1e-5 * np.linalg.norm(dr) * 10
+    # a constant commanded acceleration integrates as a*t^2/2 on top of the free motion (to first order)
+    y2 = orbit.rkf45(lambda t, yy: orbit.relative_motion_rates(t, yy, R0, V0, (0.26, 0.0, 0.0)), 0.0, 0.005,
+                     np.concatenate([dr, dv]))
+    y1 = orbit.rkf45(lambda t, yy: orbit.relative_motion_rates(t, yy, R0, V0, (0.0, 0.0, 0.0)), 0.0, 0.005,
+                     np.concatenate([dr, dv]))
+    assert abs((y2[3] - y1[3]) - 0.26 * 0.005) < 1e-9                  # dv = a t exactly (constant derivative)
+    assert 0.5 < (y2[0] - y1[0]) / (0.26 * 0.005 ** 2 / 2) < 1.6      # dx = a t^2 / 2 up to the clipped-step error
