@@ -25,6 +25,7 @@
 #include "kernels_lookup.h"
 #include "kernels_tabled.h"
 #include "kernels_rowwise.h"
+#include "kernels_tile2d.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -66,9 +67,12 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     int gexec_variant = -1;
+    bool gexec_tiled = false;
     bool use_graph = true;
     size_t packed_lds = 0;
     size_t packed2_lds = 0;       // variant 4 (two controls per packed op)
+    int tile2d = -1;              // K9 (several stages per launch, kernels_tile2d.h): -1 not examined yet, 0 no, 1 yes
+    int use_temporal = 1;         // option "temporal": 0 off, 1 when applicable, 2 required (hjb_solve fails otherwise)
     bool row_ok = false;          // variant 6 (one wave per grid row) applies
     bool row_auto = false;        // ... and is chosen automatically
     int packed_pre = 0;           // variant 4 contraction mode (kernels_packed2.h MODE): 0 plain, 1 C2 shape, 2 state-only axes first
@@ -606,6 +610,59 @@ int ensure_tabled(Handle *h) {
     return h->dtype != HJB_F64 ? ensure_tabled_t<float>(h) : ensure_tabled_t<double>(h);
 }
 
+// K9 applies when, for every state and control, each axis' interpolation cell is the state's own cell or the one
+// below (clamped to the grid): then J_k at a state depends on J_{k+1} within +-1 cell only.  Checked on the host
+// from the variant-5 tables (small: 2-D problems only).
+template <typename T>
+int examine_tile2d_t(Handle *h) {
+    h->tile2d = 0;
+    const DParams &P = h->hp;
+    if (P.D != 2 || h->j_elems != h->n_owned || !h->tabled_ok || h->hp.model) return HJB_OK;
+    if (h->dom_entries[0] + h->dom_entries[1] > ((int64_t)1 << 26)) return HJB_OK;
+    int st = ensure_tabled(h);
+    if (st) return st;
+    for (int a = 0; a < 2; ++a) {
+        std::vector<TabEntry<T>> tab((size_t)h->dom_entries[a]);
+        HIP_TRY(h, hipMemcpy(tab.data(), h->htb.ax[a].tab, tab.size() * sizeof(TabEntry<T>), hipMemcpyDeviceToHost));
+        // entry index -> this axis' state index: strides of the table domain
+        const DTabled::Axis &A = h->htb.ax[a];
+        const int na = P.n[a];
+        if (A.sstride[a] == 0) return HJB_OK;               // x_next_a does not depend on x_a: not a local problem
+        // walk every entry: its axis-a index is (e / sstride[a]) % n[a] because domains are dense column-major
+        for (int64_t e = 0; e < h->dom_entries[a]; ++e) {
+            const int i = (int)((e / A.sstride[a]) % na);
+            const int lo = std::max(i - 1, 0), hi = std::min(i, na - 2);
+            if (tab[(size_t)e].cell < lo || tab[(size_t)e].cell > hi) return HJB_OK;
+        }
+    }
+    h->tile2d = 1;
+    return HJB_OK;
+}
+
+int examine_tile2d(Handle *h) {
+    return h->dtype != HJB_F64 ? examine_tile2d_t<float>(h) : examine_tile2d_t<double>(h);
+}
+
+int launch_tile2d(Handle *h, const void *dJn, void *dJo, int32_t *didx, int K, hipStream_t st) {
+    const DParams &P = h->hp;
+    const int tiles = ((P.n[0] + kTileX - 1) / kTileX) * ((P.n[1] + kTileY - 1) / kTileY);
+    dim3 g(tiles), b(256);
+    const bool cached = P.C == 1 && h->nU <= kTileMaxU;     // stage-invariant per-control data kept in registers
+#define HJB_LAUNCH_TILE(TT, TTJ)                                                                                       \
+    do {                                                                                                               \
+        if (cached)                                                                                                    \
+            hipLaunchKernelGGL((k_backup_tile2d_cached<TT, TTJ>), g, b, 0, st, h->dp, h->dtb, (const TTJ *)dJn, (TTJ *)dJo, didx, K); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_backup_tile2d<TT, TTJ>), g, b, 0, st, h->dp, h->dtb, (const TTJ *)dJn, (TTJ *)dJo, didx, K); \
+    } while (0)
+    if (h->dtype == HJB_F16S) HJB_LAUNCH_TILE(float, _Float16);
+    else if (h->dtype == HJB_F32) HJB_LAUNCH_TILE(float, float);
+    else HJB_LAUNCH_TILE(double, double);
+#undef HJB_LAUNCH_TILE
+    HIP_TRY(h, hipGetLastError());
+    return HJB_OK;
+}
+
 void choose_launch(Handle *h) {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     // few states x many controls (Kirk): one wave per state, controls across lanes
@@ -1035,6 +1092,11 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         h->lds_pad = (size_t)value;
         return HJB_OK;
     }
+    if (!strcmp(key, "temporal")) {
+        if (value < 0 || value > 2) return fail(h, HJB_E_INVALID, "temporal must be 0, 1 or 2");
+        h->use_temporal = (int)value;
+        return HJB_OK;
+    }
     if (!strcmp(key, "graph")) {
         h->use_graph = value != 0;
         return HJB_OK;
@@ -1126,16 +1188,40 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     SOLVE_TRY(hipDeviceSynchronize());   // the sweep runs on the handle's own stream from here
     // launch-bound sweeps: replay kGraphStages ping-pong launches per hipGraphLaunch
     const bool graph_ok = h->use_graph && !dJst && !dIst && o->n_stages >= 2 * kGraphStages;
+    // K9: several stages per launch for local 2-D problems (no per-stage outputs, no monitor read-backs)
+    bool tiled = false;
+    if (h->use_temporal && !dJst && !dIst && o->monitor_period <= 0 && o->n_stages >= 2 * kTileK && h->forced_variant < 0) {
+        if (h->tile2d < 0) {
+            const int tst = examine_tile2d(h);
+            if (tst) { cleanup(); return tst; }
+        }
+        tiled = h->tile2d == 1;
+    }
+    if (h->use_temporal == 2 && !tiled) {
+        cleanup();
+        return fail(h, HJB_E_UNSUPPORTED, "option temporal=2: several stages per launch do not apply (needs D=2, whole grid, "
+                    "every query within one cell of its state, no per-stage outputs or monitor, >= %d stages)", 2 * kTileK);
+    }
+    if (h->gexec && h->gexec_tiled != tiled) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     unsafe_lk.unlock();
     if (graph_ok && !h->gexec) {
         std::unique_lock<std::shared_mutex> capture_lk(g_capture_mu);
         hipGraph_t graph = nullptr;
         SOLVE_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         int cst = HJB_OK;
-        for (int i = 0; i < kGraphStages / 2 && cst == HJB_OK; ++i) {
-            cst = launch_stage(h, h->dJ[0], h->dJ[1], h->d_idx, stream);
-            if (cst == HJB_OK) cst = launch_stage(h, h->dJ[1], h->dJ[0], h->d_idx, stream);
+        if (tiled) {          // kGraphStages = 4 launches of kTileK stages, ending in dJ[0]
+            static_assert(kGraphStages % (2 * kTileK) == 0, "a graph must hold an even number of tile launches");
+            for (int i = 0; i < kGraphStages / (2 * kTileK) && cst == HJB_OK; ++i) {
+                cst = launch_tile2d(h, h->dJ[0], h->dJ[1], h->d_idx, kTileK, stream);
+                if (cst == HJB_OK) cst = launch_tile2d(h, h->dJ[1], h->dJ[0], h->d_idx, kTileK, stream);
+            }
+        } else {
+            for (int i = 0; i < kGraphStages / 2 && cst == HJB_OK; ++i) {
+                cst = launch_stage(h, h->dJ[0], h->dJ[1], h->d_idx, stream);
+                if (cst == HJB_OK) cst = launch_stage(h, h->dJ[1], h->dJ[0], h->d_idx, stream);
+            }
         }
+        h->gexec_tiled = tiled;
         hipError_t ce = hipStreamEndCapture(stream, &graph);
         if (cst != HJB_OK || ce != hipSuccess) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -1171,6 +1257,15 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
                 SOLVE_TRY(hipGraphLaunch(h->gexec, stream));
                 done += kGraphStages; run -= kGraphStages; k_s -= kGraphStages;
             }
+        }
+        while (tiled && run > 0) {                           // K9: up to kTileK stages per launch
+            const int K = std::min(run, kTileK);
+            st = launch_tile2d(h, cur, h->dJ[pp], h->d_idx, K, stream);
+            if (st) { cleanup(); return st; }
+            cur = h->dJ[pp];
+            cur_idx = h->d_idx;
+            pp ^= 1;
+            done += K; run -= K; k_s -= K;
         }
         for (; run > 0; --run, --k_s) {
             void *outJ = dJst ? (void *)(dJst + (size_t)(k_s - 1) * jb) : h->dJ[pp];

@@ -641,3 +641,46 @@ def test_handles_on_different_threads_overlap_safely(env):
         for o, r in zip(outs, refs):
             assert o["stages_done"] == r["stages_done"]
             assert np.array_equal(o["J"], r["J"]) and np.array_equal(o["idx"], r["idx"])
+
+
+@pytest.mark.parametrize("dtype,j_storage,n,stages", [
+    (np.float64, None, (41, 37), 37), (np.float32, None, (70, 20), 100), (np.float32, np.float16, (33, 50), 29),
+    (np.float64, None, (16, 16), 16), (np.float64, None, (5, 90), 70)])
+def test_temporal_blocking_2d_bit_exact(env, dtype, j_storage, n, stages):
+    """K9 (kernels_tile2d.h): several stages per launch with the J patch resident in LDS must leave exactly what
+    one launch per stage leaves - ragged tiles, stage counts that are not multiples of the block, graph replay,
+    float16 storage rounding at every stage."""
+    hjbdp, _abi, c_oracle = env
+    from problems import Term
+    rng = np.random.default_rng(n[0])
+    kx, kv = np.linspace(-0.5, 0.5, n[0]), np.linspace(-0.4, 0.6, n[1])
+    hx, hv = kx[1] - kx[0], kv[1] - kv[0]
+    U = np.array([-0.26, 0.0, 0.13, 0.26])
+    # x+ = x + a(v) with |a| < one cell, v+ = v + b(x) + c(u) with |b| + |c| < one cell: local dynamics
+    nxt = [[Term((0,), kx), Term((1,), 0.9 * hx * np.sin(3 * kv))],
+           [Term((1,), kv), Term((0,), 0.4 * hv * np.cos(5 * kx)), Term((2,), 0.55 * hv * U / 0.26)]]
+    cost = [Term((0,), 6 * kx ** 2), Term((1,), 3 * kv ** 2), Term((2,), 0.1 * U ** 2), Term((0, 1), 0.05 * rng.random(n))]
+    spec = hjbdp.ProblemSpec([kx, kv], [len(U)], nxt, cost, dtype=dtype, index_base=1, j_storage=j_storage)
+    term = (rng.random(spec.nS) * 2).astype(spec.j_dtype)
+    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, nthreads=8)
+    with hjbdp.Backup(spec) as bk:
+        bk.set_option("temporal", 2)                 # fail if the blocked path is not the one that runs
+        out = bk.solve(stages, terminal=term)
+        assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+        bk.set_option("temporal", 0)
+        out0 = bk.solve(stages, terminal=term)
+        assert np.array_equal(out0["J"], ref["J"]) and np.array_equal(out0["idx"], ref["idx"])
+
+
+def test_temporal_blocking_refused_when_not_local(env):
+    """Kirk's dynamics move x2 by up to ~40 cells per stage: K9 must not be used (and says so when required)."""
+    hjbdp, _abi, c_oracle = env
+    spec = _kirk(hjbdp, "double", 20, 25, 30).build_spec()
+    with hjbdp.Backup(spec) as bk:
+        out = bk.solve(20)                            # default: falls back silently to one launch per stage
+        ref = c_oracle.sweep(_abi, spec, 20, nthreads=8)
+        assert np.array_equal(out["J"], ref["J"])
+        bk.set_option("temporal", 2)
+        with pytest.raises(hjbdp.HjbError) as ei:
+            bk.solve(20)
+        assert ei.value.status == _abi.HJB_E_UNSUPPORTED
