@@ -75,6 +75,8 @@ struct Handle {
     int use_temporal = 1;         // option "temporal": 0 off, 1 when applicable, 2 required (hjb_solve fails otherwise)
     bool row_ok = false;          // variant 6 (one wave per grid row) applies
     bool row_auto = false;        // ... and is chosen automatically
+    bool row_lean_ok = false;     // variant 6: the lean form applies (kernels_rowwise.h)
+    bool row_lean = true;         // option "row_lean"
     int packed_pre = 0;           // variant 4 contraction mode (kernels_packed2.h MODE): 0 plain, 1 C2 shape, 2 state-only axes first
     size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
     bool tabled_ok = false;       // variant 5: per-axis (cell, t) tables for every axis (built on first use)
@@ -545,6 +547,12 @@ int build(Handle *h, const hjb_problem *p) {
         bool rw = h->tabled_ok && D >= 2 && !p->model;
         for (int a = 1; a < D; ++a) rw = rw && (h->dom_mask[a] & 1u) == 0;
         h->row_ok = rw;
+        {   // lean form: few controls, 32-bit element offsets, control terms of the cost involve controls only
+            bool ln = rw && h->nU <= 64 && h->j_elems < ((int64_t)1 << 31) && (P.n_cost - P.n_cost_prefix) <= kLeanMaxCu;
+            const uint32_t smask = (1u << D) - 1u;
+            for (int k = P.n_cost_prefix; k < P.n_cost; ++k) ln = ln && (p->cost_terms[k].mask & smask) == 0;
+            h->row_lean_ok = ln;
+        }
         // worth it when a 64-lane wave is mostly filled by a row and the grid is large (C4: +10 %); small grids
         // have too few rows to fill the chip with one wave per row
         h->row_auto = rw && p->n[0] >= 96 && h->n_owned >= ((int64_t)1 << 22);
@@ -694,14 +702,19 @@ int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t
     dim3 g(h->grid), b(h->block);
     if (h->variant == 6) {
         if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 6 tables missing");
+        const bool lean = h->row_lean && h->row_lean_ok && !h->htb.ax[0].has_ctrl;
+        const size_t lean_wave = (((size_t)h->nU * 4 + 15) & ~(size_t)15) + (((size_t)h->nU * (D - 1 + kLeanMaxCu) * sizeof(T) + 15) & ~(size_t)15);
+        const size_t lds = lean ? 4 * lean_wave + (size_t)h->nU * 12 : 0;
+#define HJB_LAUNCH_ROW(DD)                                                                                             \
+    case DD:                                                                                                           \
+        if (lean) hipLaunchKernelGGL((k_backup_rowlean<T, TJ, DD>), g, b, lds, st, h->dp, h->dtb, dJn, dJo, didx);      \
+        else hipLaunchKernelGGL((k_backup_rowwise<T, TJ, DD>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx);             \
+        break;
         switch (D) {
-            case 2: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 2>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 3: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 3>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 4: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 4>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 5: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 5>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 6: hipLaunchKernelGGL((k_backup_rowwise<T, TJ, 6>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
+            HJB_LAUNCH_ROW(2) HJB_LAUNCH_ROW(3) HJB_LAUNCH_ROW(4) HJB_LAUNCH_ROW(5) HJB_LAUNCH_ROW(6)
             default: return fail(h, HJB_E_UNSUPPORTED, "variant 6 with D=%d", D);
         }
+#undef HJB_LAUNCH_ROW
         HIP_TRY(h, hipGetLastError());
         return HJB_OK;
     }
@@ -1090,6 +1103,10 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     if (!strcmp(key, "lds_pad")) {
         if (value < 0 || value > 128 * 1024) return fail(h, HJB_E_INVALID, "lds_pad out of range");
         h->lds_pad = (size_t)value;
+        return HJB_OK;
+    }
+    if (!strcmp(key, "row_lean")) {
+        h->row_lean = value != 0;
         return HJB_OK;
     }
     if (!strcmp(key, "temporal")) {

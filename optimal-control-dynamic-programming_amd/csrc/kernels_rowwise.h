@@ -199,3 +199,178 @@ k_backup_rowwise(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
 }
 
 }  // namespace hjb
+
+namespace hjb {
+
+// ---- lean form ------------------------------------------------------------------------------------------
+// Ablation on C4 (removing the gathers, the cost terms and the table lookups in turn changed nothing) showed what
+// k_backup_rowwise spends its time on: its own ~270-instruction control loop.  The scalar unit and the vector unit
+// of a CU each retire one wave-instruction per cycle, and "scalarising" had only moved 64-bit address arithmetic
+// (150 SALU per control) from one to the other.  This form removes the instructions instead:
+//   * everything that depends on the CONTROL but not on the lane - row base offset, weights of axes 1..D-1,
+//     control-only cost terms - is computed once per row item with LANE u WORKING ON CONTROL u (all controls in
+//     parallel, a handful of instructions per item instead of per control) and parked in LDS;
+//   * element offsets are 32-bit (J has < 2^31 elements), so a gather is `J + 4*(row + delta_c + cell0)` with the
+//     2^(D-1) corner deltas in scalar registers: one v_add per corner row, no 64-bit arithmetic;
+//   * the control loop reads its per-control record from LDS (broadcast), gathers, lerps, compares: ~45 VALU.
+// Requirements on top of variant 6 (checked on the host): axis 0 independent of the control, nU <= 64, fewer than
+// 2^31 J elements, every cost term that involves a control involves controls ONLY (at most kLeanMaxCu of them).
+constexpr int kLeanMaxCu = 4;
+
+template <typename T, typename TJ, int D>
+__global__ void __launch_bounds__(256)
+k_backup_rowlean(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
+                 TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+    static_assert(D >= 2, "one wave per row needs a second axis");
+    constexpr int DR = D - 1;
+    constexpr int NR = 1 << (D - 1);
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int C = P->C;
+    const int nU = (int)P->nU;
+    const int plane0 = P->plane0, nplanes = P->nplanes;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ncu = P->n_cost - P->n_cost_prefix;                   // control-only cost terms
+    // LDS, per wave: rb[nU] (uint32) | tw[nU][DR] (T) | cu[nU][ncu] (T) ; after the four waves: cj[nU][3] (block)
+    const size_t rb_bytes = ((size_t)nU * 4 + 15) & ~(size_t)15;
+    const size_t per_wave = rb_bytes + (((size_t)nU * (DR + kLeanMaxCu) * sizeof(T) + 15) & ~(size_t)15);
+    unsigned char *wbase = smem_raw + (size_t)wave * per_wave;
+    uint32_t *s_rb = reinterpret_cast<uint32_t *>(wbase);
+    T *s_tw = reinterpret_cast<T *>(wbase + rb_bytes);
+    T *s_cu = s_tw + (size_t)nU * DR;
+    int *s_cj = reinterpret_cast<int *>(smem_raw + 4 * per_wave);
+    // control index -> per-dim indices (control dim 0 slowest), once per workgroup
+    for (int u = threadIdx.x; u < nU; u += blockDim.x) {
+        int j0 = u, j1 = 0, j2 = 0;
+        if (C == 2) { j1 = u % P->m[1]; j0 = u / P->m[1]; }
+        if (C == 3) { j2 = u % P->m[2]; const int r = u / P->m[2]; j1 = r % P->m[1]; j0 = r / P->m[1]; }
+        s_cj[3 * u] = j0; s_cj[3 * u + 1] = j1; s_cj[3 * u + 2] = j2;
+    }
+    __syncthreads();
+    const uint32_t n0 = (uint32_t)P->n[0];
+    const uint32_t chunks = (n0 + 63u) >> 6;
+    uint32_t rows = 1;
+#pragma unroll
+    for (int a = 1; a < D; ++a) rows *= (uint32_t)P->n[a];
+    const uint32_t items = rows * chunks;
+    const uint32_t wstride = gridDim.x * 4u;
+    uint32_t js[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) js[a] = (uint32_t)P->jstride[a];
+    uint32_t delta[NR];                                             // corner-row offsets (uniform)
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int a = 1; a < D; ++a)
+            if (c & (1 << (a - 1))) d += js[a];
+        delta[c] = d;
+    }
+    const int my_cj[3] = {lane < nU ? s_cj[3 * lane] : 0, lane < nU ? s_cj[3 * lane + 1] : 0, lane < nU ? s_cj[3 * lane + 2] : 0};
+
+    for (uint32_t item = blockIdx.x * 4u + wave; item < items; item += wstride) {
+        int sl[D], si[D];
+        {
+            uint32_t r = item;
+            const uint32_t chunk = r % chunks;
+            r /= chunks;
+            sl[0] = (int)(chunk * 64u + lane);
+#pragma unroll
+            for (int a = 1; a < D; ++a) {
+                const uint32_t na = (uint32_t)P->n[a];
+                sl[a] = (int)(r % na);
+                r /= na;
+            }
+        }
+        const bool valid = (uint32_t)sl[0] < n0;
+        if (!valid) sl[0] = (int)n0 - 1;
+#pragma unroll
+        for (int a = 0; a < D; ++a) si[a] = sl[a];
+        si[D - 1] += P->slab_begin;
+        int aoff0 = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) aoff0 += TB->ax[0].sstride[d] * sl[d];
+        const uint32_t c0 = (uint32_t)as_global<TabEntry<T>>(TB->ax[0].tab)[aoff0].cell;
+        const T t0 = as_global<TabEntry<T>>(TB->ax[0].tab)[aoff0].t;
+        int cjz[HJB_MAX_C] = {0, 0, 0};
+        T gpre = (T)0;
+        for (int k = 0; k < P->n_cost_prefix; ++k) {
+            const T x = term_value<T, D>(P->cost[k], si, cjz);
+            gpre = (k == 0) ? x : (T)(gpre + x);
+        }
+        // ---- phase A: lane u prepares control u ------------------------------------------------------
+        if (lane < nU) {
+            uint32_t rb = 0;
+            bool bad = false;
+#pragma unroll
+            for (int a = 1; a < D; ++a) {
+                const DTabled::Axis &A = TB->ax[a];
+                int off = A.cstride[0] * my_cj[0] + A.cstride[1] * my_cj[1] + A.cstride[2] * my_cj[2];
+#pragma unroll
+                for (int d = 1; d < D; ++d) off += A.sstride[d] * sl[d];
+                int cl = as_global<TabEntry<T>>(A.tab)[off].cell;
+                s_tw[lane * DR + (a - 1)] = as_global<TabEntry<T>>(A.tab)[off].t;
+                if (a == D - 1) {
+                    cl -= plane0;
+                    if (cl < 0 || cl + 1 >= nplanes) { bad = true; cl = cl < 0 ? 0 : nplanes - 2; }
+                }
+                rb += js[a] * (uint32_t)cl;
+            }
+            if (bad) *P->status = 1;
+            s_rb[lane] = rb;
+            for (int k = 0; k < ncu; ++k) {
+                const DTerm &t = P->cost[P->n_cost_prefix + k];
+                const int off = t.stride[D] * my_cj[0] + t.stride[D + 1] * my_cj[1] + t.stride[D + 2] * my_cj[2];
+                s_cu[lane * kLeanMaxCu + k] = as_global<T>(t.data)[off];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase B: the control loop ------------------------------------------------------------------
+        T best = (T)0;
+        int best_u = 0;
+        for (int u = 0; u < nU; ++u) {
+            const uint32_t row = s_rb[u] + c0;
+            T v[1 << D];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                const uint32_t o = row + delta[c];
+                v[2 * c] = (T)Jn[o];
+                v[2 * c + 1] = (T)Jn[o + 1u];
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) v[j] = fma_t<T>(t0, (T)(v[2 * j + 1] - v[2 * j]), v[2 * j]);
+#pragma unroll
+            for (int a = 1; a < D; ++a) {
+                const T ta = s_tw[u * DR + (a - 1)];
+#pragma unroll
+                for (int j = 0; j < (1 << (D - 1 - a)); ++j)
+                    v[j] = fma_t<T>(ta, (T)(v[2 * j + 1] - v[2 * j]), v[2 * j]);
+            }
+            T g = gpre;
+            for (int k = 0; k < ncu; ++k) {
+                const T x = s_cu[u * kLeanMaxCu + k];
+                g = (P->n_cost_prefix == 0 && k == 0) ? x : (T)(g + x);
+            }
+            const T tot = (T)(g + v[0]);
+            if (u == 0 || tot < best) {
+                best = tot;
+                best_u = u;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const int j0 = s_cj[3 * best_u], j1 = s_cj[3 * best_u + 1], j2 = s_cj[3 * best_u + 2];
+            const int label = C == 1 ? j0 : (C == 2 ? j0 + P->m[0] * j1 : j0 + P->m[0] * (j1 + P->m[1] * j2));
+            uint32_t ls = 0, mul = 1, lj = 0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                ls += mul * (uint32_t)sl[a];
+                lj += js[a] * (uint32_t)(a == D - 1 ? sl[a] + P->halo_lo : sl[a]);
+                mul *= (uint32_t)P->n[a];
+            }
+            stj<T, TJ>(Jout, lj, best);
+            if (idx_out) idx_out[ls] = label + P->index_base;
+        }
+    }
+}
+
+}  // namespace hjb

@@ -159,12 +159,14 @@ def test_rowwise_variant_bit_exact(env, n, m, dtype, nonuniform, spread):
     from problems import random_terminal
     spec = _row_problem(n, m, dtype, nonuniform, spread)
     term = random_terminal(spec, 5)
-    with hjbdp.Backup(spec, variant=6) as bk:
-        assert bk.info()["kernel_variant"] == 6
-        out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
     ref = c_oracle.sweep(_abi, spec, 3, terminal=term, keep_J=True, keep_idx=True)
-    assert np.array_equal(out["J_stages"], ref["J_stages"])
-    assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+    for lean in (1, 0):                       # the lean form (per-control records prepared lane-parallel) and the plain one
+        with hjbdp.Backup(spec, variant=6) as bk:
+            assert bk.info()["kernel_variant"] == 6
+            bk.set_option("row_lean", lean)
+            out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
+        assert np.array_equal(out["J_stages"], ref["J_stages"]), lean
+        assert np.array_equal(out["idx_stages"], ref["idx_stages"]), lean
 
 
 def test_rowwise_variant_pos_att_slab_and_f16(env):

@@ -18,7 +18,9 @@ spec0, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_T
 for label, spec in (("(x,v,theta,w)", spec0),):
     for v in variants:
         try:
-            with hjbdp.Backup(spec, variant=v) as bk:
+            with hjbdp.Backup(spec, variant=v % 10) as bk:
+                if v >= 10:
+                    bk.set_option("row_lean", 0)    # 16 = variant 6 without the lean form
                 info = bk.info()
                 bk.solve(2)
                 out = bk.solve(stages)
