@@ -548,7 +548,7 @@ int build(Handle *h, const hjb_problem *p) {
         for (int a = 1; a < D; ++a) rw = rw && (h->dom_mask[a] & 1u) == 0;
         h->row_ok = rw;
         {   // lean form: few controls, 32-bit element offsets, control terms of the cost involve controls only
-            bool ln = rw && h->nU <= 64 && h->j_elems < ((int64_t)1 << 31) && (P.n_cost - P.n_cost_prefix) <= kLeanMaxCu;
+            bool ln = rw && h->nU <= 64 && h->j_elems * (int64_t)h->esz < ((int64_t)1 << 32) && (P.n_cost - P.n_cost_prefix) <= kLeanMaxCu;
             const uint32_t smask = (1u << D) - 1u;
             for (int k = P.n_cost_prefix; k < P.n_cost; ++k) ln = ln && (p->cost_terms[k].mask & smask) == 0;
             h->row_lean_ok = ln;
