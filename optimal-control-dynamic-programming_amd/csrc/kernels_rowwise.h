@@ -12,6 +12,7 @@
 // (load -> LDS write -> LDS read is one long dependent chain per control).  Same canonical arithmetic and lerp order: bit-identical to every other variant.
 // Any D <= 6, C <= 3, float32/float64/float16-storage, slabs.
 #pragma once
+#include <type_traits>
 #include "hjbdp_dev.h"
 #include "kernels_generic.h"
 #include "kernels_tabled.h"
@@ -230,6 +231,7 @@ k_backup_rowlean(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
     const int plane0 = P->plane0, nplanes = P->nplanes;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ncu = P->n_cost - P->n_cost_prefix;                   // control-only cost terms
+    const bool has_prefix = P->n_cost_prefix > 0;
     // LDS, per wave: rb[nU] (uint32) | tw[nU][DR] (T) | cu[nU][ncu] (T) ; after the four waves: cj[nU][3] (block)
     const size_t rb_bytes = ((size_t)nU * 4 + 15) & ~(size_t)15;
     const size_t per_wave = rb_bytes + (((size_t)nU * (DR + kLeanMaxCu) * sizeof(T) + 15) & ~(size_t)15);
@@ -343,6 +345,8 @@ k_backup_rowlean(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
                 v[2 * c] = (T) * reinterpret_cast<const TJ *>(Jb + o);
                 v[2 * c + 1] = (T) * reinterpret_cast<gptr<TJ>>(Jb1 + o);
             }
+            // (packing these lerps two rows per v_pk_fma_f32 was measured slower: 7.3 vs 6.8 ms on C4 - the loaded
+            // corners land in unrelated registers and have to be moved into pairs first)
 #pragma unroll
             for (int j = 0; j < NR; ++j) v[j] = fma_t<T>(t0, (T)(v[2 * j + 1] - v[2 * j]), v[2 * j]);
 #pragma unroll
@@ -352,12 +356,17 @@ k_backup_rowlean(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
                 for (int j = 0; j < (1 << (D - 1 - a)); ++j)
                     v[j] = fma_t<T>(ta, (T)(v[2 * j + 1] - v[2 * j]), v[2 * j]);
             }
+            const T interp = v[0];
             T g = gpre;
-            for (int k = 0; k < ncu; ++k) {
-                const T x = s_cu[u * kLeanMaxCu + k];
-                g = (P->n_cost_prefix == 0 && k == 0) ? x : (T)(g + x);
+            if (ncu == 1 && has_prefix) {                          // the usual shape: state terms + one control term
+                g = (T)(g + s_cu[u * kLeanMaxCu]);
+            } else {
+                for (int k = 0; k < ncu; ++k) {
+                    const T x = s_cu[u * kLeanMaxCu + k];
+                    g = (!has_prefix && k == 0) ? x : (T)(g + x);
+                }
             }
-            const T tot = (T)(g + v[0]);
+            const T tot = (T)(g + interp);
             if (u == 0 || tot < best) {
                 best = tot;
                 best_u = u;
