@@ -1087,6 +1087,8 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         if (value == 6 && !h->row_ok)
             return fail(h, HJB_E_UNSUPPORTED, "variant 6 (one wave per grid row) needs D >= 2, per-axis tables that fit, and "
                         "no axis other than axis 0 depending on state dim 0");
+        if (h->dtype == HJB_F16S && value >= 1 && value <= 3)
+            return fail(h, HJB_E_UNSUPPORTED, "variant %lld does not support float16 J storage (use 0, 4, 5 or 6)", (long long)value);
         if (h->hp.model && value != -1 && value != 4)
             return fail(h, HJB_E_UNSUPPORTED, "a problem with a state model runs on variant 4 only");
         if (value == 5 && !h->tabled_ok)

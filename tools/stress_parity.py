@@ -1,0 +1,87 @@
+"""Randomised GPU-vs-oracle parity stress: random shapes (D, C, grid sizes, dtype, knot spacing, displacement
+spread, J storage), every applicable stage-kernel variant plus hjb_solve's multi-stage paths, whole grids and slabs.
+Every result must equal the C oracle's bit for bit.  usage: python tools/stress_parity.py [seconds=120] [seed=0]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "optimal-control-dynamic-programming_amd"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hjbdp
+from hjbdp import _abi
+from oracle import c_oracle
+from problems import nested_problem, random_problem, random_terminal
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + budget
+n_prob = n_runs = 0
+seen = {}
+while time.time() < t_end:
+    D = int(rng.integers(1, 7))
+    C = int(rng.integers(1, 4))
+    cap = {1: 400, 2: 70, 3: 18, 4: 9, 5: 6, 6: 5}[D]
+    n = tuple(int(rng.integers(2, cap + 1)) for _ in range(D))
+    m = tuple(int(rng.integers(1, 8)) for _ in range(C))
+    if np.prod(n) * np.prod(m) > 3e6:
+        continue
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    nonuniform = bool(rng.random() < 0.4)
+    spread = float(rng.choice([0.02, 0.1, 0.3, 0.8]))
+    seed = int(rng.integers(1 << 30))
+    kind = rng.choice(["nested", "nested_mixed", "random"]) if C <= D else "random"
+    try:
+        if kind == "random":
+            spec = random_problem(seed, n, m, dtype=dtype, nonuniform=nonuniform)
+        else:
+            spec = nested_problem(seed, n, m, dtype=dtype, nonuniform=nonuniform, spread=spread,
+                                  mixed_inner=(kind == "nested_mixed"))
+    except Exception as e:       # generator constraints (e.g. too many terms)
+        continue
+    if dtype == np.float32 and rng.random() < 0.25:
+        spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=1,
+                                 j_storage=np.float16)
+    term = random_terminal(spec, seed + 1)
+    stages = int(rng.choice([1, 2, 5, 17, 40, 70]))
+    if spec.nS * spec.nU * stages > 4e7:
+        stages = 2
+    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, nthreads=16)
+    if not np.all(np.isfinite(ref["J"].astype(np.float64))):
+        continue      # random dynamics with strong extrapolation can blow J up to inf/NaN: outside the contract
+                      # (SURVEY 8a note 3: "NaNs ... none arise"; min/argmin of NaNs is not defined alike everywhere)
+    n_prob += 1
+    for v in (None, 0, 1, 2, 3, 4, 5, 6):
+        try:
+            bk = hjbdp.Backup(spec, variant=v)
+        except hjbdp.HjbError as e:
+            assert e.status == _abi.HJB_E_UNSUPPORTED, (v, str(e))
+            continue
+        with bk:
+            kv = bk.info()["kernel_variant"]
+            out = bk.solve(stages, terminal=term)
+        ok = np.array_equal(out["J"], ref["J"], equal_nan=True) and np.array_equal(out["idx"], ref["idx"])   # (f16 J may overflow to inf/NaN over many stages - on both sides alike)
+        seen[(v, kv)] = seen.get((v, kv), 0) + 1
+        n_runs += 1
+        if not ok:
+            print("MISMATCH", dict(D=D, C=C, n=n, m=m, dtype=str(np.dtype(dtype)), j=str(spec.j_dtype), nonuniform=nonuniform,
+                                   spread=spread, seed=seed, kind=str(kind), stages=stages, forced=v, ran=kv), flush=True)
+            sys.exit(1)
+    # a random slab of the last axis with the halos the library asks for, one stage
+    nl = spec.n[-1]
+    if nl >= 4:
+        with hjbdp.Backup(spec) as bk:
+            need = bk.info()
+        b = int(rng.integers(0, nl - 1)); e = int(rng.integers(b + 1, nl + 1))
+        lo, hi = min(need["halo_needed_lo"], b), min(need["halo_needed_hi"], nl - e)
+        if (e + hi) - (b - lo) >= 2:
+            inner = spec.nS // nl
+            sub = np.asfortranarray(term.reshape(inner, nl, order="F")[:, b - lo:e + hi]).reshape(-1, order="F")
+            Jr, ir = c_oracle.backup_stage(_abi, spec, sub, slab=(b, e, lo, hi), nthreads=16)
+            with hjbdp.Backup(spec, slab=(b, e, lo, hi)) as bk:
+                Jg, ig = bk.backup_stage(sub)
+            n_runs += 1
+            own = slice(lo * inner, (lo + e - b) * inner)
+            if not (np.array_equal(Jg[own], Jr[own], equal_nan=True) and np.array_equal(ig, ir)):
+                print("SLAB MISMATCH", dict(D=D, C=C, n=n, m=m, seed=seed, kind=str(kind), slab=(b, e, lo, hi)), flush=True)
+                sys.exit(1)
+print("stress ok: %d problems, %d GPU runs, all bit-exact; (forced, ran) counts: %s" % (n_prob, n_runs, dict(sorted(seen.items(), key=str))))
