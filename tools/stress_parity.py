@@ -29,9 +29,27 @@ while time.time() < t_end:
     nonuniform = bool(rng.random() < 0.4)
     spread = float(rng.choice([0.02, 0.1, 0.3, 0.8]))
     seed = int(rng.integers(1 << 30))
-    kind = rng.choice(["nested", "nested_mixed", "random"]) if C <= D else "random"
+    kind = rng.choice(["nested", "nested_mixed", "random", "rowwise", "local2d"]) if C <= D else "random"
     try:
-        if kind == "random":
+        if kind == "local2d":         # every query within one cell of its state: hjb_solve's several-stages-per-launch path
+            from hjbdp import Term
+            D, C = 2, 1
+            n = (int(rng.integers(3, 90)), int(rng.integers(3, 90)))
+            kx, kv = np.linspace(-0.5, 0.5, n[0]), np.linspace(-0.4, 0.6, n[1])
+            hx, hv = kx[1] - kx[0], kv[1] - kv[0]
+            U = np.linspace(-0.26, 0.26, int(rng.integers(1, 6)))
+            m = (len(U),)
+            nxt = [[Term((0,), kx), Term((1,), 0.9 * hx * np.sin(3 * kv))],
+                   [Term((1,), kv), Term((0,), 0.4 * hv * np.cos(5 * kx)), Term((2,), 0.55 * hv * U / 0.26)]]
+            cost = [Term((0,), 6 * kx ** 2), Term((1,), 3 * kv ** 2), Term((2,), 0.1 * U ** 2), Term((0, 1), 0.05 * rng.random(n))]
+            spec = hjbdp.ProblemSpec([kx, kv], m, nxt, cost, dtype=dtype, index_base=1)
+        elif kind == "rowwise":       # no axis but axis 0 depends on state dim 0: variant 6 (lean form when it applies)
+            if D < 2:
+                continue
+            sp0 = nested_problem(seed, n, m, dtype=dtype, nonuniform=nonuniform, spread=spread)
+            nxt = [sp0.next_terms[0]] + [[t for t in sp0.next_terms[a] if 0 not in t.dims] for a in range(1, D)]
+            spec = hjbdp.ProblemSpec(sp0.knots, sp0.m, nxt, sp0.cost_terms, dtype=dtype, index_base=1)
+        elif kind == "random":
             spec = random_problem(seed, n, m, dtype=dtype, nonuniform=nonuniform)
         else:
             spec = nested_problem(seed, n, m, dtype=dtype, nonuniform=nonuniform, spread=spread,
@@ -43,6 +61,8 @@ while time.time() < t_end:
                                  j_storage=np.float16)
     term = random_terminal(spec, seed + 1)
     stages = int(rng.choice([1, 2, 5, 17, 40, 70]))
+    if kind == "local2d":
+        stages = int(rng.choice([16, 23, 40, 70, 129]))
     if spec.nS * spec.nU * stages > 4e7:
         stages = 2
     ref = c_oracle.sweep(_abi, spec, stages, terminal=term, nthreads=16)
