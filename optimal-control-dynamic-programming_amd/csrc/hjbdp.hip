@@ -71,6 +71,7 @@ struct Handle {
     bool use_graph = true;
     size_t packed_lds = 0;
     size_t packed2_lds = 0;       // variant 4 (two controls per packed op)
+    void *tile_plan = nullptr;    // K9 cached form: per (state, control) stage-invariant record (k_tile2d_plan)
     int tile2d = -1;              // K9 (several stages per launch, kernels_tile2d.h): -1 not examined yet, 0 no, 1 yes
     int use_temporal = 1;         // option "temporal": 0 off, 1 when applicable, 2 required (hjb_solve fails otherwise)
     bool row_ok = false;          // variant 6 (one wave per grid row) applies
@@ -645,6 +646,17 @@ int examine_tile2d_t(Handle *h) {
         }
     }
     h->tile2d = 1;
+    if (P.C == 1 && h->nU <= kTileMaxU) {          // the cached form: its per-(state, control) plan, built once
+        const int64_t ne = h->n_owned * h->nU;
+        void *d = nullptr;
+        st = dev_alloc(h, (size_t)ne * sizeof(TilePlan<T>), &d);
+        if (st) return st;
+        hipLaunchKernelGGL((k_tile2d_plan<T>), dim3((unsigned)std::min<int64_t>((ne + 255) / 256, 65536)), dim3(256), 0, nullptr,
+                           h->dp, h->dtb, (TilePlan<T> *)d);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipDeviceSynchronize());
+        h->tile_plan = d;
+    }
     return HJB_OK;
 }
 
@@ -656,11 +668,11 @@ int launch_tile2d(Handle *h, const void *dJn, void *dJo, int32_t *didx, int K, h
     const DParams &P = h->hp;
     const int tiles = ((P.n[0] + kTileX - 1) / kTileX) * ((P.n[1] + kTileY - 1) / kTileY);
     dim3 g(tiles), b(256);
-    const bool cached = P.C == 1 && h->nU <= kTileMaxU;     // stage-invariant per-control data kept in registers
+    const bool cached = h->tile_plan != nullptr;             // stage-invariant per-control data kept in registers
 #define HJB_LAUNCH_TILE(TT, TTJ)                                                                                       \
     do {                                                                                                               \
         if (cached)                                                                                                    \
-            hipLaunchKernelGGL((k_backup_tile2d_cached<TT, TTJ>), g, b, 0, st, h->dp, h->dtb, (const TTJ *)dJn, (TTJ *)dJo, didx, K); \
+            hipLaunchKernelGGL((k_backup_tile2d_cached<TT, TTJ>), g, b, 0, st, h->dp, (const TilePlan<TT> *)h->tile_plan, (const TTJ *)dJn, (TTJ *)dJo, didx, K); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_backup_tile2d<TT, TTJ>), g, b, 0, st, h->dp, h->dtb, (const TTJ *)dJn, (TTJ *)dJo, didx, K); \
     } while (0)

@@ -28,9 +28,44 @@ constexpr int kPatchX = kTileX + 2 * kTileK, kPatchY = kTileY + 2 * kTileK;
 constexpr int kTileMaxU = 4;
 constexpr int kTileStatesPerThread = (kPatchX * kPatchY + 255) / 256;
 
+// Everything a backup needs that does not change from stage to stage, per (state, control): built ONCE per problem
+// (k_tile2d_plan) so that a launch's prologue is a handful of independent coalesced loads instead of a chain of
+// table look-ups and cost-term evaluations per control.
+template <typename T> struct TilePlan { int32_t c0, c1; T w0, w1, g; };
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_tile2d_plan(const DParams *__restrict__ P, const DTabled *__restrict__ TB, TilePlan<T> *__restrict__ plan) {
+    const int n0 = P->n[0], n1 = P->n[1], nU = (int)P->nU;
+    gptr<TabEntry<T>> tab0 = as_global<TabEntry<T>>(TB->ax[0].tab), tab1 = as_global<TabEntry<T>>(TB->ax[1].tab);
+    const DTabled::Axis &A0 = TB->ax[0], &A1 = TB->ax[1];
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)n0 * n1 * nU;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int u = (int)(e % nU);
+        const int64_t st = e / nU;
+        const int gx = (int)(st % n0), gy = (int)(st / n0);
+        int si[2] = {gx, gy};
+        int cj[HJB_MAX_C] = {u, 0, 0};
+        const int o0 = A0.sstride[0] * gx + A0.sstride[1] * gy + A0.cstride[0] * u;
+        const int o1 = A1.sstride[0] * gx + A1.sstride[1] * gy + A1.cstride[0] * u;
+        TilePlan<T> pl;
+        pl.c0 = tab0[o0].cell;
+        pl.c1 = tab1[o1].cell;
+        pl.w0 = tab0[o0].t;
+        pl.w1 = tab1[o1].t;
+        T g = (T)0;
+        for (int k = 0; k < P->n_cost; ++k) {                    // left to right, like every other kernel
+            const T x = term_value<T, 2>(P->cost[k], si, cj);
+            g = (k == 0) ? x : (T)(g + x);
+        }
+        pl.g = g;
+        plan[e] = pl;
+    }
+}
+
 template <typename T, typename TJ>
 __global__ void __launch_bounds__(256)
-k_backup_tile2d_cached(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
+k_backup_tile2d_cached(const DParams *__restrict__ P, const TilePlan<T> *__restrict__ plan_, const TJ *__restrict__ Jn,
                        TJ *__restrict__ Jout, int32_t *__restrict__ idx_out, int K) {
     __shared__ T patch[2][kPatchY * kPatchX];
     const int n0 = P->n[0], n1 = P->n[1];
@@ -39,8 +74,7 @@ k_backup_tile2d_cached(const DParams *__restrict__ P, const DTabled *__restrict_
     const int px0 = tx0 - K, py0 = ty0 - K;
     const int pw = kTileX + 2 * K, ph = kTileY + 2 * K;
     const int nU = (int)P->nU;                               // <= kTileMaxU, C == 1 (checked on the host)
-    gptr<TabEntry<T>> tab0 = as_global<TabEntry<T>>(TB->ax[0].tab), tab1 = as_global<TabEntry<T>>(TB->ax[1].tab);
-    const DTabled::Axis &A0 = TB->ax[0], &A1 = TB->ax[1];
+    gptr<TilePlan<T>> plan = as_global<TilePlan<T>>(plan_);
 
     int gxs[kTileStatesPerThread], gys[kTileStatesPerThread];     // this thread's patch states (grid coordinates)
     bool live[kTileStatesPerThread];                              // inside the grid
@@ -60,19 +94,11 @@ k_backup_tile2d_cached(const DParams *__restrict__ P, const DTabled *__restrict_
             qoff[m][u] = 0;
             w0[m][u] = w1[m][u] = gc[m][u] = (T)0;
             if (live[m] && u < nU) {
-                int si[2] = {gx, gy};
-                int cj[HJB_MAX_C] = {u, 0, 0};
-                const int o0 = A0.sstride[0] * gx + A0.sstride[1] * gy + A0.cstride[0] * u;
-                const int o1 = A1.sstride[0] * gx + A1.sstride[1] * gy + A1.cstride[0] * u;
-                qoff[m][u] = (tab1[o1].cell - py0) * kPatchX + (tab0[o0].cell - px0);
-                w0[m][u] = tab0[o0].t;
-                w1[m][u] = tab1[o1].t;
-                T g = (T)0;
-                for (int k = 0; k < P->n_cost; ++k) {            // prefix terms first: the same left-to-right sum
-                    const T x = term_value<T, 2>(P->cost[k], si, cj);
-                    g = (k == 0) ? x : (T)(g + x);
-                }
-                gc[m][u] = g;
+                const int64_t e = ((int64_t)gx + (int64_t)n0 * gy) * nU + u;
+                qoff[m][u] = (plan[e].c1 - py0) * kPatchX + (plan[e].c0 - px0);
+                w0[m][u] = plan[e].w0;
+                w1[m][u] = plan[e].w1;
+                gc[m][u] = plan[e].g;
             }
         }
     }
