@@ -628,7 +628,9 @@ int examine_tile2d_t(Handle *h) {
     h->tile2d = 0;
     const DParams &P = h->hp;
     if (P.D != 2 || h->j_elems != h->n_owned || !h->tabled_ok || h->hp.model) return HJB_OK;
-    if (h->dom_entries[0] + h->dom_entries[1] > ((int64_t)1 << 26)) return HJB_OK;
+    // few controls only (the launch-bound channels this is for), and tables small enough that checking them on the
+    // host costs nothing next to the sweep
+    if (h->nU > 64 || h->dom_entries[0] + h->dom_entries[1] > ((int64_t)1 << 24)) return HJB_OK;
     int st = ensure_tabled(h);
     if (st) return st;
     for (int a = 0; a < 2; ++a) {
