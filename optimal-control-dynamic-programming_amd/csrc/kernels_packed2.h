@@ -527,7 +527,90 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 for (int a = 0; a < D - 1; ++a) b += js[a] * cell[a];
                 return b;
             };
-            for (int o1 = 0; o1 < m_o1; ++o1, ++uo) {
+            int o1 = 0;
+            // ---- modes 1-3, TWO (o0, o1) steps per trip ---------------------------------------------------
+            // When every cell change of the wave is a wave-uniform first crossing (UX == 0: the C2 and attitude
+            // shapes) and both steps stay inside the prepared window, steps o1 and o1+1 share one pass over the
+            // control pairs: one read of (t, r2), one set of loop/segment bookkeeping, two running minima.  Per
+            // element the arithmetic is unchanged, and step o1 is compared with `best` before step o1+1: same bits,
+            // same first-minimum.  Anything else falls through to the one-step loop below.
+            if constexpr (HIER) {
+                if (UX == 0u && !slow_a) {
+                    while (o1 + 1 < m_o1) {
+                        const i2v eA = e_nx, eB = tb1[(o1 + 1) * tb1_step];
+                        const int rA = eA.x - c1min, rB = eB.x - c1min;
+                        if (__any(!((rA == 0 || rA == 1) && (rB == 0 || rB == 1)))) break;   // e_nx, g_nx still belong to o1
+                        const float gA = g_nx, gB = level1_cost(o1 + 1);
+                        if (o1 + 2 < m_o1) {
+                            e_nx = tb1[(o1 + 2) * tb1_step];
+                            g_nx = level1_cost(o1 + 2);
+                        }
+                        float a0[2], ad[2], b0[2], bd[2];                        // (E0, dE) first / second cell, per step
+#pragma unroll
+                        for (int sI = 0; sI < 2; ++sI) {
+                            const bool up = (sI == 0 ? rA : rB) != 0;
+                            const float t1 = __int_as_float(sI == 0 ? eA.y : eB.y);
+                            float X[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float f0 = up ? F[1][q] : F[0][q];
+                                const float f1 = up ? F[2][q] : F[1][q];
+                                X[q] = __builtin_fmaf(t1, f1 - f0, f0);
+                            }
+                            a0[sI] = X[0]; ad[sI] = X[1] - X[0];
+                            b0[sI] = X[2]; bd[sI] = X[3] - X[2];
+                        }
+                        float cA0 = a0[0], cAd = ad[0], cB0 = a0[1], cBd = ad[1];   // current cell's (E0, dE) of step A / B
+                        const f2 gA2 = {gA, gA}, gB2 = {gB, gB};
+                        float mA = INFINITY, mB = INFINITY;
+                        int pA = 0, pB = 0;
+                        f2 t = my_t[0];
+                        f2 r2 = s_r2[0];
+                        int p = 0;
+                        while (p < npairs) {
+                            const unsigned int rest = PU >> p;
+                            const int pstop = rest ? p + __builtin_ctz(rest) : npairs;
+                            const f2 eA0v = {cA0, cA0}, eAdv = {cAd, cAd}, eB0v = {cB0, cB0}, eBdv = {cBd, cBd};
+#pragma unroll 2
+                            for (; p < pstop; ++p) {
+                                const f2 totA = (gA2 + r2) + __builtin_elementwise_fma(t, eAdv, eA0v);
+                                const f2 totB = (gB2 + r2) + __builtin_elementwise_fma(t, eBdv, eB0v);
+                                t = my_t[(p + 1) * 256];
+                                r2 = s_r2[p + 1];
+                                const float nA = __builtin_fminf(mA, __builtin_fminf(totA.x, totA.y));
+                                const float nB = __builtin_fminf(mB, __builtin_fminf(totB.x, totB.y));
+                                pA = (nA == mA) ? pA : p;
+                                pB = (nB == mB) ? pB : p;
+                                mA = nA;
+                                mB = nB;
+                            }
+                            if (p < npairs) {                                    // the wave changes cell inside this pair
+                                const int jb = 2 * p;
+                                if ((UA >> jb) & 1u) { cA0 = b0[0]; cAd = bd[0]; cB0 = b0[1]; cBd = bd[1]; }
+                                float yA0 = cA0, yAd = cAd, yB0 = cB0, yBd = cBd;
+                                if ((UA >> (jb + 1)) & 1u) { yA0 = b0[0]; yAd = bd[0]; yB0 = b0[1]; yBd = bd[1]; }
+                                const f2 totA = (gA2 + r2) + __builtin_elementwise_fma(t, (f2){cAd, yAd}, (f2){cA0, yA0});
+                                const f2 totB = (gB2 + r2) + __builtin_elementwise_fma(t, (f2){cBd, yBd}, (f2){cB0, yB0});
+                                cA0 = yA0; cAd = yAd; cB0 = yB0; cBd = yBd;
+                                t = my_t[(p + 1) * 256];
+                                r2 = s_r2[p + 1];
+                                const float nA = __builtin_fminf(mA, __builtin_fminf(totA.x, totA.y));
+                                const float nB = __builtin_fminf(mB, __builtin_fminf(totB.x, totB.y));
+                                pA = (nA == mA) ? pA : p;
+                                pB = (nB == mB) ? pB : p;
+                                mA = nA;
+                                mB = nB;
+                                ++p;
+                            }
+                        }
+                        if (uo == 0 || mA < best) { best = mA; best_uo = uo; best_ip = pA; }
+                        if (mB < best) { best = mB; best_uo = uo + 1; best_ip = pB; }
+                        o1 += 2;
+                        uo += 2;
+                    }
+                }
+            }
+            for (; o1 < m_o1; ++o1, ++uo) {
                 // ---- level 1: (E0, dE) of the two last-axis cells this state visits ----------
                 float e0a, dea, e0b, deb;
                 if constexpr (HIER) {
