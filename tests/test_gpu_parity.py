@@ -685,3 +685,13 @@ def test_temporal_blocking_refused_when_not_local(env):
         with pytest.raises(hjbdp.HjbError) as ei:
             bk.solve(20)
         assert ei.value.status == _abi.HJB_E_UNSUPPORTED
+
+
+def test_randomised_stress_slice(env):
+    """20 seconds of tools/stress_parity.py (random shapes, every applicable stage-kernel variant, multi-stage paths,
+    slabs): everything that stays finite must equal the oracle bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "20", "5"],
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
