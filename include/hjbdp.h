@@ -163,7 +163,7 @@ int32_t hjb_destroy(hjb_handle h);
 /* text of the last error on this handle (h may be NULL: last create error) */
 const char *hjb_last_error(hjb_handle h);
 int32_t hjb_get_info(hjb_handle h, hjb_info *info);
-/* tuning/testing knobs: "variant" (-1 automatic, 0..6 force a stage kernel; HJB_E_UNSUPPORTED when it does not
+/* tuning/testing knobs: "variant" (-1 automatic, 0..7 force a stage kernel; HJB_E_UNSUPPORTED when it does not
  * apply), "graph" (0/1: hipGraph replay inside hjb_solve), "temporal" (several stages per launch inside hjb_solve
  * for local 2-D problems, kernels_tile2d.h: 0 off, 1 when applicable [default], 2 required), "row_lean" (0/1: lean form of
  * stage kernel 6), "lds_pad" (extra dynamic LDS bytes per workgroup: occupancy experiments) */

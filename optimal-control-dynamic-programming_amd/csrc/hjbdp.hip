@@ -26,6 +26,7 @@
 #include "kernels_tabled.h"
 #include "kernels_rowwise.h"
 #include "kernels_tile2d.h"
+#include "kernels_colsweep.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -86,6 +87,10 @@ struct Handle {
     DTabled htb{};
     DTabled *dtb = nullptr;
     size_t nested_lds = 0;
+    int cs_state = -1;            // variant 7 (column sweep, kernels_colsweep.h): -1 not examined, 0 does not apply, 1 plan built
+    DColSweep hcs{};
+    DColSweep *dcs = nullptr;
+    int cs_tile2 = 8, cs_tile3 = 8;
     int variant = 0;
     int forced_variant = -1;
     int block = 256, grid = 0;
@@ -620,6 +625,143 @@ int ensure_tabled(Handle *h) {
     return h->dtype != HJB_F64 ? ensure_tabled_t<float>(h) : ensure_tabled_t<double>(h);
 }
 
+// ---- variant 7 (kernels_colsweep.h): eligibility + the per-(i2, i3) plan, built once on the host from the
+// variant-5 tables of axes 2 and 3 (tiny: n2 * n3 * nU entries) --------------------------------------------------
+template <typename T>
+bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2], const std::vector<std::vector<T>> &cu,
+                   std::vector<int32_t> &plan, int64_t *rows_total, int *ng_max) {
+    static_assert(sizeof(T) == 4, "plan words are 32-bit");
+    const DParams &P = h->hp;
+    const int n2 = P.n[2], n3 = P.n[3], nU = (int)h->nU, wax = 5 - gax;
+    const int64_t gs = P.jstride[gax], ws = P.jstride[wax];
+    plan.assign((size_t)n2 * n3 * kCsPlanWords, 0);
+    *rows_total = 0;
+    *ng_max = 1;
+    auto bits = [](T x) { int32_t b; memcpy(&b, &x, 4); return b; };
+    for (int i3 = 0; i3 < n3; ++i3) {
+        for (int i2 = 0; i2 < n2; ++i2) {
+            int32_t *q = &plan[(size_t)(i2 + n2 * i3) * kCsPlanWords];
+            struct Grp { int cg, wmin, wmax, n, mem[kCsMMax]; };
+            Grp grp[kCsGMax];
+            int ng = 0, bad = 0;
+            int cc[2][kCsUMax];
+            T tt[2][kCsUMax];
+            for (int u = 0; u < nU; ++u) {
+                for (int a = 2; a < 4; ++a) {
+                    const DTabled::Axis &A = h->htb.ax[a];
+                    const TabEntry<T> &e = tab[a - 2][(size_t)(A.sstride[2] * i2 + A.sstride[3] * i3 + A.cstride[0] * u)];
+                    int c = e.cell;
+                    if (a == 3) {                       // global plane -> plane of this handle's J buffers
+                        c -= h->plane0;
+                        if (c < 0 || c + 1 >= h->nplanes) { bad = 1; c = c < 0 ? 0 : h->nplanes - 2; }
+                    }
+                    cc[a - 2][u] = c;
+                    tt[a - 2][u] = e.t;
+                }
+                const int cg = cc[gax - 2][u], cw = cc[wax - 2][u];
+                int g = 0;
+                for (; g < ng; ++g)
+                    if (grp[g].cg == cg && grp[g].n < kCsMMax && std::max(grp[g].wmax, cw) - std::min(grp[g].wmin, cw) + 2 <= kCsNW) break;
+                if (g == ng) {
+                    if (ng == kCsGMax) return false;
+                    grp[ng].cg = cg; grp[ng].wmin = grp[ng].wmax = cw; grp[ng].n = 0;
+                    ++ng;
+                }
+                grp[g].wmin = std::min(grp[g].wmin, cw);
+                grp[g].wmax = std::max(grp[g].wmax, cw);
+                grp[g].mem[grp[g].n++] = u;
+            }
+            *ng_max = std::max(*ng_max, ng);
+            q[0] = bad;
+            int umax_seen = -1;
+            for (int g = 0; g < kCsGMax; ++g) {
+                const Grp &G = grp[g < ng ? g : 0];                 // padding: a member-less copy of group 0's rows
+                const int64_t off = (gs * G.cg + ws * G.wmin) * (int64_t)h->esz;
+                const int nw = G.wmax - G.wmin + 2;
+                q[1 + g] = (int32_t)(uint32_t)off;
+                q[1 + kCsGMax + g] = nw | ((g < ng ? G.n : 0) << 8);
+                if (g >= ng) continue;
+                *rows_total += 2 * nw;
+                for (int m = 0; m < G.n; ++m) {
+                    const int u = G.mem[m];
+                    const int tie = u < umax_seen ? 1 : 0;          // visited after a higher-numbered control
+                    umax_seen = std::max(umax_seen, u);
+                    int32_t *sl = q + kCsPI + 8 * (g * kCsMMax + m);
+                    sl[0] = bits(tt[wax - 2][u]);
+                    sl[1] = bits(tt[gax - 2][u]);
+                    sl[3] = u | ((cc[wax - 2][u] - G.wmin) << 8) | (tie << 16);
+                    for (size_t k = 0; k < cu.size(); ++k) sl[k == 0 ? 2 : 3 + k] = bits(cu[k][(size_t)u]);
+                }
+            }
+        }
+    }
+    return true;
+}
+
+template <typename T>
+int ensure_colsweep_t(Handle *h) {
+    if (h->cs_state >= 0) return HJB_OK;
+    h->cs_state = 0;
+    const DParams &P = h->hp;
+    if (P.D != 4 || P.C != 1 || P.model || !h->tabled_ok || h->nU > kCsUMax) return HJB_OK;
+    if (h->j_elems * (int64_t)h->esz >= ((int64_t)1 << 32) || h->n_owned >= ((int64_t)1 << 31)) return HJB_OK;
+    const uint32_t cbit = 1u << 4;
+    if ((h->dom_mask[0] & (cbit | 2u)) || (h->dom_mask[1] & (cbit | 1u)) || (h->dom_mask[2] & 3u) || (h->dom_mask[3] & 3u)) return HJB_OK;
+    const int ncu = P.n_cost - P.n_cost_prefix;
+    if (ncu > kCsMaxCu) return HJB_OK;
+    for (int k = P.n_cost_prefix; k < P.n_cost; ++k)
+        if (h->prob.cost_terms[k].mask != cbit) return HJB_OK;
+    int npre_col = 0;
+    while (npre_col < P.n_cost_prefix && (h->prob.cost_terms[npre_col].mask & 2u) == 0) ++npre_col;
+    bool step_uniform = true;
+    for (int k = npre_col; k < P.n_cost_prefix; ++k) step_uniform = step_uniform && (h->prob.cost_terms[k].mask & 1u) == 0;
+    int st = ensure_tabled(h);
+    if (st) return st;
+    std::vector<TabEntry<T>> tab[2];
+    for (int a = 2; a < 4; ++a) {
+        tab[a - 2].resize((size_t)h->dom_entries[a]);
+        HIP_TRY(h, hipMemcpy(tab[a - 2].data(), h->htb.ax[a].tab, tab[a - 2].size() * sizeof(TabEntry<T>), hipMemcpyDeviceToHost));
+    }
+    std::vector<std::vector<T>> cu((size_t)ncu, std::vector<T>((size_t)h->nU));
+    for (int k = 0; k < ncu; ++k)
+        HIP_TRY(h, hipMemcpy(cu[(size_t)k].data(), P.cost[P.n_cost_prefix + k].data, (size_t)h->nU * sizeof(T), hipMemcpyDeviceToHost));
+    // group by the axis that leaves fewer corner rows to load
+    std::vector<int32_t> plan[2];
+    int64_t rows[2] = {0, 0};
+    int ngm[2] = {1, 1};
+    const bool ok3 = colsweep_plan<T>(h, 3, tab, cu, plan[1], &rows[1], &ngm[1]);
+    const bool ok2 = colsweep_plan<T>(h, 2, tab, cu, plan[0], &rows[0], &ngm[0]);
+    if (!ok2 && !ok3) return HJB_OK;
+    const int pick = (ok3 && (!ok2 || ngm[1] < ngm[0] || (ngm[1] == ngm[0] && rows[1] <= rows[0]))) ? 1 : 0;
+    DColSweep &CSh = h->hcs;
+    memset(&CSh, 0, sizeof CSh);
+    CSh.gax = pick ? 3 : 2;
+    CSh.ng = ngm[pick];
+    void *d = nullptr;
+    st = upload(h, plan[pick], &d);
+    if (st) return st;
+    CSh.plan = (const int32_t *)d;
+    CSh.npre_col = npre_col;
+    CSh.step_uniform = step_uniform ? 1 : 0;
+    CSh.ncu = ncu;
+    CSh.g_bytes = (uint32_t)(P.jstride[CSh.gax] * (int64_t)h->esz);
+    CSh.w_bytes = (uint32_t)(P.jstride[5 - CSh.gax] * (int64_t)h->esz);
+    CSh.s1_bytes = (uint32_t)(P.jstride[1] * (int64_t)h->esz);
+    CSh.tile2 = h->cs_tile2;
+    CSh.tile3 = h->cs_tile3;
+    st = dev_alloc(h, sizeof(DColSweep), &d);
+    if (st) return st;
+    h->dcs = (DColSweep *)d;
+    HIP_TRY(h, hipMemcpy(h->dcs, &CSh, sizeof(DColSweep), hipMemcpyHostToDevice));
+    h->cs_state = 1;
+    return HJB_OK;
+}
+
+int ensure_colsweep(Handle *h) {
+    if (h->dtype == HJB_F64) { if (h->cs_state < 0) h->cs_state = 0; return HJB_OK; }   // float32 arithmetic only
+    return ensure_colsweep_t<float>(h);
+}
+
 // K9 applies when, for every state and control, each axis' interpolation cell is the state's own cell or the one
 // below (clamped to the grid): then J_k at a state depends on J_{k+1} within +-1 cell only.  Checked on the host
 // from the variant-5 tables (small: 2-D problems only).
@@ -690,11 +832,19 @@ void choose_launch(Handle *h) {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     // few states x many controls (Kirk): one wave per state, controls across lanes
     const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
+    // variant 7 (column sweep) wants what variant 6 wants - long axis-0 rows on a large grid - plus its own structure;
+    // its plan is built here (never inside a launch: launches may be under graph capture)
+    bool cs_auto = false;
+    if (h->hp.D == 4 && h->hp.C == 1 && !h->hp.model && (h->forced_variant == 7 || (h->forced_variant < 0 && h->row_auto && !h->packed_mode && !h->nested_ok && !want_split))) {
+        if (h->cs_state < 0 && ensure_colsweep(h) != HJB_OK) h->cs_state = 0;
+        cs_auto = h->cs_state == 1;
+    }
     h->variant = h->forced_variant >= 0 ? h->forced_variant
-                                        : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0)))));
+                                        : (h->packed_mode ? 4 : (h->nested_ok ? 1 : (want_split ? 3 : (cs_auto ? 7 : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0))))));
     if (h->hp.model) h->variant = 4;
-    if (h->dtype == HJB_F16S && h->variant >= 1 && h->variant <= 3)     // float16 J storage: variants 0, 4, 5 only
-        h->variant = h->forced_variant >= 0 ? h->forced_variant : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0));
+    if (h->dtype == HJB_F16S && h->variant >= 1 && h->variant <= 3)     // float16 J storage: variants 0, 4, 5, 6, 7 only
+        h->variant = h->forced_variant >= 0 ? h->forced_variant : (cs_auto ? 7 : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0)));
+    if (h->variant == 7 && h->cs_state != 1) h->variant = h->row_ok ? 6 : (h->tabled_ok ? 5 : 0);
     // build the variant 5/6 tables now (never inside a launch: launches may be under graph capture)
     if ((h->variant == 5 || h->variant == 6) && ensure_tabled(h) != HJB_OK) h->variant = 0;
     h->block = 256;
@@ -707,6 +857,13 @@ void choose_launch(Handle *h) {
         const int64_t items = (h->n_owned / n0) * ((n0 + 63) / 64);
         h->grid = (int)std::min<int64_t>((items + 3) / 4, 256 * 16);
     }
+    if (h->variant == 7) {       // one wave per (64-state chunk of axis 0, i2, i3) column, (i2, i3) in padded tiles
+        const DParams &P = h->hp;
+        const int64_t chunks = (P.n[0] + 63) / 64;
+        const int64_t p2 = (int64_t)((P.n[2] + h->hcs.tile2 - 1) / h->hcs.tile2) * h->hcs.tile2;
+        const int64_t p3 = (int64_t)((P.n[3] + h->hcs.tile3 - 1) / h->hcs.tile3) * h->hcs.tile3;
+        h->grid = (int)((chunks * p2 * p3 + 3) / 4);
+    }
     if (h->grid < 1) h->grid = 1;
 }
 
@@ -715,6 +872,31 @@ int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t
     constexpr bool same = std::is_same<T, TJ>::value;   // variants 1-3 exist for J stored in the arithmetic type only
     const int D = h->hp.D;
     dim3 g(h->grid), b(h->block);
+    if (h->variant == 7) {
+        if (!h->dtb || !h->dcs) return fail(h, HJB_E_DEVICE, "variant 7 plan missing");
+        if constexpr (std::is_same<T, float>::value) {
+#define HJB_LAUNCH_CS(NG)                                                                                              \
+    case NG:                                                                                                           \
+        if (fastcost) {                                                                                                \
+            if (h->hcs.gax == 3) hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 3, NG, true>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
+            else hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 2, NG, true>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
+        } else {                                                                                                       \
+            if (h->hcs.gax == 3) hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 3, NG, false>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
+            else hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 2, NG, false>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
+        }                                                                                                              \
+        break;
+            const bool fastcost = h->hcs.ncu == 1 && h->hp.n_cost_prefix > 0;    // state terms + one control term
+            switch (h->hcs.ng) {
+                HJB_LAUNCH_CS(1) HJB_LAUNCH_CS(2) HJB_LAUNCH_CS(3) HJB_LAUNCH_CS(4) HJB_LAUNCH_CS(5) HJB_LAUNCH_CS(6)
+                default: return fail(h, HJB_E_DEVICE, "variant 7: %d groups", h->hcs.ng);
+            }
+#undef HJB_LAUNCH_CS
+            HIP_TRY(h, hipGetLastError());
+            return HJB_OK;
+        } else {
+            return fail(h, HJB_E_UNSUPPORTED, "variant 7 is float32 arithmetic only");
+        }
+    }
     if (h->variant == 6) {
         if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 6 tables missing");
         const bool lean = h->row_lean && h->row_lean_ok && !h->htb.ax[0].has_ctrl;
@@ -1097,7 +1279,15 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     std::shared_lock<std::shared_mutex> lk(g_capture_mu);     // may build tables (allocation, device sync)
     if (!strcmp(key, "variant")) {
-        if (value < -1 || value > 6) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value < -1 || value > 7) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
+        if (value == 7) {
+            const int cst = ensure_colsweep(h);
+            if (cst) return cst;
+            if (h->cs_state != 1)
+                return fail(h, HJB_E_UNSUPPORTED, "variant 7 (column sweep) needs D = 4, one control dim, float32 arithmetic, axes 0/1 "
+                            "independent of the control (and of each other's state dim), axes 2/3 depending on state dims 2, 3 and the "
+                            "control only, control terms of the cost involving the control only, and <= %d groups of corner rows per (i2, i3)", kCsGMax);
+        }
         if (value == 6 && !h->row_ok)
             return fail(h, HJB_E_UNSUPPORTED, "variant 6 (one wave per grid row) needs D >= 2, per-axis tables that fit, and "
                         "no axis other than axis 0 depending on state dim 0");
@@ -1117,13 +1307,26 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         choose_launch(h);
         return HJB_OK;
     }
+    if (!strcmp(key, "cs_tile2") || !strcmp(key, "cs_tile3")) {      // variant 7 traversal tile over (i2, i3)
+        if (value < 1 || value > 1024) return fail(h, HJB_E_INVALID, "%s out of range", key);
+        (key[7] == '2' ? h->cs_tile2 : h->cs_tile3) = (int)value;
+        if (h->cs_state == 1) {
+            h->hcs.tile2 = h->cs_tile2;
+            h->hcs.tile3 = h->cs_tile3;
+            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            choose_launch(h);
+        }
+        return HJB_OK;
+    }
     if (!strcmp(key, "lds_pad")) {
         if (value < 0 || value > 128 * 1024) return fail(h, HJB_E_INVALID, "lds_pad out of range");
         h->lds_pad = (size_t)value;
+        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the captured launches carry the old LDS size
         return HJB_OK;
     }
     if (!strcmp(key, "row_lean")) {
         h->row_lean = value != 0;
+        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the captured launches are the other form
         return HJB_OK;
     }
     if (!strcmp(key, "temporal")) {

@@ -42,6 +42,12 @@ def vectors_allcomb(f1, f2, f3, f4):
 
 
 class Solver_pos_att:
+    # Relabelling of the state axes (x, v, theta, w) -> (x, theta, v, w) for large grids: the two axes whose next value
+    # does not depend on the thrusters (x+ over (x, v), theta+ over (theta, w), :299-328) come first, which is the
+    # shape of libhjbdp's column-sweep stage kernel (csrc/kernels_colsweep.h).  Pure bookkeeping: the 1-D lerps of the
+    # interpolation are taken in the new order (results agree with the reference order to a few ulp).
+    FAST_AXIS_ORDER = (0, 2, 1, 3)
+
     def __init__(self):
         # Solver_pos_att.m:96-195
         self.v_min, self.v_max, self.n_mesh_v = -0.1, 0.1, 30
@@ -72,6 +78,7 @@ class Solver_pos_att:
         self.monitor_period = 50      # :273
         self.monitor_tol = 1e-2       # :269
         self.cost_mode = "exact"
+        self.axis_order = None        # e.g. FAST_AXIS_ORDER: sweep on relabelled axes, results mapped back
         self.device = 0
         self.controllers = {}
 
@@ -118,9 +125,24 @@ class Solver_pos_att:
                                     n_stages=None, progress=None):
         spec, combos = self.build_channel_spec(s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw, R, J)
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
-        with Backup(spec, device=self.device) as bk:
+        run_spec, to_old = self._relabel(spec)
+        with Backup(run_spec, device=self.device) as bk:
             out = bk.solve(n_st, monitor_period=self.monitor_period, monitor_tol=self.monitor_tol, progress=progress)
+        out = self._map_back(out, to_old)
         return self._store_controller(file_name, (s_x, s_v, s_t, s_w), spec.n, combos, out)
+
+    def _relabel(self, spec):
+        if self.axis_order is None:
+            return spec, None
+        from .problem import permute_state_axes
+        return permute_state_axes(spec, self.axis_order)
+
+    @staticmethod
+    def _map_back(out, to_old):
+        if to_old is not None:
+            out = dict(out)
+            out["J"], out["idx"] = to_old(out["J"]), to_old(out["idx"])
+        return out
 
     def _store_controller(self, file_name, grids, shape, combos, out):
         self.controllers[file_name] = {                                  # save(file_name, ...) :289
@@ -188,9 +210,10 @@ class Solver_pos_att:
         ]
         built = [self.build_channel_spec(*args) for args, _ in jobs]
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
-        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device,
+        rel = [self._relabel(b[0]) for b in built]
+        outs, self.wall_ms, _ = solve_many([r[0] for r in rel], n_st, device=self.device,
                                            monitor_period=self.monitor_period, monitor_tol=self.monitor_tol,
                                            progress=progress)
-        for (args, name), (spec, combos), out in zip(jobs, built, outs):
-            self._store_controller(name, args[:4], spec.n, combos, out)
+        for (args, name), (spec, combos), out, r in zip(jobs, built, outs, rel):
+            self._store_controller(name, args[:4], spec.n, combos, self._map_back(out, r[1]))
         return self

@@ -98,3 +98,49 @@ def nested_problem(seed, n, m, dtype=np.float32, nonuniform=False, spread=0.2, m
     for c in range(C):
         cost.append(Term((D + c,), 0.3 * rng.standard_normal(m[c]) ** 2))
     return ProblemSpec(knots, m, nxt, cost[:12], dtype=dtype, index_base=1)
+
+
+def colsweep_problem(seed, n, nU=9, nonuniform=False, gax=3, big=2.7, small=0.6, cost="fast", a1_amp=0.6, levels=5,
+                     dtype=np.float32, index_base=1, j_storage=None):
+    """The shape of the column-sweep stage kernel (variant 7, kernels_colsweep.h; pos-att with the axes relabelled
+    (x, theta, v, w)): D = 4, one control dim; axes 0 and 1 move with the state only (axis 0 over dims {0,2,3}, axis 1
+    over dims {1,2,3}); axes 2 and 3 move with the control - the "group" axis `gax` by `big` cells times one of
+    `levels` distinct values, the other ("window") axis by less than `small` < 1 cells.  a1_amp > 1 makes the axis-1
+    cell jump irregularly along a column (re-priming path).  cost: 'fast' (state terms, the dim-1 term last, one
+    control term), 'step01' (first term over dims (0,1): nothing is column-invariant, per-step term not uniform),
+    'multi' (two control-only terms), 'ctrl_only' (no state term at all)."""
+    rng = np.random.default_rng(seed)
+    assert len(n) == 4
+    knots = []
+    for a in range(4):
+        if nonuniform:
+            k = np.cumsum(rng.uniform(0.6, 1.4, n[a]))
+            k = (k - k[0]) / (k[-1] - k[0]) * 2.0 - 1.0
+        else:
+            k = np.linspace(-1.0, 1.0, n[a])
+        knots.append(k.astype(dtype).astype(np.float64))
+    hs = [2.0 / (n[a] - 1) for a in range(4)]
+    wax = 5 - gax
+    lev = np.linspace(-1.0, 1.0, levels) if levels > 1 else np.zeros(1)
+    d = lev[rng.permutation(nU) % levels]                       # group-axis displacement level of each control
+    c = rng.uniform(-1.0, 1.0, nU)                              # window-axis displacement of each control
+    nxt = [None] * 4
+    nxt[0] = [Term((0,), knots[0].copy()), Term((2,), 0.7 * hs[0] * rng.uniform(-1, 1, n[2])),
+              Term((3,), 0.25 * hs[0] * rng.uniform(-1, 1, n[3]))]
+    nxt[1] = [Term((1,), knots[1].copy()), Term((3,), a1_amp * hs[1] * rng.uniform(-1, 1, n[3])),
+              Term((2,), 0.2 * hs[1] * rng.uniform(-1, 1, n[2]))]
+    nxt[gax] = [Term((gax,), knots[gax].copy()), Term((4,), big * hs[gax] * d)]
+    nxt[wax] = [Term((wax,), knots[wax].copy()), Term((4,), small * hs[wax] * c)]
+    cu = 0.3 * np.round(rng.uniform(0, 3, nU)) ** 2             # repeated values: exact ties between controls
+    st = {a: Term((a,), (1.0 + a) * knots[a] ** 2) for a in range(4)}
+    if cost == "fast":
+        ct = [st[0], st[2], st[3], st[1], Term((4,), cu)]
+    elif cost == "step01":
+        ct = [Term((0, 1), 0.1 * rng.random((n[0], n[1]))), st[2], st[3], Term((4,), cu)]
+    elif cost == "multi":
+        ct = [st[0], st[1], st[3], Term((4,), cu), Term((4,), 0.1 * rng.random(nU))]
+    elif cost == "ctrl_only":
+        ct = [Term((4,), cu)]
+    else:
+        raise ValueError(cost)
+    return ProblemSpec(knots, [nU], nxt, ct, dtype=dtype, index_base=index_base, j_storage=j_storage)

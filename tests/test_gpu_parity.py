@@ -207,6 +207,95 @@ def test_rowwise_variant_pos_att_slab_and_f16(env):
     assert np.array_equal(oh["J"], rh["J"]) and np.array_equal(oh["idx"], rh["idx"])
 
 
+COLSWEEP = [
+    # n, nU, nonuniform, gax, cost, a1_amp, levels, j_storage, terminal
+    ((70, 9, 8, 11), 9, False, 3, "fast", 0.6, 5, None, True),       # two chunks of axis 0 (64 + 6)
+    ((64, 7, 9, 12), 9, True, 3, "fast", 0.6, 5, None, False),       # zero terminal: every first-stage total ties
+    ((33, 10, 12, 7), 9, True, 2, "fast", 0.5, 5, None, True),       # group axis = axis 2, window = the last axis
+    ((5, 4, 3, 4), 6, False, 3, "fast", 0.6, 3, None, True),         # tiny
+    ((40, 13, 6, 9), 9, True, 3, "fast", 1.8, 5, None, True),        # axis-1 cells jump: re-priming inside a column
+    ((37, 6, 7, 10), 12, False, 3, "multi", 0.6, 4, None, True),     # two control-only cost terms
+    ((37, 6, 7, 10), 9, True, 2, "step01", 0.6, 5, None, True),      # per-step cost term over (dim 0, dim 1)
+    ((20, 6, 7, 10), 7, False, 3, "ctrl_only", 0.6, 6, None, True),  # no state cost term; 6 groups
+    ((66, 8, 9, 10), 9, True, 3, "fast", 0.6, 5, "f16", True),       # float16 cost-to-go storage
+    ((30, 8, 9, 10), 16, False, 3, "fast", 0.6, 5, None, True),      # 16 controls: groups split at 3 members
+]
+
+
+@pytest.mark.parametrize("n,nU,nonuniform,gax,cost,a1_amp,levels,j_storage,terminal", COLSWEEP)
+def test_colsweep_variant_bit_exact(env, n, nU, nonuniform, gax, cost, a1_amp, levels, j_storage, terminal):
+    """Variant 7 (column sweep, kernels_colsweep.h): the two control-independent lerps once per corner row, rolling
+    along axis 1; controls grouped by the cell of the group axis.  Bit-exact J and argmin against the oracle."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, random_terminal
+    spec = colsweep_problem(700 + n[0] + nU, n, nU=nU, nonuniform=nonuniform, gax=gax, cost=cost, a1_amp=a1_amp,
+                            levels=levels, j_storage=np.float16 if j_storage else None)
+    term = random_terminal(spec, 11) if terminal else None
+    ref = c_oracle.sweep(_abi, spec, 3, terminal=term, keep_J=True, keep_idx=True)
+    with hjbdp.Backup(spec, variant=7) as bk:
+        assert bk.info()["kernel_variant"] == 7
+        out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
+        for t2, t3 in ((1, 1), (5, 3)):                      # ragged traversal tiles give the same result
+            bk.set_option("cs_tile2", t2)
+            bk.set_option("cs_tile3", t3)
+            o2 = bk.solve(3, terminal=term)
+            assert np.array_equal(o2["J"], ref["J"]) and np.array_equal(o2["idx"], ref["idx"]), (t2, t3)
+    assert np.array_equal(out["J_stages"], ref["J_stages"])
+    assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+
+
+@pytest.mark.parametrize("gax", [2, 3])
+def test_colsweep_variant_slab(env, gax):
+    """Variant 7 on a slab of the last axis with halos (the multi-GPU form): gax = 2 shards the window axis (halo of
+    one or two planes), gax = 3 the group axis (a halo as wide as the largest control displacement)."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, random_terminal
+    spec = colsweep_problem(41 + gax, (36, 7, 9, 14) if gax == 3 else (36, 7, 14, 9), gax=gax, nonuniform=True)
+    term = random_terminal(spec, 2)
+    with hjbdp.Backup(spec, variant=7) as bk:
+        need = bk.info()
+    b, e = 4, 8 if gax == 3 else 7
+    hl, hh = min(need["halo_needed_lo"], b), min(need["halo_needed_hi"], spec.n[-1] - e)
+    inner = spec.nS // spec.n[-1]
+    sub = np.asfortranarray(term.reshape(inner, -1, order="F")[:, b - hl:e + hh]).reshape(-1, order="F")
+    Jr, ir = c_oracle.backup_stage(_abi, spec, sub, slab=(b, e, hl, hh))
+    with hjbdp.Backup(spec, slab=(b, e, hl, hh), variant=7) as bk:
+        assert bk.info()["kernel_variant"] == 7
+        Jg, ig = bk.backup_stage(sub)
+    assert np.array_equal(Jg, Jr) and np.array_equal(ig, ir)
+    # no halo at all: reported, never silent
+    sub2 = np.asfortranarray(term.reshape(inner, -1, order="F")[:, b:e]).reshape(-1, order="F")
+    with hjbdp.Backup(spec, slab=(b, e, 0, 0), variant=7) as bk:
+        with pytest.raises(hjbdp.HjbError) as ei:
+            bk.backup_stage(sub2)
+        assert ei.value.status == _abi.HJB_E_HALO
+
+
+def test_colsweep_variant_refused_when_not_applicable(env):
+    """pos-att in the reference's axis order (x, v, theta, w): axis 1 (v) moves with the control -> not variant 7's shape."""
+    hjbdp, _abi, c_oracle = env
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = "terms"
+    sx, sv, st, sw = pa.grids()
+    spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                    pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    with hjbdp.Backup(spec) as bk:
+        with pytest.raises(hjbdp.HjbError):
+            bk.set_option("variant", 7)
+    # relabelled (x, theta, v, w) it applies, and agrees with the oracle on the relabelled problem bit for bit
+    pspec, to_old = hjbdp.permute_state_axes(spec, (0, 2, 1, 3))
+    ref = c_oracle.sweep(_abi, pspec, 4)
+    with hjbdp.Backup(pspec, variant=7) as bk:
+        assert bk.info()["kernel_variant"] == 7
+        out = bk.solve(4)
+    assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+    # and with the reference order to rounding (the lerp order differs: a few ulp), same policy almost everywhere
+    ref0 = c_oracle.sweep(_abi, spec, 4)
+    J_old = to_old(out["J"])
+    assert np.max(np.abs(J_old - ref0["J"])) <= 2e-6 * np.max(np.abs(ref0["J"]))
+    assert np.mean(to_old(out["idx"]) == ref0["idx"]) > 0.999
+
+
 PACKED = [
     ((9, 8), (3,), False, "inc"),
     ((40, 37), (7,), True, "dec"),                 # > 512 states, odd tail

@@ -258,6 +258,42 @@ def test_c4_full_size_plane_vs_oracle(env):
     assert np.array_equal(io, idx.reshape(n3, 120, order="F")[:, p])
 
 
+@pytest.mark.parametrize("j_storage", [None, np.float16])
+def test_c4_c5_full_size_colsweep_plane_vs_oracle(env, j_storage):
+    """BASELINE configs[3] and [4] (C4: pos-att 120^4 x 9 float32; C5: the same with float16 cost-to-go storage) on the
+    kernel that is meant for them: the axes relabelled (x, theta, v, w) select the column-sweep stage kernel
+    (variant 7) automatically; one stage from a smooth terminal cost, and one whole plane of the last axis is
+    recomputed by the oracle (slab + halos) and must match bit for bit."""
+    hjbdp, _abi, c_oracle = env
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = "terms"
+    pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = 120
+    sx, sv, st, sw = pa.grids()
+    spec0, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                     pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    spec, _ = hjbdp.permute_state_axes(spec0, hjbdp.Solver_pos_att.FAST_AXIS_ORDER)
+    if j_storage is not None:
+        spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=1,
+                                 j_storage=j_storage)
+    assert spec.nS == 120 ** 4 and spec.n == (120, 120, 120, 120)
+    X, T, V = np.meshgrid(sx, st[0], sv, indexing="ij")
+    inner = (np.sin(7 * X) + 3 * V ** 2 + np.cos(5 * T)).astype(np.float32).reshape(-1, order="F")
+    term = (inner[:, None] * (1.0 + 10.0 * sw[None, :] ** 2).astype(np.float32)).astype(spec.j_dtype)   # [120^3, 120]
+    with hjbdp.Backup(spec) as bk:
+        need = bk.info()
+        assert need["kernel_variant"] == 7
+        J, idx = bk.backup_stage(term.reshape(-1, order="F"))
+    hl, hh = need["halo_needed_lo"], need["halo_needed_hi"]
+    assert 6 <= hl <= 9 and 6 <= hh <= 9            # w moves up to ~7.6 cells per stage on this fine grid
+    n3 = 120 ** 3
+    for p in (0, 61, 119):                          # both edges (clamped cells) and the interior
+        lo, hi = min(hl, p), min(hh, 119 - p)
+        sub = np.asfortranarray(term[:, p - lo:p + 1 + hi]).reshape(-1, order="F")
+        Jo, io = c_oracle.backup_stage(_abi, spec, sub, slab=(p, p + 1, lo, hi))
+        assert np.array_equal(Jo.reshape(n3, -1, order="F")[:, lo], J.reshape(n3, 120, order="F")[:, p]), p
+        assert np.array_equal(io, idx.reshape(n3, 120, order="F")[:, p]), p
+
+
 def test_solver_position_closed_loop_rollout(env):
     """Solver_position.get_optimal_path (:189-311): the policies of simplified_run fly the chaser from 1 km behind
     the target towards it: full positive thrust first (x = -1 lies below the grid: 'nearest' clamps to its edge),
