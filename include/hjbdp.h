@@ -110,9 +110,28 @@ typedef struct hjb_problem {
 typedef struct hjb_handle_s *hjb_handle;
 
 /* optional progress callback, replaces fprintf/waitbar in the stage loops
- * (Dynamic_Solver.m:101, Solver_pos_att.m:278): called at monitor points with
- * the reference's k_s, e = d(sum J), e2 = d(sum idx), elapsed seconds. */
+ * (Dynamic_Solver.m:101, Solver_pos_att.m:278): called at monitor points (and, with
+ * hjb_solve_opts.progress_every_stage, after every stage) with the reference's k_s,
+ * e = d(sum J), e2 = d(sum idx), elapsed seconds. */
 typedef void (*hjb_progress_fn)(void *user, int32_t k_s, double e, double e2, double seconds);
+
+/* Optional probe block = the reference's debug taps (test/Dynamic_Solver.m:212-219, `checkstagesXJF`): per stage the
+ * reference copies the fixed sub-block (50:55, 52:57, 105) of J_current_state, X_next_M1, X_next_M2 (and, commented
+ * out, of J_F_next) into *_check(:,:,k).  Here: any rectangular sub-block of states [lo, hi) (0-based, half open -
+ * 50:55 is lo 49, hi 55) at ONE control (0-based index per control dim - 105 is 104).  With B = prod(hi - lo) block
+ * states in column-major order, plane k_s - 1 of each output holds stage k_s (as J_stages does):
+ *   g        [B, n_stages]     the stage cost g(x, u)                      (J_current_state_check)
+ *   x_next   [B, D, n_stages]  the next-state coordinate of every axis     (X_next_M1_check, X_next_M2_check, ...)
+ *   j_interp [B, n_stages]     J_{k+1} interpolated at x_next              (J_F_next_check)
+ * all in the problem's arithmetic dtype (float for HJB_F16S); any of the three may be NULL. */
+typedef struct hjb_probe {
+    int32_t lo[HJB_MAX_D], hi[HJB_MAX_D];
+    int32_t control[HJB_MAX_C];
+    int32_t reserved;
+    void *g;
+    void *x_next;
+    void *j_interp;
+} hjb_probe;
 
 typedef struct hjb_solve_opts {
     int32_t n_stages;        /* number of backups: N-1 (Dynamic_Solver.m:86), N_stage-1 */
@@ -127,6 +146,10 @@ typedef struct hjb_solve_opts {
     int32_t *idx_stages;     /* out [nS * n_stages] or NULL (Dynamic_Solver.m:100)      */
     hjb_progress_fn progress;
     void *progress_user;
+    const hjb_probe *probe;  /* NULL = no debug taps (Dynamic_Solver.m:212-219)                    */
+    int32_t progress_every_stage; /* 0: progress is called at monitor points only; 1: after every stage (the reference
+                                     prints per stage, Dynamic_Solver.m:101; e, e2 are then 0 between monitor points) */
+    int32_t reserved;
 } hjb_solve_opts;
 
 typedef struct hjb_result {
@@ -168,6 +191,10 @@ int32_t hjb_get_info(hjb_handle h, hjb_info *info);
  * for local 2-D problems, kernels_tile2d.h: 0 off, 1 when applicable [default], 2 required), "row_lean" (0/1: lean form of
  * stage kernel 6), "lds_pad" (extra dynamic LDS bytes per workgroup: occupancy experiments) */
 int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
+/* read a knob back, plus what the column-sweep kernel (variant 7) settled on: "cs_dpp" (1: one load per corner row, the
+ * upper axis-0 neighbour taken from the next lane), "cs_groups", "cs_group_axis".  "cs_dpp" and "cs_xcd_mod" (residue
+ * modulus of the column -> XCD assignment: 0/1 contiguous ranges, -1 the group spacing) are also settable (testing, tuning). */
+int32_t hjb_get_option(hjb_handle h, const char *key, int64_t *value);
 
 /* ONE backup, host buffers (exactly the MATLAB statement above):
  * J_next [j_elems] -> J_out [j_elems] (owned planes written), idx_out [n_states]. */
@@ -193,6 +220,46 @@ int32_t hjb_solve(hjb_handle h, const hjb_solve_opts *opts, hjb_result *result);
 #define HJB_LOOKUP_LINEAR 1
 int32_t hjb_policy_lookup(int32_t device, int32_t dtype, int32_t D, const int32_t *n, const double *const *knots,
                           const void *values, int64_t nq, const void *queries, int32_t method, void *out);
+
+/* One stage of the probe block from a host J_next (for host-driven stage loops): same outputs as hjb_probe, one
+ * plane each (g [B], x_next [B, D], j_interp [B]).  J_next may be NULL when j_interp is NULL. */
+int32_t hjb_probe_stage(hjb_handle h, const void *J_next, const hjb_probe *probe);
+
+/* ---- flat builder API -------------------------------------------------------------------------------------------
+ * hjb_problem holds arrays of structs with pointers, which MATLAB's loadlibrary/calllib cannot marshal.  These entry
+ * points take primitives and plain arrays only, copy what they are given (the caller may free it at once), and end in
+ * hjb_create_from, after which the handle is used exactly like one from hjb_create.  They replace, for a MATLAB host,
+ * the table building of the reference's run methods (test/Dynamic_Solver.m:66-84: grid vectors, a_D_M, g_D):
+ *   hjb_problem_new(D, C, n, m, dtype, index_base, &b)
+ *   hjb_problem_set_knots(b, axis, knots, len)                      once per state axis
+ *   hjb_problem_add_next_term(b, axis, mask, data, count)           in MATLAB's left-to-right order of the sum
+ *   hjb_problem_add_cost_term(b, mask, data, count)
+ *   [hjb_problem_set_slab(b, begin, end, halo_lo, halo_hi)]  [hjb_problem_set_model(b, model, h, t0, t1, t2, t3)]
+ *   hjb_create_from(b, device, &h);  hjb_problem_free(b)
+ * data: `count` elements of the problem dtype (float for HJB_F32 / HJB_F16S, double for HJB_F64), column-major over
+ * the masked grid dims; count must equal the product of their sizes. */
+typedef struct hjb_builder_s *hjb_builder;
+int32_t hjb_problem_new(int32_t D, int32_t C, const int32_t *n, const int32_t *m, int32_t dtype, int32_t index_base,
+                        hjb_builder *out);
+int32_t hjb_problem_set_knots(hjb_builder b, int32_t axis, const double *knots, int32_t len);
+int32_t hjb_problem_add_next_term(hjb_builder b, int32_t axis, uint32_t mask, const void *data, int64_t count);
+int32_t hjb_problem_add_cost_term(hjb_builder b, uint32_t mask, const void *data, int64_t count);
+int32_t hjb_problem_set_slab(hjb_builder b, int32_t slab_begin, int32_t slab_end, int32_t halo_lo, int32_t halo_hi);
+int32_t hjb_problem_set_model(hjb_builder b, int32_t model, double model_h, const void *t0, const void *t1,
+                              const void *t2, const void *t3);
+int32_t hjb_create_from(hjb_builder b, int32_t device, hjb_handle *out);
+int32_t hjb_problem_free(hjb_builder b);
+/* text of the last error of a builder call (b may be NULL) */
+const char *hjb_problem_last_error(hjb_builder b);
+
+/* hjb_solve without structs: every argument a scalar or a plain array (NULL where hjb_solve_opts allows NULL);
+ * the three result scalars may be NULL.  No progress callback, no probe. */
+int32_t hjb_solve_flat(hjb_handle h, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
+                       void *J_final, int32_t *idx_final, void *J_stages, int32_t *idx_stages, int32_t *stages_done,
+                       int32_t *stopped_early, double *sweep_ms);
+/* hjb_get_info without the struct: out[0..7] = n_states, n_controls, j_elems, kernel_variant, lds_bytes, grid,
+ * halo_needed_lo, halo_needed_hi */
+int32_t hjb_get_info_flat(hjb_handle h, int64_t *out8);
 
 #ifdef __cplusplus
 }

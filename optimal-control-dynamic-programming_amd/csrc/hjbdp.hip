@@ -27,6 +27,7 @@
 #include "kernels_rowwise.h"
 #include "kernels_tile2d.h"
 #include "kernels_colsweep.h"
+#include "kernels_probe.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -90,8 +91,10 @@ struct Handle {
     int cs_state = -1;            // variant 7 (column sweep, kernels_colsweep.h): -1 not examined, 0 does not apply, 1 plan built
     DColSweep hcs{};
     DColSweep *dcs = nullptr;
-    int cs_tile2 = 8, cs_tile3 = 8;
+    int cs_xcd_mod = 0;           // option "cs_xcd_mod": 0 = automatic (see colsweep_map)
+    int cs_dpp = 1;               // option "cs_dpp": allow the DPP form of variant 7 when the axis-0 cells permit it
     int variant = 0;
+    int launch_status = HJB_OK;   // status of the table build inside choose_launch
     int forced_variant = -1;
     int block = 256, grid = 0;
     int halo_need_lo = 0, halo_need_hi = 0;
@@ -634,6 +637,8 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
     const DParams &P = h->hp;
     const int n2 = P.n[2], n3 = P.n[3], nU = (int)h->nU, wax = 5 - gax;
     const int64_t gs = P.jstride[gax], ws = P.jstride[wax];
+    const int nwk = wax == 3 ? h->nplanes : P.n[wax];        // knots of the window axis present in this handle's J buffers
+    if (nwk < 3) return false;
     plan.assign((size_t)n2 * n3 * kCsPlanWords, 0);
     *rows_total = 0;
     *ng_max = 1;
@@ -641,7 +646,9 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
     for (int i3 = 0; i3 < n3; ++i3) {
         for (int i2 = 0; i2 < n2; ++i2) {
             int32_t *q = &plan[(size_t)(i2 + n2 * i3) * kCsPlanWords];
-            struct Grp { int cg, wmin, wmax, n, mem[kCsMMax]; };
+            // a group: the cell cg of the group axis, window knots wmin .. wmin + 2 of the other axis, member slots
+            // [0, MMAX/2) (window cell wmin) and [MMAX/2, MMAX) (window cell wmin + 1)
+            struct Grp { int cg, wmin, slot[kCsMMax]; };
             Grp grp[kCsGMax];
             int ng = 0, bad = 0;
             int cc[2][kCsUMax];
@@ -658,44 +665,138 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
                     cc[a - 2][u] = c;
                     tt[a - 2][u] = e.t;
                 }
+            }
+            // windows per group-axis cell: the smallest uncovered window cell opens a window of two cells
+            for (int u = 0; u < nU; ++u) {
                 const int cg = cc[gax - 2][u], cw = cc[wax - 2][u];
+                int wmin = cw;                              // the window this control belongs to: greedy cover, walked
+                {                                           // from the smallest window cell among the controls of cg
+                    int start = cw;
+                    for (int v = 0; v < nU; ++v) if (cc[gax - 2][v] == cg) start = std::min(start, cc[wax - 2][v]);
+                    for (;;) {
+                        if (cw <= start + 1) { wmin = start; break; }
+                        int nxt = cw;                       // the next uncovered cell opens the next window
+                        for (int v = 0; v < nU; ++v)
+                            if (cc[gax - 2][v] == cg && cc[wax - 2][v] > start + 1) nxt = std::min(nxt, cc[wax - 2][v]);
+                        start = nxt;
+                    }
+                }
+                // three knots wmin .. wmin + 2 must exist: the last window of the axis starts one knot lower
+                if (wmin + 2 > nwk - 1) wmin = nwk - 3;
+                const int pair = cw - wmin;                 // 0 or 1
+                constexpr int PS = kCsMMax / 2;             // slots per window pair
+                auto free_slot = [&](const Grp &G) {
+                    for (int s = pair * PS; s < (pair + 1) * PS; ++s) if (G.slot[s] < 0) return s;
+                    return -1;
+                };
                 int g = 0;
                 for (; g < ng; ++g)
-                    if (grp[g].cg == cg && grp[g].n < kCsMMax && std::max(grp[g].wmax, cw) - std::min(grp[g].wmin, cw) + 2 <= kCsNW) break;
+                    if (grp[g].cg == cg && grp[g].wmin == wmin && free_slot(grp[g]) >= 0) break;
                 if (g == ng) {
                     if (ng == kCsGMax) return false;
-                    grp[ng].cg = cg; grp[ng].wmin = grp[ng].wmax = cw; grp[ng].n = 0;
+                    grp[ng].cg = cg; grp[ng].wmin = wmin;
+                    for (int s = 0; s < kCsMMax; ++s) grp[ng].slot[s] = -1;
                     ++ng;
                 }
-                grp[g].wmin = std::min(grp[g].wmin, cw);
-                grp[g].wmax = std::max(grp[g].wmax, cw);
-                grp[g].mem[grp[g].n++] = u;
+                grp[g].slot[free_slot(grp[g])] = u;
             }
             *ng_max = std::max(*ng_max, ng);
-            q[0] = bad;
-            int umax_seen = -1;
+            q[0] = bad | (ng << 8);
             for (int g = 0; g < kCsGMax; ++g) {
                 const Grp &G = grp[g < ng ? g : 0];                 // padding: a member-less copy of group 0's rows
                 const int64_t off = (gs * G.cg + ws * G.wmin) * (int64_t)h->esz;
-                const int nw = G.wmax - G.wmin + 2;
+                const int nw = 3;
+                int usedbits = 0;
                 q[1 + g] = (int32_t)(uint32_t)off;
-                q[1 + kCsGMax + g] = nw | ((g < ng ? G.n : 0) << 8);
-                if (g >= ng) continue;
-                *rows_total += 2 * nw;
-                for (int m = 0; m < G.n; ++m) {
-                    const int u = G.mem[m];
-                    const int tie = u < umax_seen ? 1 : 0;          // visited after a higher-numbered control
-                    umax_seen = std::max(umax_seen, u);
-                    int32_t *sl = q + kCsPI + 8 * (g * kCsMMax + m);
-                    sl[0] = bits(tt[wax - 2][u]);
-                    sl[1] = bits(tt[gax - 2][u]);
-                    sl[3] = u | ((cc[wax - 2][u] - G.wmin) << 8) | (tie << 16);
-                    for (size_t k = 0; k < cu.size(); ++k) sl[k == 0 ? 2 : 3 + k] = bits(cu[k][(size_t)u]);
+                if (g < ng) {
+                    *rows_total += 2 * nw;
+                    for (int sidx = 0; sidx < kCsMMax; ++sidx) {
+                        const int u = G.slot[sidx];
+                        if (u < 0) continue;
+                        usedbits |= 1 << sidx;
+                        int32_t *sl = q + kCsPI + 8 * (g * kCsMMax + sidx);
+                        sl[0] = bits(tt[wax - 2][u]);
+                        sl[1] = bits(tt[gax - 2][u]);
+                        sl[3] = u;
+                        for (size_t k = 0; k < cu.size(); ++k) sl[k == 0 ? 2 : 3 + k] = bits(cu[k][(size_t)u]);
+                    }
                 }
+                q[1 + kCsGMax + g] = usedbits | (nw << 8);
             }
         }
     }
     return true;
+}
+
+// Column -> XCD assignment of variant 7 (DColSweep::xcd_ig): group-axis indices sorted by (index mod M, index), cut
+// into 8 equal parts.  Default M = 1: plain contiguous ranges; option "cs_xcd_mod" sets M, -1 = the spacing of the
+// groups' cells in a mid-grid plan.
+int colsweep_map(Handle *h, const std::vector<int32_t> &plan) {
+    const DParams &P = h->hp;
+    DColSweep &CSh = h->hcs;
+    const int gax = CSh.gax, n2 = P.n[2], n3 = P.n[3];
+    const int ngx = P.n[gax];
+    int M = h->cs_xcd_mod;
+    if (M == 0) M = 1;           // measured on C4 (120^4 x 9): contiguous ranges 2.67 ms per stage, residue classes of the
+                                 // group spacing (cs_xcd_mod = -1) 2.84 ms
+    if (M < 0) {
+        // spacing of the distinct group cells of the middle column, from the row offsets of its plan
+        const int32_t *q = &plan[(size_t)(n2 / 2 + n2 * (n3 / 2)) * kCsPlanWords];
+        const int ng = q[0] >> 8;
+        const int64_t gb = P.jstride[gax] * (int64_t)h->esz, wb = P.jstride[5 - gax] * (int64_t)h->esz;
+        std::vector<int64_t> cells;
+        for (int g = 0; g < ng; ++g) {
+            // row offset = gs * cg + ws * wmin (bytes): the group-axis cell is the quotient by the larger stride
+            const int64_t off = (uint32_t)q[1 + g];
+            cells.push_back(gax == 3 ? off / gb : (off % wb) / gb);
+        }
+        std::sort(cells.begin(), cells.end());
+        cells.erase(std::unique(cells.begin(), cells.end()), cells.end());
+        int64_t best = 0;
+        for (size_t i = 1; i < cells.size(); ++i) best = best == 0 ? cells[i] - cells[i - 1] : std::min(best, cells[i] - cells[i - 1]);
+        M = (int)std::max<int64_t>(1, std::min<int64_t>(best, ngx));
+    }
+    std::vector<int> order((size_t)ngx);
+    for (int i = 0; i < ngx; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (a % M) < (b % M); });
+    const int stride = (ngx + 7) / 8;
+    std::vector<int32_t> tab((size_t)8 * stride, 0);
+    for (int x = 0; x < 8; ++x) {
+        const int b = (int)((int64_t)ngx * x / 8), e = (int)((int64_t)ngx * (x + 1) / 8);
+        CSh.xcd_cnt[x] = e - b;
+        for (int i = b; i < e; ++i) tab[(size_t)x * stride + (i - b)] = order[(size_t)i];
+    }
+    CSh.xcd_stride = stride;
+    void *d = nullptr;
+    const int st = upload(h, tab, &d);
+    if (st) return st;
+    CSh.xcd_ig = (const int32_t *)d;
+    return HJB_OK;
+}
+
+// DPP form of variant 7: every wave of kCsDppLanes consecutive axis-0 states must have (cell - state index) within two
+// adjacent values, so that lane L's two neighbours are among the knots lanes L .. L + 2 load.
+template <typename T>
+int colsweep_dpp_ok(Handle *h, bool *ok) {
+    const DParams &P = h->hp;
+    const DTabled::Axis &A0 = h->htb.ax[0];
+    std::vector<TabEntry<T>> tab((size_t)h->dom_entries[0]);
+    HIP_TRY(h, hipMemcpy(tab.data(), A0.tab, tab.size() * sizeof(TabEntry<T>), hipMemcpyDeviceToHost));
+    const int n0 = P.n[0];
+    const int r2 = A0.sstride[2] ? P.n[2] : 1, r3 = A0.sstride[3] ? P.n[3] : 1;
+    *ok = true;
+    for (int i3 = 0; i3 < r3 && *ok; ++i3)
+        for (int i2 = 0; i2 < r2 && *ok; ++i2)
+            for (int c = 0; c < n0 && *ok; c += kCsDppLanes) {
+                int mn = INT32_MAX, mx = INT32_MIN;
+                for (int i0 = c; i0 < std::min(n0, c + kCsDppLanes); ++i0) {
+                    const int rel = tab[(size_t)(A0.sstride[0] * i0 + A0.sstride[2] * i2 + A0.sstride[3] * i3)].cell - i0;
+                    mn = std::min(mn, rel);
+                    mx = std::max(mx, rel);
+                }
+                if (mx - mn > 1) *ok = false;
+            }
+    return HJB_OK;
 }
 
 template <typename T>
@@ -747,8 +848,14 @@ int ensure_colsweep_t(Handle *h) {
     CSh.g_bytes = (uint32_t)(P.jstride[CSh.gax] * (int64_t)h->esz);
     CSh.w_bytes = (uint32_t)(P.jstride[5 - CSh.gax] * (int64_t)h->esz);
     CSh.s1_bytes = (uint32_t)(P.jstride[1] * (int64_t)h->esz);
-    CSh.tile2 = h->cs_tile2;
-    CSh.tile3 = h->cs_tile3;
+    st = colsweep_map(h, plan[pick]);
+    if (st) return st;
+    {
+        bool dok = false;
+        st = colsweep_dpp_ok<T>(h, &dok);
+        if (st) return st;
+        CSh.dpp = (dok && h->cs_dpp) ? 1 : 0;
+    }
     st = dev_alloc(h, sizeof(DColSweep), &d);
     if (st) return st;
     h->dcs = (DColSweep *)d;
@@ -846,7 +953,8 @@ void choose_launch(Handle *h) {
         h->variant = h->forced_variant >= 0 ? h->forced_variant : (cs_auto ? 7 : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0)));
     if (h->variant == 7 && h->cs_state != 1) h->variant = h->row_ok ? 6 : (h->tabled_ok ? 5 : 0);
     // build the variant 5/6 tables now (never inside a launch: launches may be under graph capture)
-    if ((h->variant == 5 || h->variant == 6) && ensure_tabled(h) != HJB_OK) h->variant = 0;
+    h->launch_status = HJB_OK;
+    if ((h->variant == 5 || h->variant == 6) && (h->launch_status = ensure_tabled(h)) != HJB_OK) h->variant = 0;
     h->block = 256;
     h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
     const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass (variant 4: 256)
@@ -857,12 +965,14 @@ void choose_launch(Handle *h) {
         const int64_t items = (h->n_owned / n0) * ((n0 + 63) / 64);
         h->grid = (int)std::min<int64_t>((items + 3) / 4, 256 * 16);
     }
-    if (h->variant == 7) {       // one wave per (64-state chunk of axis 0, i2, i3) column, (i2, i3) in padded tiles
+    if (h->variant == 7) {       // one wave per (chunk of axis 0, i2, i3) column; workgroup b serves XCD b % 8
         const DParams &P = h->hp;
-        const int64_t chunks = (P.n[0] + 63) / 64;
-        const int64_t p2 = (int64_t)((P.n[2] + h->hcs.tile2 - 1) / h->hcs.tile2) * h->hcs.tile2;
-        const int64_t p3 = (int64_t)((P.n[3] + h->hcs.tile3 - 1) / h->hcs.tile3) * h->hcs.tile3;
-        h->grid = (int)((chunks * p2 * p3 + 3) / 4);
+        const int lanes = h->hcs.dpp ? kCsDppLanes : 64;
+        const int64_t chunks = (P.n[0] + lanes - 1) / lanes;
+        const int64_t nwax = P.n[5 - h->hcs.gax];
+        int64_t most = 0;
+        for (int x = 0; x < 8; ++x) most = std::max<int64_t>(most, (int64_t)h->hcs.xcd_cnt[x] * chunks * nwax);
+        h->grid = (int)(8 * ((most + 3) / 4));
     }
     if (h->grid < 1) h->grid = 1;
 }
@@ -875,21 +985,23 @@ int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t
     if (h->variant == 7) {
         if (!h->dtb || !h->dcs) return fail(h, HJB_E_DEVICE, "variant 7 plan missing");
         if constexpr (std::is_same<T, float>::value) {
+#define HJB_LAUNCH_CS2(NG, FC, DP)                                                                                     \
+    do {                                                                                                               \
+        if (h->hcs.gax == 3) hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 3, NG, FC, DP>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
+        else hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 2, NG, FC, DP>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
+    } while (0)
 #define HJB_LAUNCH_CS(NG)                                                                                              \
     case NG:                                                                                                           \
-        if (fastcost) {                                                                                                \
-            if (h->hcs.gax == 3) hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 3, NG, true>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
-            else hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 2, NG, true>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
-        } else {                                                                                                       \
-            if (h->hcs.gax == 3) hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 3, NG, false>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
-            else hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 2, NG, false>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
-        }                                                                                                              \
+        if (fastcost) { if (dppf) HJB_LAUNCH_CS2(NG, true, true); else HJB_LAUNCH_CS2(NG, true, false); }              \
+        else { if (dppf) HJB_LAUNCH_CS2(NG, false, true); else HJB_LAUNCH_CS2(NG, false, false); }                     \
         break;
             const bool fastcost = h->hcs.ncu == 1 && h->hp.n_cost_prefix > 0;    // state terms + one control term
+            const bool dppf = h->hcs.dpp != 0;
             switch (h->hcs.ng) {
                 HJB_LAUNCH_CS(1) HJB_LAUNCH_CS(2) HJB_LAUNCH_CS(3) HJB_LAUNCH_CS(4) HJB_LAUNCH_CS(5) HJB_LAUNCH_CS(6)
                 default: return fail(h, HJB_E_DEVICE, "variant 7: %d groups", h->hcs.ng);
             }
+#undef HJB_LAUNCH_CS2
 #undef HJB_LAUNCH_CS
             HIP_TRY(h, hipGetLastError());
             return HJB_OK;
@@ -1073,6 +1185,50 @@ int check_status(Handle *h, hipStream_t st) {
     return HJB_OK;
 }
 
+// ---- probe block (Dynamic_Solver.m:212-219) -------------------------------------------------------------------
+int make_probe(Handle *h, const hjb_probe *pb, DProbe *out) {
+    if (h->hp.model) return fail(h, HJB_E_UNSUPPORTED, "the probe block is not available for problems with a state model");
+    memset(out, 0, sizeof *out);
+    int64_t B = 1;
+    for (int a = 0; a < h->hp.D; ++a) {
+        if (pb->lo[a] < 0 || pb->hi[a] > h->prob.n[a] || pb->lo[a] >= pb->hi[a])
+            return fail(h, HJB_E_INVALID, "probe block [%d, %d) on axis %d of %d points (the reference's taps 50:55, 52:57 need dx >= 57, "
+                        "Dynamic_Solver.m:213)", pb->lo[a], pb->hi[a], a, h->prob.n[a]);
+        out->lo[a] = pb->lo[a];
+        out->ext[a] = pb->hi[a] - pb->lo[a];
+        B *= out->ext[a];
+    }
+    for (int c = 0; c < HJB_MAX_C; ++c) {
+        const int mc = c < h->hp.C ? h->prob.m[c] : 1;
+        if (c < h->hp.C && (pb->control[c] < 0 || pb->control[c] >= mc))
+            return fail(h, HJB_E_INVALID, "probe control index %d on control dim %d of %d levels (the reference's tap 105 needs du >= 105)",
+                        pb->control[c], c, mc);
+        out->control[c] = c < h->hp.C ? pb->control[c] : 0;
+    }
+    if (B > ((int64_t)1 << 24)) return fail(h, HJB_E_INVALID, "probe block of %lld states is too large", (long long)B);
+    out->B = B;
+    return HJB_OK;
+}
+
+int launch_probe(Handle *h, const DProbe &pr, const void *dJn, hipStream_t st) {
+    dim3 g((unsigned)std::min<int64_t>((pr.B + 255) / 256, 4096)), b(256);
+#define HJB_LAUNCH_PROBE(TT, TTJ)                                                                                     \
+    switch (h->hp.D) {                                                                                                \
+        case 1: hipLaunchKernelGGL((k_probe<TT, TTJ, 1>), g, b, 0, st, h->dp, pr, (const TTJ *)dJn); break;            \
+        case 2: hipLaunchKernelGGL((k_probe<TT, TTJ, 2>), g, b, 0, st, h->dp, pr, (const TTJ *)dJn); break;            \
+        case 3: hipLaunchKernelGGL((k_probe<TT, TTJ, 3>), g, b, 0, st, h->dp, pr, (const TTJ *)dJn); break;            \
+        case 4: hipLaunchKernelGGL((k_probe<TT, TTJ, 4>), g, b, 0, st, h->dp, pr, (const TTJ *)dJn); break;            \
+        case 5: hipLaunchKernelGGL((k_probe<TT, TTJ, 5>), g, b, 0, st, h->dp, pr, (const TTJ *)dJn); break;            \
+        default: hipLaunchKernelGGL((k_probe<TT, TTJ, 6>), g, b, 0, st, h->dp, pr, (const TTJ *)dJn); break;           \
+    }
+    if (h->dtype == HJB_F16S) { HJB_LAUNCH_PROBE(float, _Float16) }
+    else if (h->dtype == HJB_F32) { HJB_LAUNCH_PROBE(float, float) }
+    else { HJB_LAUNCH_PROBE(double, double) }
+#undef HJB_LAUNCH_PROBE
+    HIP_TRY(h, hipGetLastError());
+    return HJB_OK;
+}
+
 }  // namespace
 
 template <typename T>
@@ -1088,7 +1244,12 @@ int policy_lookup_t(int32_t D, const int32_t *n, const double *const *knots, con
         std::vector<T> kk(n[a]), rdx(n[a]);
         for (int i = 0; i < n[a]; ++i) kk[i] = (T)knots[a][i];
         for (int i = 0; i + 1 < n[a]; ++i) {
-            if (!(kk[i + 1] > kk[i])) { g_last_error = "lookup: knots not strictly increasing"; return HJB_E_INVALID; }
+            if (!(kk[i + 1] > kk[i])) {
+                for (void *d : h->allocs) (void)hipFree(d);      // the axes uploaded so far
+                h->allocs.clear();
+                g_last_error = "lookup: knots not strictly increasing";
+                return HJB_E_INVALID;
+            }
             rdx[i] = (T)1 / (T)(kk[i + 1] - kk[i]);
         }
         rdx[n[a] - 1] = (T)0;
@@ -1305,14 +1466,35 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             return fail(h, HJB_E_UNSUPPORTED, "variant 1 (control-nested) needs: only the last state axis depends on the innermost control dim");
         h->forced_variant = (int)value;
         choose_launch(h);
+        if (value >= 0 && h->variant != (int)value) {      // e.g. the tables of a forced variant 5/6 could not be built
+            const int lst = h->launch_status != HJB_OK ? h->launch_status : HJB_E_UNSUPPORTED;
+            h->forced_variant = -1;
+            choose_launch(h);
+            return fail(h, lst, "variant %lld could not be set up (%s); the automatic choice is in effect", (long long)value,
+                        h->err.empty() ? "not applicable" : h->err.c_str());
+        }
         return HJB_OK;
     }
-    if (!strcmp(key, "cs_tile2") || !strcmp(key, "cs_tile3")) {      // variant 7 traversal tile over (i2, i3)
-        if (value < 1 || value > 1024) return fail(h, HJB_E_INVALID, "%s out of range", key);
-        (key[7] == '2' ? h->cs_tile2 : h->cs_tile3) = (int)value;
+    if (!strcmp(key, "cs_dpp")) {                                    // 0: variant 7 loads both axis-0 neighbours (testing)
+        h->cs_dpp = value != 0;
         if (h->cs_state == 1) {
-            h->hcs.tile2 = h->cs_tile2;
-            h->hcs.tile3 = h->cs_tile3;
+            bool dok = false;
+            const int cst = colsweep_dpp_ok<float>(h, &dok);
+            if (cst) return cst;
+            h->hcs.dpp = (dok && h->cs_dpp) ? 1 : 0;
+            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            choose_launch(h);
+        }
+        return HJB_OK;
+    }
+    if (!strcmp(key, "cs_xcd_mod")) {      // variant 7: residue modulus of the column -> XCD assignment (0 = automatic)
+        if (value < -1 || value > 4096) return fail(h, HJB_E_INVALID, "%s out of range", key);
+        h->cs_xcd_mod = (int)value;
+        if (h->cs_state == 1) {
+            std::vector<int32_t> plan((size_t)h->hp.n[2] * h->hp.n[3] * kCsPlanWords);
+            HIP_TRY(h, hipMemcpy(plan.data(), h->hcs.plan, plan.size() * 4, hipMemcpyDeviceToHost));
+            const int cst = colsweep_map(h, plan);
+            if (cst) return cst;
             HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
             choose_launch(h);
         }
@@ -1339,6 +1521,22 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         return HJB_OK;
     }
     return fail(h, HJB_E_INVALID, "unknown option '%s'", key);
+}
+
+int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
+    Handle *h = (Handle *)hh;
+    if (!h || !key || !value) return fail(h, HJB_E_INVALID, "null argument");
+    if (!strcmp(key, "variant")) *value = h->variant;
+    else if (!strcmp(key, "graph")) *value = h->use_graph ? 1 : 0;
+    else if (!strcmp(key, "temporal")) *value = h->use_temporal;
+    else if (!strcmp(key, "row_lean")) *value = h->row_lean ? 1 : 0;
+    else if (!strcmp(key, "lds_pad")) *value = (int64_t)h->lds_pad;
+    else if (!strcmp(key, "cs_xcd_mod")) *value = h->cs_xcd_mod;
+    else if (!strcmp(key, "cs_dpp")) *value = (h->variant == 7 && h->hcs.dpp) ? 1 : 0;          // the form in effect
+    else if (!strcmp(key, "cs_groups")) *value = h->variant == 7 ? h->hcs.ng : 0;
+    else if (!strcmp(key, "cs_group_axis")) *value = h->variant == 7 ? h->hcs.gax : -1;
+    else return fail(h, HJB_E_INVALID, "unknown option '%s'", key);
+    return HJB_OK;
 }
 
 int32_t hjb_backup_stage_device(hjb_handle hh, const void *dJ_next, void *dJ_out, int32_t *d_idx_out, void *stream) {
@@ -1397,7 +1595,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
         void *d = nullptr;
         if (hipMalloc(&d, jb * o->n_stages) != hipSuccess) return fail(h, HJB_E_NOMEM, "cannot hold %d J stages on the device", o->n_stages);
         dJst = (char *)d;
-        (void)hipMemset(dJst, 0, jb * o->n_stages);
+        if (hipMemset(dJst, 0, jb * o->n_stages) != hipSuccess) { (void)hipFree(dJst); return fail(h, HJB_E_DEVICE, "hipMemset of the J stage planes failed"); }
     }
     if (o->idx_stages) {
         void *d = nullptr;
@@ -1406,12 +1604,39 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
             return fail(h, HJB_E_NOMEM, "cannot hold %d idx stages on the device", o->n_stages);
         }
         dIst = (int32_t *)d;
-        (void)hipMemset(dIst, 0, (size_t)nS * 4 * o->n_stages);
+        if (hipMemset(dIst, 0, (size_t)nS * 4 * o->n_stages) != hipSuccess) {
+            if (dJst) (void)hipFree(dJst);
+            (void)hipFree(dIst);
+            return fail(h, HJB_E_DEVICE, "hipMemset of the idx stage planes failed");
+        }
     }
+    // optional probe block (the reference's debug taps): one plane of each requested output per stage
+    DProbe pr{};
+    char *dPg = nullptr, *dPx = nullptr, *dPj = nullptr;
+    const size_t tsz = h->dtype == HJB_F64 ? 8 : 4;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     auto cleanup = [&]() {
-        if (dJst) (void)hipFree(dJst);
-        if (dIst) (void)hipFree(dIst);
+        // hipFree is one of the calls a stream capture elsewhere in the process must not see: hold the shared lock
+        std::shared_lock<std::shared_mutex> lk(g_capture_mu, std::defer_lock);
+        if (!unsafe_lk.owns_lock()) lk.lock();
+        if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
+        if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        if (dJst) { (void)hipFree(dJst); dJst = nullptr; }
+        if (dIst) { (void)hipFree(dIst); dIst = nullptr; }
+        if (dPg) { (void)hipFree(dPg); dPg = nullptr; }
+        if (dPx) { (void)hipFree(dPx); dPx = nullptr; }
+        if (dPj) { (void)hipFree(dPj); dPj = nullptr; }
     };
+    if (o->probe) {
+        st = make_probe(h, o->probe, &pr);
+        if (st) { cleanup(); return st; }
+        const size_t pb = (size_t)pr.B * tsz;
+        void *d = nullptr;
+        if (o->probe->g) { if (hipMalloc(&d, pb * o->n_stages) != hipSuccess) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); } dPg = (char *)d; }
+        if (o->probe->x_next) { if (hipMalloc(&d, pb * h->hp.D * o->n_stages) != hipSuccess) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); } dPx = (char *)d; }
+        if (o->probe->j_interp) { if (hipMalloc(&d, pb * o->n_stages) != hipSuccess) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); } dPj = (char *)d; }
+    }
+    const bool every_stage = o->progress && o->progress_every_stage;
 #define SOLVE_TRY(expr)                                                                            \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -1424,10 +1649,10 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     else SOLVE_TRY(hipMemset(h->dJ[0], 0, jb));
     SOLVE_TRY(hipDeviceSynchronize());   // the sweep runs on the handle's own stream from here
     // launch-bound sweeps: replay kGraphStages ping-pong launches per hipGraphLaunch
-    const bool graph_ok = h->use_graph && !dJst && !dIst && o->n_stages >= 2 * kGraphStages;
+    const bool graph_ok = h->use_graph && !dJst && !dIst && !o->probe && !every_stage && o->n_stages >= 2 * kGraphStages;
     // K9: several stages per launch for local 2-D problems (no per-stage outputs, no monitor read-backs)
     bool tiled = false;
-    if (h->use_temporal && !dJst && !dIst && o->monitor_period <= 0 && o->n_stages >= 2 * kTileK && h->forced_variant < 0) {
+    if (h->use_temporal && !dJst && !dIst && !o->probe && !every_stage && o->monitor_period <= 0 && o->n_stages >= 2 * kTileK && h->forced_variant < 0) {
         if (h->tile2d < 0) {
             const int tst = examine_tile2d(h);
             if (tst) { cleanup(); return tst; }
@@ -1469,7 +1694,6 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
         (void)hipGraphDestroy(graph);
         if (ce != hipSuccess) { cleanup(); return fail(h, HJB_E_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(ce)); }
     }
-    hipEvent_t ev0, ev1;
     SOLVE_TRY(hipEventCreate(&ev0));
     SOLVE_TRY(hipEventCreate(&ev1));
     SOLVE_TRY(hipEventRecord(ev0, stream));
@@ -1507,8 +1731,23 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
         for (; run > 0; --run, --k_s) {
             void *outJ = dJst ? (void *)(dJst + (size_t)(k_s - 1) * jb) : h->dJ[pp];
             int32_t *outI = dIst ? dIst + (size_t)(k_s - 1) * nS : h->d_idx;
+            if (o->probe) {                              // taps of stage k_s: tables at the block, J_{k+1} = cur
+                const size_t pb = (size_t)pr.B * tsz;
+                pr.g = dPg ? dPg + (size_t)(k_s - 1) * pb : nullptr;
+                pr.x_next = dPx ? dPx + (size_t)(k_s - 1) * pb * h->hp.D : nullptr;
+                pr.j_interp = dPj ? dPj + (size_t)(k_s - 1) * pb : nullptr;
+                st = launch_probe(h, pr, cur, stream);
+                if (st) { cleanup(); return st; }
+            }
             st = launch_stage(h, cur, outJ, outI, stream);
             if (st) { cleanup(); return st; }
+            if (every_stage && !(o->monitor_period > 0 && k_s == stop)) {   // Dynamic_Solver.m:101: one line per stage
+                float ems = 0;
+                (void)hipEventRecord(ev1, stream);
+                (void)hipEventSynchronize(ev1);
+                (void)hipEventElapsedTime(&ems, ev0, ev1);
+                o->progress(o->progress_user, k_s, 0.0, 0.0, ems * 1e-3);
+            }
             cur = outJ;
             cur_idx = outI;
             if (!dJst) pp ^= 1;
@@ -1543,13 +1782,14 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     SOLVE_TRY(hipEventSynchronize(ev1));
     float ms = 0;
     SOLVE_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     unsafe_lk.lock();
     st = check_status(h, stream);
     if (st) { cleanup(); return st; }
     if (o->J_final) SOLVE_TRY(hipMemcpy(o->J_final, cur, jb, hipMemcpyDeviceToHost));
     if (o->idx_final) SOLVE_TRY(hipMemcpy(o->idx_final, cur_idx, (size_t)nS * 4, hipMemcpyDeviceToHost));
+    if (dPg) SOLVE_TRY(hipMemcpy(o->probe->g, dPg, (size_t)pr.B * tsz * o->n_stages, hipMemcpyDeviceToHost));
+    if (dPx) SOLVE_TRY(hipMemcpy(o->probe->x_next, dPx, (size_t)pr.B * tsz * h->hp.D * o->n_stages, hipMemcpyDeviceToHost));
+    if (dPj) SOLVE_TRY(hipMemcpy(o->probe->j_interp, dPj, (size_t)pr.B * tsz * o->n_stages, hipMemcpyDeviceToHost));
     if (o->J_stages) SOLVE_TRY(hipMemcpy(o->J_stages, dJst, jb * o->n_stages, hipMemcpyDeviceToHost));
     if (o->idx_stages) SOLVE_TRY(hipMemcpy(o->idx_stages, dIst, (size_t)nS * 4 * o->n_stages, hipMemcpyDeviceToHost));
     cleanup();
@@ -1582,6 +1822,208 @@ int32_t hjb_policy_lookup(int32_t device, int32_t dtype, int32_t D, const int32_
     if (nq == 0) return HJB_OK;
     return dtype == HJB_F32 ? policy_lookup_t<float>(D, n, knots, values, nq, queries, method, out)
                             : policy_lookup_t<double>(D, n, knots, values, nq, queries, method, out);
+}
+
+int32_t hjb_probe_stage(hjb_handle hh, const void *J_next, const hjb_probe *probe) {
+    Handle *h = (Handle *)hh;
+    if (!h || !probe) return fail(h, HJB_E_INVALID, "null argument");
+    if (probe->j_interp && !J_next) return fail(h, HJB_E_INVALID, "j_interp needs J_next");
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+    HIP_TRY(h, hipSetDevice(h->device));
+    DProbe pr{};
+    int st = make_probe(h, probe, &pr);
+    if (st) return st;
+    const size_t tsz = h->dtype == HJB_F64 ? 8 : 4, pb = (size_t)pr.B * tsz;
+    void *dg = nullptr, *dx = nullptr, *dj = nullptr;
+    auto release = [&]() { if (dg) (void)hipFree(dg); if (dx) (void)hipFree(dx); if (dj) (void)hipFree(dj); };
+    if ((probe->g && hipMalloc(&dg, pb) != hipSuccess) || (probe->x_next && hipMalloc(&dx, pb * h->hp.D) != hipSuccess) ||
+        (probe->j_interp && hipMalloc(&dj, pb) != hipSuccess)) {
+        release();
+        return fail(h, HJB_E_NOMEM, "probe buffers");
+    }
+    pr.g = dg; pr.x_next = dx; pr.j_interp = dj;
+    const void *dJn = nullptr;
+    if (probe->j_interp) {
+        st = ensure_work(h);
+        if (st) { release(); return st; }
+        if (hipMemcpy(h->dJ[0], J_next, (size_t)h->j_elems * h->esz, hipMemcpyHostToDevice) != hipSuccess) { release(); return fail(h, HJB_E_DEVICE, "copy of J_next failed"); }
+        dJn = h->dJ[0];
+    }
+    st = launch_probe(h, pr, dJn, nullptr);
+    if (!st) st = check_status(h, nullptr);
+    hipError_t e = hipSuccess;
+    if (!st && dg) e = hipMemcpy(probe->g, dg, pb, hipMemcpyDeviceToHost);
+    if (!st && e == hipSuccess && dx) e = hipMemcpy(probe->x_next, dx, pb * h->hp.D, hipMemcpyDeviceToHost);
+    if (!st && e == hipSuccess && dj) e = hipMemcpy(probe->j_interp, dj, pb, hipMemcpyDeviceToHost);
+    release();
+    if (st) return st;
+    if (e != hipSuccess) return fail(h, HJB_E_DEVICE, "hjb_probe_stage: %s", hipGetErrorString(e));
+    return HJB_OK;
+}
+
+// ---- flat builder API (MATLAB loadlibrary/calllib cannot marshal hjb_problem) ---------------------------------------
+struct hjb_builder_s {
+    hjb_problem p{};
+    std::vector<std::vector<double>> knots;
+    std::vector<std::vector<unsigned char>> blobs;   // owned copies of every term / model table
+    std::string err;
+};
+
+static int bfail(hjb_builder b, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (b) b->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+const char *hjb_problem_last_error(hjb_builder b) { return b ? b->err.c_str() : g_last_error.c_str(); }
+
+int32_t hjb_problem_new(int32_t D, int32_t C, const int32_t *n, const int32_t *m, int32_t dtype, int32_t index_base,
+                        hjb_builder *out) {
+    if (!out || !n || !m) return bfail(nullptr, HJB_E_INVALID, "null argument");
+    *out = nullptr;
+    if (D < 1 || D > HJB_MAX_D) return bfail(nullptr, HJB_E_UNSUPPORTED, "D=%d not in 1..%d", D, HJB_MAX_D);
+    if (C < 1 || C > HJB_MAX_C) return bfail(nullptr, HJB_E_UNSUPPORTED, "C=%d not in 1..%d", C, HJB_MAX_C);
+    if (dtype != HJB_F32 && dtype != HJB_F64 && dtype != HJB_F16S) return bfail(nullptr, HJB_E_UNSUPPORTED, "dtype %d", dtype);
+    if (index_base != 0 && index_base != 1) return bfail(nullptr, HJB_E_INVALID, "index_base must be 0 or 1");
+    for (int a = 0; a < D; ++a) if (n[a] < 2) return bfail(nullptr, HJB_E_INVALID, "n[%d]=%d < 2", a, n[a]);
+    for (int c = 0; c < C; ++c) if (m[c] < 1) return bfail(nullptr, HJB_E_INVALID, "m[%d]=%d < 1", c, m[c]);
+    hjb_builder b = new hjb_builder_s();
+    b->p.D = D; b->p.C = C; b->p.dtype = dtype; b->p.index_base = index_base;
+    for (int a = 0; a < D; ++a) b->p.n[a] = n[a];
+    for (int c = 0; c < C; ++c) b->p.m[c] = m[c];
+    b->knots.resize((size_t)D);
+    *out = b;
+    return HJB_OK;
+}
+
+int32_t hjb_problem_set_knots(hjb_builder b, int32_t axis, const double *knots, int32_t len) {
+    if (!b || !knots) return bfail(b, HJB_E_INVALID, "null argument");
+    if (axis < 0 || axis >= b->p.D) return bfail(b, HJB_E_INVALID, "axis %d not in 0..%d", axis, b->p.D - 1);
+    if (len != b->p.n[axis]) return bfail(b, HJB_E_INVALID, "axis %d has %d grid points, %d knots given", axis, b->p.n[axis], len);
+    b->knots[(size_t)axis].assign(knots, knots + len);
+    return HJB_OK;
+}
+
+static int add_term(hjb_builder b, hjb_term *slot, uint32_t mask, const void *data, int64_t count, const char *what) {
+    if (!data) return bfail(b, HJB_E_INVALID, "%s: null data", what);
+    if (mask >> (b->p.D + b->p.C)) return bfail(b, HJB_E_INVALID, "%s: mask 0x%x names a grid dim >= %d", what, mask, b->p.D + b->p.C);
+    const int64_t need = term_elems(&b->p, mask);
+    if (count != need) return bfail(b, HJB_E_INVALID, "%s: mask 0x%x spans %lld elements, %lld given", what, mask, (long long)need, (long long)count);
+    const size_t esz = b->p.dtype == HJB_F64 ? 8 : 4;
+    b->blobs.emplace_back((const unsigned char *)data, (const unsigned char *)data + (size_t)count * esz);
+    slot->mask = mask;
+    slot->reserved = 0;
+    slot->data = nullptr;          // bound in hjb_create_from (the vectors may still move)
+    return HJB_OK;
+}
+
+int32_t hjb_problem_add_next_term(hjb_builder b, int32_t axis, uint32_t mask, const void *data, int64_t count) {
+    if (!b) return bfail(b, HJB_E_INVALID, "null builder");
+    if (axis < 0 || axis >= b->p.D) return bfail(b, HJB_E_INVALID, "axis %d not in 0..%d", axis, b->p.D - 1);
+    if (b->p.n_next_terms[axis] >= HJB_MAX_TERMS) return bfail(b, HJB_E_UNSUPPORTED, "more than %d terms for axis %d", HJB_MAX_TERMS, axis);
+    hjb_term *slot = &b->p.next_terms[axis][b->p.n_next_terms[axis]];
+    const int st = add_term(b, slot, mask, data, count, "next term");
+    if (st) return st;
+    slot->reserved = (uint32_t)b->blobs.size();          // 1-based blob number until hjb_create_from binds the pointer
+    ++b->p.n_next_terms[axis];
+    return HJB_OK;
+}
+
+int32_t hjb_problem_add_cost_term(hjb_builder b, uint32_t mask, const void *data, int64_t count) {
+    if (!b) return bfail(b, HJB_E_INVALID, "null builder");
+    if (b->p.n_cost_terms >= HJB_MAX_TERMS) return bfail(b, HJB_E_UNSUPPORTED, "more than %d cost terms", HJB_MAX_TERMS);
+    hjb_term *slot = &b->p.cost_terms[b->p.n_cost_terms];
+    const int st = add_term(b, slot, mask, data, count, "cost term");
+    if (st) return st;
+    slot->reserved = (uint32_t)b->blobs.size();
+    ++b->p.n_cost_terms;
+    return HJB_OK;
+}
+
+int32_t hjb_problem_set_slab(hjb_builder b, int32_t slab_begin, int32_t slab_end, int32_t halo_lo, int32_t halo_hi) {
+    if (!b) return bfail(b, HJB_E_INVALID, "null builder");
+    b->p.slab_begin = slab_begin; b->p.slab_end = slab_end; b->p.halo_lo = halo_lo; b->p.halo_hi = halo_hi;
+    return HJB_OK;
+}
+
+int32_t hjb_problem_set_model(hjb_builder b, int32_t model, double model_h, const void *t0, const void *t1,
+                              const void *t2, const void *t3) {
+    if (!b) return bfail(b, HJB_E_INVALID, "null builder");
+    if (model == HJB_MODEL_NONE) { b->p.model = HJB_MODEL_NONE; return HJB_OK; }
+    if (model != HJB_MODEL_QUAT_EULER321) return bfail(b, HJB_E_INVALID, "model %d", model);
+    if (b->p.D != 6 || b->p.C != 3 || b->p.dtype == HJB_F64) return bfail(b, HJB_E_UNSUPPORTED, "HJB_MODEL_QUAT_EULER321 needs D=6, C=3, float32 arithmetic");
+    const void *t[4] = {t0, t1, t2, t3};
+    const size_t ne = (size_t)b->p.n[0] * b->p.n[1] * b->p.n[2];
+    for (int i = 0; i < 4; ++i) {
+        if (!t[i]) return bfail(b, HJB_E_INVALID, "model table %d is null", i);
+        b->blobs.emplace_back((const unsigned char *)t[i], (const unsigned char *)t[i] + ne * 4);
+        b->p.model_tables[i] = (const void *)(uintptr_t)b->blobs.size();     // blob number, bound in hjb_create_from
+    }
+    b->p.model = model;
+    b->p.model_h = model_h;
+    return HJB_OK;
+}
+
+int32_t hjb_create_from(hjb_builder b, int32_t device, hjb_handle *out) {
+    if (!b || !out) return bfail(b, HJB_E_INVALID, "null argument");
+    hjb_problem p = b->p;
+    for (int a = 0; a < p.D; ++a) {
+        if (b->knots[(size_t)a].empty()) return bfail(b, HJB_E_INVALID, "knots of axis %d were not set", a);
+        p.knots[a] = b->knots[(size_t)a].data();
+        for (int k = 0; k < p.n_next_terms[a]; ++k) {
+            p.next_terms[a][k].data = b->blobs[p.next_terms[a][k].reserved - 1].data();
+            p.next_terms[a][k].reserved = 0;
+        }
+    }
+    for (int k = 0; k < p.n_cost_terms; ++k) {
+        p.cost_terms[k].data = b->blobs[p.cost_terms[k].reserved - 1].data();
+        p.cost_terms[k].reserved = 0;
+    }
+    if (p.model != HJB_MODEL_NONE)
+        for (int i = 0; i < 4; ++i) p.model_tables[i] = b->blobs[(size_t)(uintptr_t)b->p.model_tables[i] - 1].data();
+    const int st = hjb_create(&p, device, out);
+    if (st) b->err = g_last_error;
+    return st;
+}
+
+int32_t hjb_problem_free(hjb_builder b) {
+    delete b;
+    return HJB_OK;
+}
+
+int32_t hjb_solve_flat(hjb_handle h, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
+                       void *J_final, int32_t *idx_final, void *J_stages, int32_t *idx_stages, int32_t *stages_done,
+                       int32_t *stopped_early, double *sweep_ms) {
+    hjb_solve_opts o{};
+    o.n_stages = n_stages;
+    o.monitor_period = monitor_period;
+    o.monitor_tol = monitor_tol;
+    o.terminal = terminal;
+    o.J_final = J_final;
+    o.idx_final = idx_final;
+    o.J_stages = J_stages;
+    o.idx_stages = idx_stages;
+    hjb_result r{};
+    const int st = hjb_solve(h, &o, &r);
+    if (stages_done) *stages_done = r.stages_done;
+    if (stopped_early) *stopped_early = r.stopped_early;
+    if (sweep_ms) *sweep_ms = r.sweep_ms;
+    return st;
+}
+
+int32_t hjb_get_info_flat(hjb_handle h, int64_t *out8) {
+    if (!out8) return fail((Handle *)h, HJB_E_INVALID, "null argument");
+    hjb_info i{};
+    const int st = hjb_get_info(h, &i);
+    if (st) return st;
+    out8[0] = i.n_states; out8[1] = i.n_controls; out8[2] = i.j_elems; out8[3] = i.kernel_variant;
+    out8[4] = i.lds_bytes; out8[5] = i.grid; out8[6] = i.halo_needed_lo; out8[7] = i.halo_needed_hi;
+    return HJB_OK;
 }
 
 }  // extern "C"

@@ -12,22 +12,28 @@
 //   B[k2, k3]      = lerp_axis1( A[c1; ..], A[c1+1; ..]; t1 )                       c1, t1: uniform over the wave
 //   total_u        = g_u + lerp_axis3( lerp_axis2( B[c2_u + {0,1}, c3_u + {0,1}] ) )
 //
-// and A does not depend on the state's index along axis 1.  So one WAVE = 64 consecutive axis-0 states of one
-// (i2, i3) pair, and it SWEEPS THE COLUMN i1 = 0..n1-1: the A row at knot c1+1 of one step is the A row at knot c1
-// of the next (axis-1 cells advance by one per state when the displacement is sub-cell; anything else re-primes,
-// a wave-uniform branch).  Per step a lane loads each needed corner row once (2 loads), not once per control.
+// and A does not depend on the state's index along axis 1.  So one WAVE = consecutive axis-0 states of one (i2, i3)
+// pair, and it SWEEPS THE COLUMN i1 = 0..n1-1: the A row at knot c1+1 of one step is the A row at knot c1 of the next
+// (axis-1 cells advance by one per state when the displacement is sub-cell; anything else re-primes, a wave-uniform
+// branch).  Per step a lane loads each needed corner row once, not once per control.
 //
 // Which (k2, k3) rows a state needs is stage-invariant and identical for the whole column, so the host builds a PLAN
 // per (i2, i3): the controls are put into GROUPS sharing the cell of the "group axis" GAX (pos-att: w, 5 distinct
-// cells among the 9 thruster combinations, Solver_pos_att.m:886-904) whose cells along the other, "window" axis span
-// at most NW knots (v moves < 1 cell).  A group = 2 x NW corner rows; its members differ only in weights, cost and
-// which window pair they use.  The kernel is a template over the number of groups NG (the maximum over the plans;
-// plans with fewer are padded with member-less groups) and straight-line over groups and rows: all 4 NG NW loads of a
-// step are issued back to back, the rolling A values sit in registers with static indices, and everything per control
-// is wave-uniform data of the plan, parked in LDS for the column and read back by broadcast.  Groups are visited in
-// plan order, not control order: a member that is visited after a higher-numbered control carries a tie flag and
-// compares (value, index), so the first-index-wins rule of MATLAB's min holds exactly.  Same canonical arithmetic:
-// bit-identical to every other variant.
+// cells among the 9 thruster combinations, Solver_pos_att.m:886-904) and a window of 3 knots of the other, "window"
+// axis (v moves < 1 cell).  A group = 2 x 3 corner rows and 6 member SLOTS: slots 0-2 interpolate between window
+// knots (0, 1), slots 3-5 between (1, 2) - which pair a control uses is therefore static, and a slot's weights,
+// control cost and control number are wave-uniform plan data parked in LDS for the column.  The kernel is a template
+// over the number of groups NG (the maximum over the plans; plans with fewer are padded with member-less groups) and
+// straight-line over groups, rows and slots: the rolling A values sit in registers with static indices.  Groups are
+// visited in plan order, not control order, so the running minimum compares (value, control number)
+// lexicographically: the first-index-wins rule of MATLAB's min holds exactly.
+//
+// The two axis-0 neighbours (c0, c0 + 1) of a corner row: the L1 path (64 B per clock per CU) is what bounds this
+// kernel (profiles/r02_c4_colsweep_v1_pmc.json: TA busy 87 %), and the two loads of a pair hit the same cache lines.
+// DPP form (template DPP, chosen on the host when every wave's axis-0 cells satisfy it): a wave carries 62 states
+// + 2 halo lanes, lane L loads knot kb + L ONCE, and the upper neighbour is the next lane's value (`wave_shl:1`, folded
+// by the compiler into the subtract); lanes whose cell sits one knot further (grid-edge clamping, uneven knots) take
+// the values one and two lanes up.  Same values, same arithmetic: bit-identical to every other variant.
 #pragma once
 #include "hjbdp_dev.h"
 #include "kernels_generic.h"
@@ -37,14 +43,15 @@
 namespace hjb {
 
 constexpr int kCsGMax = 6;      // groups per (i2, i3)
-constexpr int kCsMMax = 3;      // members per group
-constexpr int kCsNW = 3;        // window knots per group (cells span <= NW - 1)
+constexpr int kCsMMax = 6;      // member slots per group: 3 per window pair
+constexpr int kCsNW = 3;        // window knots per group
 constexpr int kCsUMax = 16;     // controls
 constexpr int kCsMaxCu = kLeanMaxCu;
-constexpr int kCsAhead = 2;     // corner-row loads are issued this many groups ahead of their use
+constexpr int kCsFlush = 8;     // results are parked in LDS and written out every kCsFlush steps
+constexpr int kCsDppLanes = 62; // states per wave in the DPP form (+ 2 halo lanes)
 // The plan of one (i2, i3), 32-bit words:
-//   [0] halo violation flag   [1 + g] byte offset of group g's first corner row   [1 + GMAX + g] nw | nmem << 8
-//   [kCsPI + 8 s ...] member slot s = g * MMAX + ms: t_window, t_group, cu[0], u | off << 8 | tie << 16, cu[1..3], 0
+//   [0] halo violation flag | groups << 8   [1 + g] byte offset of group g's first corner row   [1 + GMAX + g] bit s = slot s is used | nw << 8
+//   [kCsPI + 8 s ...] member slot s' = g * MMAX + s: t_window, t_group, cu[0], control number, cu[1..3], 0
 constexpr int kCsPI = 16;
 constexpr int kCsSlots = kCsGMax * kCsMMax;
 constexpr int kCsPlanWords = kCsPI + 8 * kCsSlots;
@@ -57,67 +64,126 @@ struct DColSweep {
     int32_t npre_col;       // leading state-only cost terms that do not depend on state dim 1: summed once per column
     int32_t step_uniform;   // the remaining state-only cost terms do not depend on state dim 0 (wave-uniform per step)
     int32_t ncu;            // control-only cost terms
+    int32_t dpp;            // every wave of 62 states has axis-0 cells within one knot of a common shift: DPP form
     uint32_t g_bytes;       // J byte stride of the group axis
     uint32_t w_bytes;       // J byte stride of the window axis
     uint32_t s1_bytes;      // J byte stride of axis 1
-    int32_t tile2, tile3;   // traversal tile over (i2, i3): consecutive waves share corner rows
+    // Which column a wave takes (XCD-aware: workgroup b runs on XCD b % 8, each XCD has its own L2).  A corner row is
+    // shared by the columns whose group-axis index differs by a multiple of the spacing of the groups (pos-att: w moves
+    // 3.8 cells per thruster level, so columns i3, i3 + 4, i3 + 8 ... gather from the same planes) and by neighbours along
+    // the window axis.  Each XCD therefore owns the group-axis indices of (part of) one residue class, xcd_ig[x][0..cnt),
+    // and walks them fastest, then the axis-0 chunk, then the window-axis index.
+    const int32_t *xcd_ig;  // [8][xcd_stride]
+    int32_t xcd_cnt[8];
+    int32_t xcd_stride;
+    int32_t pad;
 };
 
-template <typename T, typename TJ, int GAX, int NG, bool FASTCOST>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ float lane_up(float x) {      // value of lane + 1 (lane 63 reads 0: a halo lane, never used)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+// The corner-row gathers of the column loop are issued by hand and waited for by hand.  hipcc's wait insertion is
+// path-insensitive: a load that sits behind a wave-uniform guard (a column has ng <= NG groups), or any store that may
+// still be pending (gfx9 has ONE counter for loads and stores, and they complete out of order with each other), turns
+// every wait into `vmcnt(0)` - a full drain that also waits for the rows just requested for the next half step.  Here the
+// loads are asm statements the compiler does not track; a wait is `s_waitcnt vmcnt(N)` with N = the exact number of
+// younger gathers, tied to the awaited registers by "+v" operands so that no use can move above it.  Safe because
+// loads return in order and the only stores of the loop are followed by a full drain (see the flush below).
+template <int BYTES>
+__device__ __forceinline__ uint32_t gather_async(uint32_t off, gptr<char> base) {
+    uint32_t r;
+    if (BYTES == 4) asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(off), "s"(base));
+    else asm volatile("global_load_ushort %0, %1, %2" : "=v"(r) : "v"(off), "s"(base));
+    return r;
+}
+template <int N> __device__ __forceinline__ void wait_gathers() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N)); }
+__device__ __forceinline__ void tie6(uint32_t (&r)[2][kCsNW]) {
+    static_assert(kCsNW == 3, "six registers per group and neighbour");
+    asm volatile("" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]));
+}
+template <typename T, typename TJ> __device__ __forceinline__ T raw_to(uint32_t r) {
+    if (sizeof(TJ) == 4) return __uint_as_float(r);
+    return (T)__builtin_bit_cast(_Float16, (unsigned short)r);
+}
+
+#ifndef HJB_CS_OCCUPANCY
+#define HJB_CS_OCCUPANCY            // e.g. -DHJB_CS_OCCUPANCY='__attribute__((amdgpu_waves_per_eu(5, 5)))' (tuning experiments)
+#endif
+template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP>
+__global__ void __launch_bounds__(256) HJB_CS_OCCUPANCY
 k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
                   const TJ *__restrict__ Jn, TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");
-    constexpr int D = 4, NW = kCsNW, MM = kCsMMax;
+    constexpr int D = 4, NW = kCsNW, MM = kCsMMax, LANES = DPP ? kCsDppLanes : 64;
     typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
     __shared__ f4 s_slots[4][kCsSlots * 2];
+    __shared__ T s_best[4][kCsFlush][64];
+    __shared__ int32_t s_idx[4][kCsFlush][64];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int n0 = P->n[0], n1 = P->n[1], n2 = P->n[2], n3 = P->n[3];
-    const int chunks = (n0 + 63) >> 6;
-    // ---- which column: tiles of (i2, i3), i2 fastest inside a tile --------------------------------------
-    const int t2 = CS->tile2, t3 = CS->tile3;
-    const int nt2 = (n2 + t2 - 1) / t2;
+    const int chunks = (n0 + LANES - 1) / LANES;
+    // ---- which column (see DColSweep::xcd_ig) --------------------------------------------------------------
     int i2, i3, chunk;
     {
-        const unsigned item = blockIdx.x * 4u + (unsigned)wave;
-        chunk = (int)(item % (unsigned)chunks);
-        const unsigned r = item / (unsigned)chunks;
-        const unsigned tile = r / (unsigned)(t2 * t3), within = r % (unsigned)(t2 * t3);
-        i2 = (int)(tile % (unsigned)nt2) * t2 + (int)(within % (unsigned)t2);
-        i3 = (int)(tile / (unsigned)nt2) * t3 + (int)(within / (unsigned)t2);
+        const unsigned xcd = blockIdx.x & 7u, item = (blockIdx.x >> 3) * 4u + (unsigned)wave;
+        const unsigned cnt = (unsigned)CS->xcd_cnt[xcd];
+        const unsigned nwax = (unsigned)(GAX == 3 ? n2 : n3);                 // columns along the window axis
+        if (item >= cnt * (unsigned)chunks * nwax) return;                    // uniform over the wave
+        const unsigned r = item / cnt;
+        const int ig = as_const<int32_t>(CS->xcd_ig)[xcd * (unsigned)CS->xcd_stride + item % cnt];
+        chunk = (int)(r % (unsigned)chunks);
+        const int iw = (int)(r / (unsigned)chunks);
+        i2 = GAX == 3 ? iw : ig;
+        i3 = GAX == 3 ? ig : iw;
     }
-    if (i2 >= n2 || i3 >= n3) return;                       // ragged tiles (uniform over the wave)
-    int i0 = chunk * 64 + lane;
-    const bool valid = i0 < n0;
-    if (!valid) i0 = n0 - 1;                                // duplicate work, no store
+    int i0 = chunk * LANES + lane;
+    const bool valid = lane < LANES && i0 < n0;
+    if (!valid) i0 = n0 - 1;                                // halo / tail lanes: duplicate work, no store
     // ---- the plan of this column: header words in scalar registers, member slots parked in LDS ------------
     cptr<int32_t> pl = as_const<int32_t>(CS->plan) + (size_t)(i2 + n2 * i3) * kCsPlanWords;
     {
         gptr<f4> src = as_global<f4>(CS->plan + (size_t)(i2 + n2 * i3) * kCsPlanWords + kCsPI);
-        if (lane < NG * MM * 2) s_slots[wave][lane] = src[lane];
+#pragma unroll
+        for (int e = lane; e < NG * MM * 2; e += 64) s_slots[wave][e] = src[e];
     }
-    if (pl[0] && lane == 0) *P->status = 1;
+    const int ng = pl[0] >> 8;                               // groups of this column (<= NG)
+    if ((pl[0] & 1) && lane == 0) *P->status = 1;
     const uint32_t g_bytes = CS->g_bytes, w_bytes = CS->w_bytes, s1_bytes = CS->s1_bytes;
-    uint32_t roff[NG][NW];
-    int nmem[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const uint32_t ro = (uint32_t)pl[1 + g];
-        const int info = pl[1 + kCsGMax + g];
-        const int nw = info & 0xff;
-        nmem[g] = (info >> 8) & 0xff;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) roff[g][w] = ro + (uint32_t)(w < nw ? w : nw - 1) * w_bytes;   // a short window re-reads its last row
-    }
     // ---- axis 0: the thread's own (cell, t) for the whole column ------------------------------------------
     uint32_t voff0;
     T t0;
+    bool dl = false;              // DPP form: this lane's cell sits one knot above the wave's common shift
+    bool mixed = false;           // ... and some lane of the wave does (wave-uniform)
     {
         const DTabled::Axis &A0 = TB->ax[0];
         const int off = A0.sstride[0] * i0 + A0.sstride[2] * i2 + A0.sstride[3] * i3;
-        voff0 = (uint32_t)as_global<TabEntry<T>>(A0.tab)[off].cell * (uint32_t)sizeof(TJ);
+        const int c0 = as_global<TabEntry<T>>(A0.tab)[off].cell;
         t0 = as_global<TabEntry<T>>(A0.tab)[off].t;
+        if (DPP) {
+            // rel = cell - state index takes at most two adjacent values over the wave's states (verified on the host)
+            const int rel = c0 - i0;
+            const int r0 = __builtin_amdgcn_readfirstlane(rel);                 // lane 0 is always a state
+            const bool less = __builtin_amdgcn_ballot_w64(valid && rel < r0) != 0;
+            const int kb = less ? r0 - 1 : r0;
+            dl = valid && rel != kb;
+            mixed = __builtin_amdgcn_ballot_w64(dl) != 0;
+            int knot = chunk * LANES + lane + kb;                               // the knot this lane loads
+            knot = knot < 0 ? 0 : (knot > n0 - 1 ? n0 - 1 : knot);              // clamped lanes are never referenced
+            voff0 = (uint32_t)knot * (uint32_t)sizeof(TJ);
+        } else {
+            voff0 = (uint32_t)c0 * (uint32_t)sizeof(TJ);
+        }
+    }
+    // byte offset of a corner row = (group's first row: scalar, from the plan) + (window knot w) * w_bytes + this lane's
+    // axis-0 offset + the step's axis-1 row; every group has three valid window knots (the plan keeps windows inside the grid)
+    uint32_t rog[NG];
+    int used[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        rog[g] = (uint32_t)pl[1 + g];
+        used[g] = pl[1 + kCsGMax + g];
     }
     const DTabled::Axis &A1 = TB->ax[1];
     const int a1_base = A1.sstride[2] * i2 + A1.sstride[3] * i3, a1_s = A1.sstride[1];
@@ -132,76 +198,193 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         const T x = term_value<T, D>(P->cost[k], si, cjz);
         gcol = (k == 0) ? x : (T)(gcol + x);
     }
-    // Four scalar bases - (lower, upper) group row x (lower, upper) axis-0 neighbour - and ONE 32-bit per-lane byte
-    // offset per (group, window knot): every gather is `global_load v, v_off, s[base]`, no 64-bit vector arithmetic.
-    // The bases are opaque to the compiler: the two loads of a corner pair must stay two instructions (merged into one
-    // unaligned 8-byte load they are slower, measured on the row kernel).
-    gptr<char> Jb00 = as_global<char>(Jn);
-    gptr<char> Jb01 = as_global<char>(reinterpret_cast<const char *>(Jn) + sizeof(TJ));
+    // Scalar bases: (lower, upper) group row [x (lower, upper) axis-0 neighbour], and ONE 32-bit per-lane byte offset per
+    // (group, window knot), advanced along the column: every gather is `global_load v, v_off, s[base]`, no 64-bit vector
+    // arithmetic.  The bases are opaque to the compiler: the two loads of a corner pair must stay two instructions
+    // (merged into one unaligned 8-byte load they are slower, measured on the row kernel).
+    gptr<char> Jb00 = as_global<char>(Jn), Jb01 = Jb00, Jb11 = Jb00;
     gptr<char> Jb10 = as_global<char>(reinterpret_cast<const char *>(Jn) + g_bytes);
-    gptr<char> Jb11 = as_global<char>(reinterpret_cast<const char *>(Jn) + g_bytes + sizeof(TJ));
-    asm volatile("" : "+s"(Jb01));
     asm volatile("" : "+s"(Jb10));
-    asm volatile("" : "+s"(Jb11));
+    if (!DPP) {
+        Jb01 = as_global<char>(reinterpret_cast<const char *>(Jn) + sizeof(TJ));
+        Jb11 = as_global<char>(reinterpret_cast<const char *>(Jn) + g_bytes + sizeof(TJ));
+        asm volatile("" : "+s"(Jb01));
+        asm volatile("" : "+s"(Jb11));
+    }
     const uint32_t out_col = (uint32_t)i0 + (uint32_t)P->jstride[2] * (uint32_t)i2 + (uint32_t)P->jstride[3] * (uint32_t)(i3 + P->halo_lo);
     const uint32_t idx_col = (uint32_t)i0 + (uint32_t)n0 * (uint32_t)n1 * ((uint32_t)i2 + (uint32_t)n2 * (uint32_t)i3);
     const uint32_t js1 = (uint32_t)P->jstride[1];
     const int index_base = P->index_base;
     __builtin_amdgcn_wave_barrier();
 
-    T A[NG][2][NW];
+    // the axis-0 lerp of one corner row from the value(s) a lane loaded, general form
+    auto xl = [&](T a, T b) -> T {
+        if (DPP) {                                   // a = the knot this lane loaded
+            const T k1 = lane_up(a);
+            const T k2 = lane_up(k1);
+            const T lo = dl ? k1 : a, hi = dl ? k2 : k1;
+            return fma_t<T>(t0, (T)(hi - lo), lo);
+        }
+        return fma_t<T>(t0, (T)(b - a), a);          // a, b = the lower / upper neighbour
+    };
+
+    // ---- the column loop ------------------------------------------------------------------------------------------
+    // Software pipeline in two halves of the group sequence, H0 = groups [0, NGH) and H1 = [NGH, NG): the rows of H1 are
+    // requested before H0 is computed, the rows of the NEXT step's H0 before H1 is computed, so every load has half a
+    // step of arithmetic (times the other waves of the SIMD) to land, and each half keeps its own registers - no
+    // rotation.  Results go to LDS and are written out every kCsFlush steps: on gfx9 loads and stores share one counter
+    // and complete out of order with each other, so a pending store makes every wait for a load a full drain.
+    constexpr int NGH = (NG + 1) / 2;
+    f2 A[NG][NW];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int w = 0; w < NW; ++w) A[g][w] = f2{(T)0, (T)0};
+    constexpr int LPG = DPP ? 6 : 12;                        // gathers per group
+    int ngs = ng;                                            // the group count as a value of the current step (below)
+    uint32_t rlo[NG][2][NW], rhi[NG][2][NW];
+    auto load_groups = [&](int g0, int g1, uint32_t vrow) {
+        uint32_t vb[NW];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) A[g][k][w] = (T)0;
+        for (int w = 0; w < NW; ++w) vb[w] = voff0 + (vrow + (uint32_t)w * w_bytes);
+#pragma unroll
+        for (int g = g0; g < g1; ++g) {
+            if (g < ngs) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const uint32_t o = vb[w] + rog[g];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        rlo[g][k][w] = gather_async<sizeof(TJ)>(o, k ? Jb10 : Jb00);
+                        if (!DPP) rhi[g][k][w] = gather_async<sizeof(TJ)>(o, k ? Jb11 : Jb01);
+                    }
+                }
+            }
+        }
+    };
+    // wait until at most `younger` groups' gathers are outstanding, then release groups [g0, g1) to the arithmetic
+    auto await_groups = [&](int g0, int g1, int younger) {
+        switch (younger) {
+            case 0: wait_gathers<0>(); break;
+            case 1: wait_gathers<LPG>(); break;
+            case 2: wait_gathers<2 * LPG>(); break;
+            default: wait_gathers<3 * LPG>(); break;
+        }
+#pragma unroll
+        for (int g = g0; g < g1; ++g) {
+            tie6(rlo[g]);
+            if (!DPP) tie6(rhi[g]);
+        }
+    };
+    static_assert(NG - (NG + 1) / 2 <= 3 && (NG + 1) / 2 <= 3, "await_groups counts up to three younger groups");
+    T best, gstep, t1;
+    int best_u;
+    // The arithmetic is written on PAIRS (lower, upper group row) of one window knot: v_pk_add_f32 / v_pk_fma_f32 are
+    // IEEE per component, and with the pair as the unit of data no value ever has to be moved between registers.
+    auto compute_groups = [&](int g0, int g1) {
+#pragma unroll
+        for (int g = g0; g < g1; ++g) {
+            if (g < ngs) {
+                // the slot bits as a value of THIS block: tested with s_bitcmp; hoisted out of the loop each test would
+                // become a 64-bit lane mask held in two scalar registers for the whole column
+                int ug = used[g];
+                asm volatile("" : "+s"(ug));
+                const f2 t0p = {t0, t0}, t1p = {t1, t1};
+                f2 Bv[NW];
+                auto roll = [&](int w, f2 l, f2 h) {        // axis-0 lerp of the new row, axis-1 lerp with the previous row
+                    const f2 an = __builtin_elementwise_fma(t0p, h - l, l);
+                    Bv[w] = __builtin_elementwise_fma(t1p, an - A[g][w], A[g][w]);
+                    A[g][w] = an;
+                };
+                if (DPP && mixed) {            // wave-uniform: some lanes take the values one and two lanes up
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const f2 lo = {raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
+                        const f2 k1 = {lane_up(lo.x), lane_up(lo.y)};
+                        const f2 k2 = {lane_up(k1.x), lane_up(k1.y)};
+                        roll(w, dl ? k1 : lo, dl ? k2 : k1);
+                    }
+                } else {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const f2 lo = {raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
+                        const f2 hi = DPP ? f2{lane_up(lo.x), lane_up(lo.y)}
+                                          : f2{raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])};
+                        roll(w, lo, hi);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < MM; ++s) {
+                    if (ug & (1 << s)) {
+                        const int off = s / (MM / 2);                // slots 0-2: window knots (0, 1); slots 3-5: (1, 2)
+                        const f4 ms = s_slots[wave][(g * MM + s) * 2];       // broadcast read of the slot's plan data
+                        const T tw = ms.x, tg = ms.y;
+                        const int u = __float_as_int(ms.w);
+                        T interp;
+                        if (GAX == 3) {          // window = axis 2 (lerped first, both group rows at once), group = axis 3
+                            const f2 twp = {tw, tw};
+                            const f2 v = __builtin_elementwise_fma(twp, Bv[off + 1] - Bv[off], Bv[off]);
+                            interp = fma_t<T>(tg, (T)(v.y - v.x), v.x);
+                        } else {                 // group = axis 2 (lerped first, both window knots at once), window = axis 3
+                            const f2 b0 = {Bv[off].x, Bv[off + 1].x}, b1 = {Bv[off].y, Bv[off + 1].y};
+                            const f2 tgp = {tg, tg};
+                            const f2 v = __builtin_elementwise_fma(tgp, b1 - b0, b0);
+                            interp = fma_t<T>(tw, (T)(v.y - v.x), v.x);
+                        }
+                        T gg;
+                        if (FASTCOST) {                              // the usual shape: state terms + ONE control term
+                            gg = (T)(gstep + ms.z);
+                        } else {
+                            const f4 mx = s_slots[wave][(g * MM + s) * 2 + 1];
+                            gg = gstep;
+                            for (int k = 0; k < ncu; ++k) {
+                                const T x = k == 0 ? ms.z : (k == 1 ? mx.x : (k == 2 ? mx.y : mx.z));
+                                gg = (npre == 0 && k == 0) ? x : (T)(gg + x);
+                            }
+                        }
+                        const T tot = (T)(gg + interp);
+                        // lexicographic (value, control number): groups are not visited in control order
+                        const bool take = (tot < best) | ((tot == best) & (u < best_u));
+                        best = take ? tot : best;
+                        best_u = take ? u : best_u;
+                    }
+                }
+            }
+        }
+    };
     int prev_c1 = -2;
     int c1n = tab1[0].cell;
     T t1n = tab1[0].t;
+    load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // prologue: H0 of step 0
     for (int i1 = 0; i1 < n1; ++i1) {
         const int c1 = c1n;
-        const T t1 = t1n;
+        t1 = t1n;
+        ngs = ng;
+        asm volatile("" : "+s"(ngs));        // group-count tests stay scalar compares of this step (see the slot bits)
         {   // next step's axis-1 entry: a scalar load in flight during this step
             const int nx = (i1 + 1 < n1 ? i1 + 1 : i1) * a1_s;
             c1n = tab1[nx].cell;
             t1n = tab1[nx].t;
         }
         if (c1 != prev_c1 + 1) {         // (re-)prime: A <- the row at knot c1 (column start; irregular axis-1 cells)
-            const uint32_t vrow = voff0 + (uint32_t)c1 * s1_bytes;
+            const uint32_t vrow = (uint32_t)c1 * s1_bytes;
 #pragma unroll
             for (int g = 0; g < NG; ++g)
+                if (g < ng) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const uint32_t o = roff[g][w] + vrow;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const T lo = (T) * reinterpret_cast<gptr<TJ>>((k ? Jb10 : Jb00) + o);
-                        const T hi = (T) * reinterpret_cast<gptr<TJ>>((k ? Jb11 : Jb01) + o);
-                        A[g][k][w] = fma_t<T>(t0, (T)(hi - lo), lo);
+                    for (int w = 0; w < NW; ++w) {
+                        const uint32_t o = voff0 + (vrow + (uint32_t)w * w_bytes + rog[g]);
+                        const T l0 = (T) * reinterpret_cast<gptr<TJ>>(Jb00 + o), l1 = (T) * reinterpret_cast<gptr<TJ>>(Jb10 + o);
+                        const T h0 = DPP ? l0 : (T) * reinterpret_cast<gptr<TJ>>(Jb01 + o);
+                        const T h1 = DPP ? l1 : (T) * reinterpret_cast<gptr<TJ>>(Jb11 + o);
+                        A[g][w] = f2{xl(l0, h0), xl(l1, h1)};
                     }
                 }
         }
         prev_c1 = c1;
-        // ---- the corner rows at knot c1 + 1: every load of the step, back to back ----------------------------
-        const uint32_t vrow = voff0 + (uint32_t)(c1 + 1) * s1_bytes;
-        // loads run kCsAhead groups ahead of the arithmetic (software pipeline over the straight-line group sequence)
-        T lo[NG][2][NW], hi[NG][2][NW];
-        auto load_group = [&](int g) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const uint32_t o = roff[g][w] + vrow;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    lo[g][k][w] = (T) * reinterpret_cast<gptr<TJ>>((k ? Jb10 : Jb00) + o);
-                    hi[g][k][w] = (T) * reinterpret_cast<gptr<TJ>>((k ? Jb11 : Jb01) + o);
-                }
-            }
-        };
-#pragma unroll
-        for (int g = 0; g < kCsAhead && g < NG; ++g) load_group(g);
+        load_groups(NGH, NG, (uint32_t)(c1 + 1) * s1_bytes);              // H1 of this step
         // ---- this state's cost without the control terms -----------------------------------------------
-        T gstep = gcol;
+        gstep = gcol;
         if (npre > npre_col) {
             si[1] = i1;
             if (step_uniform) {
@@ -218,71 +401,30 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                 }
             }
         }
-        T best = (T)0;
-        int best_u = 0;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + kCsAhead < NG) {
-                load_group(g + kCsAhead);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            f4 m0[MM], m1[MM];
-#pragma unroll
-            for (int ms = 0; ms < MM; ++ms) {
-                m0[ms] = s_slots[wave][(g * MM + ms) * 2];
-                if (!FASTCOST && ncu > 1) m1[ms] = s_slots[wave][(g * MM + ms) * 2 + 1];
-            }
-            T Bv[2][NW];
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const T an = fma_t<T>(t0, (T)(hi[g][k][w] - lo[g][k][w]), lo[g][k][w]);
-                    Bv[k][w] = fma_t<T>(t1, (T)(an - A[g][k][w]), A[g][k][w]);
-                    A[g][k][w] = an;
-                }
-#pragma unroll
-            for (int ms = 0; ms < MM; ++ms) {
-                if (ms < nmem[g]) {
-                    const int minfo = __builtin_amdgcn_readfirstlane(__float_as_int(m0[ms].w));
-                    const int u = minfo & 0xff, off = (minfo >> 8) & 0xff, tie = minfo >> 16;
-                    const T tw = m0[ms].x, tg = m0[ms].y;
-                    // the member's 2 x 2 corners of B: window knots off, off + 1 of both group rows
-                    T b00, b01, b10, b11;                        // [k][window lo/hi]
-                    if (off == 0) { b00 = Bv[0][0]; b01 = Bv[0][1]; b10 = Bv[1][0]; b11 = Bv[1][1]; }
-                    else          { b00 = Bv[0][1]; b01 = Bv[0][2]; b10 = Bv[1][1]; b11 = Bv[1][2]; }
-                    T interp;
-                    if (GAX == 3) {          // window = axis 2 (lerped first), group = axis 3
-                        const T v0 = fma_t<T>(tw, (T)(b01 - b00), b00);
-                        const T v1 = fma_t<T>(tw, (T)(b11 - b10), b10);
-                        interp = fma_t<T>(tg, (T)(v1 - v0), v0);
-                    } else {                 // group = axis 2 (lerped first), window = axis 3
-                        const T v0 = fma_t<T>(tg, (T)(b10 - b00), b00);
-                        const T v1 = fma_t<T>(tg, (T)(b11 - b01), b01);
-                        interp = fma_t<T>(tw, (T)(v1 - v0), v0);
-                    }
-                    T gg;
-                    if (FASTCOST) {                              // the usual shape: state terms + ONE control term
-                        gg = (T)(gstep + m0[ms].z);
-                    } else {
-                        gg = gstep;
-                        for (int k = 0; k < ncu; ++k) {
-                            const T x = k == 0 ? m0[ms].z : (k == 1 ? m1[ms].x : (k == 2 ? m1[ms].y : m1[ms].z));
-                            gg = (npre == 0 && k == 0) ? x : (T)(gg + x);
-                        }
-                    }
-                    const T tot = (T)(gg + interp);
-                    bool take;
-                    if (g == 0 && ms == 0) take = true;
-                    else if (tie) take = tot < best || (tot == best && u < best_u);
-                    else take = tot < best;
-                    if (take) { best = tot; best_u = u; }
+        best = __builtin_inff();
+        best_u = 0x7fffffff;
+        await_groups(0, NGH, ng > NGH ? ng - NGH : 0);                    // H0 landed; H1 may still be in flight
+        compute_groups(0, NGH);
+        load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // H0 of the next step
+        await_groups(NGH, NG, ng < NGH ? ng : NGH);                       // H1 landed; the next H0 in flight
+        compute_groups(NGH, NG);
+        // ---- results: parked in LDS, written out every kCsFlush steps ------------------------------------
+        const int slot = i1 % kCsFlush;
+        s_best[wave][slot][lane] = best;
+        s_idx[wave][slot][lane] = best_u + index_base;
+        if (slot == kCsFlush - 1 || i1 == n1 - 1) {
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                const int first = i1 - slot;
+                for (int j = 0; j <= slot; ++j) {
+                    stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)(first + j)), s_best[wave][j][lane]);
+                    if (idx_out) idx_out[idx_col + (uint32_t)n0 * (uint32_t)(first + j)] = s_idx[wave][j][lane];
                 }
             }
-        }
-        if (valid) {
-            stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)i1), best);
-            if (idx_out) idx_out[idx_col + (uint32_t)n0 * (uint32_t)i1] = best_u + index_base;
+            // let the stores finish here (and with them the gathers in flight): the counted waits above rely on no
+            // store being pending, loads and stores complete out of order with each other
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -60,6 +60,18 @@ class hjb_problem(C.Structure):
 hjb_progress_fn = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double)
 
 
+class hjb_probe(C.Structure):
+    _fields_ = [
+        ("lo", C.c_int32 * HJB_MAX_D),
+        ("hi", C.c_int32 * HJB_MAX_D),
+        ("control", C.c_int32 * HJB_MAX_C),
+        ("reserved", C.c_int32),
+        ("g", C.c_void_p),
+        ("x_next", C.c_void_p),
+        ("j_interp", C.c_void_p),
+    ]
+
+
 class hjb_solve_opts(C.Structure):
     _fields_ = [
         ("n_stages", C.c_int32),
@@ -72,6 +84,9 @@ class hjb_solve_opts(C.Structure):
         ("idx_stages", C.c_void_p),
         ("progress", hjb_progress_fn),
         ("progress_user", C.c_void_p),
+        ("probe", C.POINTER(hjb_probe)),
+        ("progress_every_stage", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -109,6 +124,7 @@ SYMBOLS = {
     "hjb_last_error": (C.c_char_p, [C.c_void_p]),
     "hjb_get_info": (C.c_int32, [C.c_void_p, C.POINTER(hjb_info)]),
     "hjb_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "hjb_get_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "hjb_backup_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_backup_stage_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_check_device_status": (C.c_int32, [C.c_void_p, C.c_void_p]),
@@ -116,6 +132,21 @@ SYMBOLS = {
     "hjb_policy_lookup": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                       C.POINTER(C.POINTER(C.c_double)), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                       C.c_void_p]),
+    "hjb_probe_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(hjb_probe)]),
+    # flat builder API (primitives and plain arrays only: what MATLAB's calllib can marshal)
+    "hjb_problem_new": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                    C.POINTER(C.c_void_p)]),
+    "hjb_problem_set_knots": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int32]),
+    "hjb_problem_add_next_term": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_int64]),
+    "hjb_problem_add_cost_term": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]),
+    "hjb_problem_set_slab": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "hjb_problem_set_model": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_create_from": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hjb_problem_free": (C.c_int32, [C.c_void_p]),
+    "hjb_problem_last_error": (C.c_char_p, [C.c_void_p]),
+    "hjb_solve_flat": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "hjb_get_info_flat": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 HJB_LOOKUP_NEAREST = 0
 HJB_LOOKUP_LINEAR = 1

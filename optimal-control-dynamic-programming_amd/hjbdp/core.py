@@ -136,6 +136,11 @@ class Backup:
     def set_option(self, key, value):
         _check(self.lib, self._h, self.lib.hjb_set_option(self._h, key.encode(), int(value)))
 
+    def get_option(self, key):
+        v = C.c_int64()
+        _check(self.lib, self._h, self.lib.hjb_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     # -- one stage, host buffers -------------------------------------------
     def backup_stage(self, J_next):
         """[J_k, idx] = min(g + F(x_next), [], ctrl): J_next/J_k in the (haloed)
@@ -165,10 +170,13 @@ class Backup:
 
     # -- the whole sweep -----------------------------------------------------
     def solve(self, n_stages, terminal=None, keep_J=False, keep_idx=False, monitor_period=0, monitor_tol=0.0,
-              progress=None):
+              progress=None, progress_every_stage=False, probe=None):
         """Backward sweep of n_stages backups.  Returns a dict with J (final), idx
         (final), optional J_stages/idx_stages [nS, n_stages] with reference stage
-        k_s at column k_s-1, stages_done, stopped_early, sweep_ms."""
+        k_s at column k_s-1, stages_done, stopped_early, sweep_ms.
+        probe = {"lo": [..D], "hi": [..D], "control": [..C], "want": ("g", "x_next", "j_interp")} (0-based,
+        half-open) asks for the reference's debug taps (Dynamic_Solver.m:212-219) of every stage: out["probe"]
+        holds g [block..., n_stages], x_next [block..., D, n_stages], j_interp [block..., n_stages]."""
         nS, dt = self.spec.nS, self.spec.j_dtype
         o = _abi.hjb_solve_opts()
         o.n_stages = int(n_stages)
@@ -195,12 +203,54 @@ class Backup:
             cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
             keep.append(cb)
             o.progress = cb
+        o.progress_every_stage = 1 if progress_every_stage else 0
+        pout = None
+        if probe is not None:
+            pout, pb = self._make_probe(probe, n_stages)
+            keep.append(pb)
+            o.probe = C.pointer(pb)
         res = _abi.hjb_result()
         st = self.lib.hjb_solve(self._h, C.byref(o), C.byref(res))
         _check(self.lib, self._h, st)
         return {"J": J, "idx": idx, "J_stages": Js, "idx_stages": Is, "stages_done": res.stages_done,
                 "stopped_early": bool(res.stopped_early), "sweep_ms": res.sweep_ms, "last_e": res.last_e,
-                "last_e2": res.last_e2}
+                "last_e2": res.last_e2, "probe": pout}
+
+    def _make_probe(self, probe, n_planes):
+        D, Cc = self.spec.D, self.spec.C
+        pb = _abi.hjb_probe()
+        ext = []
+        for a in range(D):
+            pb.lo[a], pb.hi[a] = int(probe["lo"][a]), int(probe["hi"][a])
+            ext.append(pb.hi[a] - pb.lo[a])
+        for c in range(Cc):
+            pb.control[c] = int(probe["control"][c])
+        want = probe.get("want", ("g", "x_next", "j_interp"))
+        dt = self.spec.dtype
+        tail = (n_planes,) if n_planes else ()
+        out = {}
+        if "g" in want:
+            out["g"] = np.zeros(tuple(ext) + tail, dtype=dt, order="F")
+            pb.g = out["g"].ctypes.data
+        if "x_next" in want:
+            out["x_next"] = np.zeros(tuple(ext) + (D,) + tail, dtype=dt, order="F")
+            pb.x_next = out["x_next"].ctypes.data
+        if "j_interp" in want:
+            out["j_interp"] = np.zeros(tuple(ext) + tail, dtype=dt, order="F")
+            pb.j_interp = out["j_interp"].ctypes.data
+        return out, pb
+
+    def probe_stage(self, probe, J_next=None):
+        """One stage of the debug taps from a host J_next (hjb_probe_stage)."""
+        out, pb = self._make_probe(probe, 0)
+        Jn = None
+        if J_next is not None:
+            Jn = np.ascontiguousarray(np.asarray(J_next, dtype=self.spec.j_dtype).reshape(-1, order="F"))
+        elif "j_interp" in out:
+            raise ValueError("j_interp needs J_next")
+        st = self.lib.hjb_probe_stage(self._h, Jn.ctypes.data if Jn is not None else None, C.byref(pb))
+        _check(self.lib, self._h, st)
+        return out
 
 
 def solve_many(specs, n_stages, device=0, **solve_kw):

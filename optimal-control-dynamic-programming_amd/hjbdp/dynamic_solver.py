@@ -85,8 +85,23 @@ class Dynamic_Solver:
         s_r, U_mesh = self.s_r, self._U_mesh
         self.X1_mesh, self.X2_mesh = np.meshgrid(s_r, s_r, indexing="ij")  # ndgrid, :70
         n_st = self.N - 1                                                  # for k=1:N-1, :86
+        # Dynamic_Solver.m:212-219 (`checkstagesXJF`, default 1): per stage the reference copies the fixed sub-block
+        # (50:55, 52:57, 105) of J_current_state, X_next_M1 and X_next_M2; the library evaluates that block on the GPU
+        # (hjb_probe).  MATLAB raises an index error when dx < 57 or du < 105; the mirror leaves the taps None instead
+        # (the fixture revision test/test_coder.m has no taps and runs at dx = 35).
+        probe = None
+        if self.checkstagesXJF and self.dx >= 57 and self.du >= 105:
+            probe = {"lo": (49, 51), "hi": (55, 57), "control": (104,), "want": ("g", "x_next", "j_interp")}
         with Backup(spec, device=self.device) as bk:
-            out = bk.solve(n_st, keep_J=True, keep_idx=True)
+            out = bk.solve(n_st, keep_J=True, keep_idx=True, probe=probe)
+        self.J_current_state_check = self.X_next_M1_check = self.X_next_M2_check = self.J_F_next_check = None
+        if probe is not None:
+            # plane k_s - 1 holds stage k_s; the reference indexes its taps by the loop counter k = N - k_s
+            flip = lambda a: a[..., ::-1]
+            self.J_current_state_check = flip(out["probe"]["g"])
+            self.X_next_M1_check = flip(out["probe"]["x_next"][:, :, 0, :])
+            self.X_next_M2_check = flip(out["probe"]["x_next"][:, :, 1, :])
+            self.J_F_next_check = flip(out["probe"]["j_interp"])        # commented out in the reference (:215)
         self.sweep_ms = out["sweep_ms"]
         dt = spec.dtype
         shape = (self.dx, self.dx, self.N)
@@ -98,27 +113,7 @@ class Dynamic_Solver:
         self.u_star[:, :, : n_st] = U_mesh[idx - 1].astype(dt)               # u_star(:,:,k_s) = U_mesh(u_star_idx)
         self.u_star_idx = idx[:, :, 0].copy()      # value left in obj.u_star_idx after the loop (k_s = 1)
         self.F_values = self.J_star[:, :, 0].copy()
-        self._debug_taps(spec, n_st)
         return self
-
-    def _debug_taps(self, spec, n_st):
-        """Dynamic_Solver.m:212-219 (`checkstagesXJF`, default 1): per stage k the reference copies the fixed
-        sub-block (50:55, 52:57, 105) of J_current_state, X_next_M1 and X_next_M2 - all three are stage-invariant
-        tables, so every plane holds the same 6x6 block.  Evaluated here from the broadcast terms in MATLAB's
-        left-to-right order.  MATLAB raises an index error when dx < 57 or du < 105; the mirror leaves the taps
-        None instead (the fixture revision test/test_coder.m has no taps and runs at dx = 35)."""
-        self.J_current_state_check = self.X_next_M1_check = self.X_next_M2_check = None
-        if not self.checkstagesXJF or self.dx < 57 or self.du < 105:
-            return
-        i, j, u = slice(49, 55), slice(51, 57), 104
-
-        def block(terms):
-            t0, t1, t2 = (t.data for t in terms)
-            return ((t0[i, None] + t1[None, j]).astype(spec.dtype) + t2[u]).astype(spec.dtype)
-        rep = lambda b: np.repeat(b[:, :, None], n_st, axis=2)
-        self.J_current_state_check = rep(block(spec.cost_terms))
-        self.X_next_M1_check = rep(block(spec.next_terms[0]))
-        self.X_next_M2_check = rep(block(spec.next_terms[1]))
 
     # ------------------------------------------------------------------
     def a_D(self, X1, X2, Ui):

@@ -20,7 +20,7 @@ def lib(built):
 def test_every_declared_symbol_is_exported(lib):
     from hjbdp import _abi
     header = (ROOT / "include" / "hjbdp.h").read_text()
-    declared = set(re.findall(r"\b(hjb_[a-z_]+)\s*\(", header)) - {"hjb_progress_fn"}
+    declared = set(re.findall(r"\b(hjb_[a-z_0-9]+)\s*\(", header)) - {"hjb_progress_fn"}
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -40,7 +40,8 @@ def test_struct_layout_matches_header(lib):
     expect = 56 + 8 * 6 + 4 * 6 + 16 * 12 * 6 + 8 + 16 * 12 + 16
     expect += 4 + 4 + 8 + 8 * 4             # model, reserved1, model_h, model_tables[4]
     assert C.sizeof(_abi.hjb_problem) == expect
-    assert C.sizeof(_abi.hjb_solve_opts) == 4 + 4 + 8 + 8 * 5 + 8 + 8
+    assert C.sizeof(_abi.hjb_solve_opts) == 4 + 4 + 8 + 8 * 5 + 8 + 8 + 8 + 4 + 4
+    assert C.sizeof(_abi.hjb_probe) == 4 * 6 * 2 + 4 * 3 + 4 + 8 * 3
     assert C.sizeof(_abi.hjb_result) == 32
     assert C.sizeof(_abi.hjb_info) == 48
 
@@ -66,6 +67,32 @@ def test_invalid_problems_are_rejected_with_status(lib):
     assert lib.hjb_create(C.byref(p), 0, C.byref(h)) == _abi.HJB_E_INVALID
     assert lib.hjb_create(None, 0, C.byref(h)) == _abi.HJB_E_INVALID
     assert lib.hjb_destroy(None) == _abi.HJB_OK
+
+
+def test_flat_builder_validates_without_a_gpu(lib):
+    """The flat builder API (what a MATLAB host binds with calllib: primitives and plain arrays only) checks its
+    arguments on the host; only hjb_create_from needs a device."""
+    from hjbdp import _abi
+    b = C.c_void_p()
+    n = (C.c_int32 * 2)(5, 4)
+    m = (C.c_int32 * 1)(3)
+    assert lib.hjb_problem_new(2, 1, n, m, _abi.HJB_F64, 1, C.byref(b)) == _abi.HJB_OK
+    k = np.linspace(0, 1, 5)
+    assert lib.hjb_problem_set_knots(b, 0, k.ctypes.data_as(C.POINTER(C.c_double)), 5) == _abi.HJB_OK
+    assert lib.hjb_problem_set_knots(b, 1, k.ctypes.data_as(C.POINTER(C.c_double)), 5) == _abi.HJB_E_INVALID   # 4 points
+    assert b"4 grid points" in lib.hjb_problem_last_error(b)
+    assert lib.hjb_problem_set_knots(b, 2, k.ctypes.data_as(C.POINTER(C.c_double)), 5) == _abi.HJB_E_INVALID
+    t = np.zeros(20)
+    assert lib.hjb_problem_add_next_term(b, 0, 0b011, t.ctypes.data, 20) == _abi.HJB_OK
+    assert lib.hjb_problem_add_next_term(b, 0, 0b011, t.ctypes.data, 19) == _abi.HJB_E_INVALID   # wrong element count
+    assert lib.hjb_problem_add_next_term(b, 0, 0b1000, t.ctypes.data, 1) == _abi.HJB_E_INVALID   # dim 3 does not exist
+    assert lib.hjb_problem_add_cost_term(b, 0b100, t.ctypes.data, 3) == _abi.HJB_OK
+    h = C.c_void_p()
+    st = lib.hjb_create_from(b, 0, C.byref(h))
+    assert st == _abi.HJB_E_INVALID and b"knots of axis 1" in lib.hjb_problem_last_error(b)
+    assert lib.hjb_problem_free(b) == _abi.HJB_OK
+    assert lib.hjb_problem_new(7, 1, n, m, _abi.HJB_F64, 1, C.byref(b)) == _abi.HJB_E_UNSUPPORTED
+    assert lib.hjb_problem_free(None) == _abi.HJB_OK
 
 
 def test_no_gpu_means_loud_failure_not_fallback(lib):

@@ -1,0 +1,150 @@
+"""GPU tests (-m gpu) of the parts of the boundary a MATLAB host would use: the flat builder API (primitives and plain
+arrays only - what loadlibrary/calllib can marshal) and the probe block (the reference's debug taps,
+test/Dynamic_Solver.m:212-219)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import hjbdp
+    from hjbdp import _abi
+    from oracle import c_oracle
+    if hjbdp.device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run the HIP path (no fallback)")
+    return hjbdp, _abi, c_oracle
+
+
+def test_kirk_fixture_through_the_flat_api_only(env, golden):
+    """C1a (test/obj_1.txt: 35x35 states x 100 controls, N = 130, float64) solved with nothing but the flat entry
+    points, exactly as the MATLAB shim matlab/hjbdp_solve.m drives them: J* within 1e-12 of test/obj_1.mat on all 129
+    stages (north_star: 1e-6), u* equal, and equal bit for bit to the struct API."""
+    hjbdp, _abi, c_oracle = env
+    lib = hjbdp.load_library()
+    A = np.array([[0.9974, 0.0539], [-0.1078, 1.1591]])
+    B = np.array([0.0013, 0.0539])
+    Q11, Q22, R = 0.25, 0.05, 0.05
+    s_r = np.ascontiguousarray(golden["knots1"])                 # the fixture's own grid vector (X1_mesh(:,1))
+    U = np.ascontiguousarray(golden["U_mesh"])
+    dx, du, N = 35, 100, 130
+    n = (C.c_int32 * 2)(dx, dx)
+    m = (C.c_int32 * 1)(du)
+    b = C.c_void_p()
+
+    def ok(st):
+        assert st == _abi.HJB_OK, (lib.hjb_problem_last_error(b), lib.hjb_last_error(None))
+
+    ok(lib.hjb_problem_new(2, 1, n, m, _abi.HJB_F64, 1, C.byref(b)))
+    for a in range(2):
+        ok(lib.hjb_problem_set_knots(b, a, s_r.ctypes.data_as(C.POINTER(C.c_double)), dx))
+    # a_D_M (Dynamic_Solver.m:184-188): X_next_a = A(a,1)*X1 + A(a,2)*X2 + B(a)*U, left to right
+    for a in range(2):
+        for mask, vec in ((0b001, A[a, 0] * s_r), (0b010, A[a, 1] * s_r), (0b100, B[a] * U)):
+            v = np.ascontiguousarray(vec)
+            ok(lib.hjb_problem_add_next_term(b, a, mask, v.ctypes.data, v.size))
+    # g_D (:196-200)
+    for mask, vec in ((0b001, Q11 * s_r ** 2), (0b010, Q22 * s_r ** 2), (0b100, R * U ** 2)):
+        v = np.ascontiguousarray(vec)
+        ok(lib.hjb_problem_add_cost_term(b, mask, v.ctypes.data, v.size))
+    h = C.c_void_p()
+    ok(lib.hjb_create_from(b, 0, C.byref(h)))
+    ok(lib.hjb_problem_free(b))
+    nS, n_st = dx * dx, N - 1
+    Js = np.zeros((nS, n_st), order="F")
+    Is = np.zeros((nS, n_st), dtype=np.int32, order="F")
+    Jf = np.zeros(nS)
+    If = np.zeros(nS, dtype=np.int32)
+    done, early, ms = C.c_int32(), C.c_int32(), C.c_double()
+    st = lib.hjb_solve_flat(h, n_st, 0, 0.0, None, Jf.ctypes.data, If.ctypes.data, Js.ctypes.data, Is.ctypes.data,
+                            C.byref(done), C.byref(early), C.byref(ms))
+    assert st == _abi.HJB_OK, lib.hjb_last_error(h)
+    info = (C.c_int64 * 8)()
+    assert lib.hjb_get_info_flat(h, info) == _abi.HJB_OK and info[0] == nS and info[1] == du
+    assert lib.hjb_destroy(h) == _abi.HJB_OK
+    assert done.value == n_st and early.value == 0 and ms.value > 0
+    ref = golden["J_star"][:, :, :n_st]
+    mine = Js.reshape(dx, dx, n_st, order="F")
+    assert np.max(np.abs(mine - ref) / np.abs(ref)) <= 1e-12
+    assert np.array_equal(Is.reshape(dx, dx, n_st, order="F") - 1, golden["u_star_idx"][:, :, :n_st])
+    assert np.array_equal(Jf, Js[:, 0]) and np.array_equal(If, Is[:, 0])
+    # the struct API on the same numbers gives the same bits
+    ds = hjbdp.Dynamic_Solver(precision="double")
+    ds.N, ds.dx, ds.du = N, dx, du
+    with hjbdp.Backup(ds.build_spec()) as bk:
+        out = bk.solve(n_st, keep_J=True)
+    if np.array_equal(ds.s_r, s_r):
+        assert np.array_equal(out["J_stages"], Js)
+
+
+@pytest.mark.parametrize("precision", ["single", "double"])
+def test_probe_block_equals_the_reference_taps(env, precision):
+    """Dynamic_Solver.m:212-219: per stage the sub-block (50:55, 52:57, 105) of J_current_state, X_next_M1, X_next_M2
+    (and J_F_next, commented out there).  GPU probe vs the reference's own formulas a_D_M (:184-188) / g_D (:196-200)
+    evaluated in numpy with MATLAB's left-to-right order, and vs the interpolation of the oracle."""
+    hjbdp, _abi, c_oracle = env
+    from oracle import hjb_oracle
+    ds = hjbdp.Dynamic_Solver(precision=precision)
+    ds.N, ds.dx, ds.du = 6, 60, 110
+    ds.run()
+    spec = ds.build_spec()
+    dt = spec.dtype
+    i, j, u = slice(49, 55), slice(51, 57), 104
+
+    def block(terms):
+        t0, t1, t2 = (t.data for t in terms)
+        return ((t0[i, None] + t1[None, j]).astype(dt) + t2[u]).astype(dt)
+    n_st = ds.N - 1
+    assert ds.J_current_state_check.shape == (6, 6, n_st) and ds.J_current_state_check.dtype == dt
+    for k in range(n_st):
+        assert np.array_equal(ds.J_current_state_check[:, :, k], block(spec.cost_terms))
+        assert np.array_equal(ds.X_next_M1_check[:, :, k], block(spec.next_terms[0]))
+        assert np.array_equal(ds.X_next_M2_check[:, :, k], block(spec.next_terms[1]))
+    # against the formulas themselves, in float64
+    s_r = ds.s_r.astype(np.float64)
+    U = ds._U_mesh[u]
+    X1, X2 = np.meshgrid(s_r[i], s_r[j], indexing="ij")
+    tol = 1e-6 if precision == "single" else 1e-13
+    assert np.allclose(ds.X_next_M1_check[:, :, 2], ds.A[0, 0] * X1 + ds.A[0, 1] * X2 + ds.B[0, 0] * U, rtol=tol)
+    assert np.allclose(ds.X_next_M2_check[:, :, 0], ds.A[1, 0] * X1 + ds.A[1, 1] * X2 + ds.B[1, 0] * U, rtol=tol)
+    assert np.allclose(ds.J_current_state_check[:, :, 3], ds.Q[0, 0] * X1 ** 2 + ds.Q[1, 1] * X2 ** 2 + ds.R * U ** 2, rtol=tol)
+    # J_F_next_check(:,:,k): J_{k+1} interpolated at the tapped next states; loop counter k = 1 taps the terminal cost
+    # (zeros), k = 2 taps J of reference stage N-1, ...  (J_star(:,:,N-k+1))
+    assert not ds.J_F_next_check[:, :, 0].any()
+    knots = [ds.s_r.astype(np.float64)] * 2
+    for k in range(1, n_st):
+        Jn = ds.J_star[:, :, ds.N - 1 - k].astype(np.float64)            # 0-based plane of reference stage N-k
+        q = np.stack([ds.X_next_M1_check[:, :, k].astype(np.float64).ravel(), ds.X_next_M2_check[:, :, k].astype(np.float64).ravel()])
+        ref = hjb_oracle.interp_linear(knots, Jn, q).reshape(6, 6)
+        assert np.allclose(ds.J_F_next_check[:, :, k], ref, rtol=2e-5 if precision == "single" else 1e-12, atol=1e-6 if precision == "single" else 0)
+    # out of range = the reference's index error, as a status
+    with hjbdp.Backup(spec) as bk:
+        with pytest.raises(hjbdp.HjbError):
+            bk.solve(2, probe={"lo": (49, 51), "hi": (61, 57), "control": (104,)})
+        with pytest.raises(hjbdp.HjbError):
+            bk.solve(2, probe={"lo": (49, 51), "hi": (55, 57), "control": (110,)})
+        # one stage from a host J_next (hjb_probe_stage) = the sweep's plane
+        one = bk.probe_stage({"lo": (49, 51), "hi": (55, 57), "control": (104,)}, J_next=ds.J_star[:, :, ds.N - 2])
+        assert np.array_equal(one["j_interp"], ds.J_F_next_check[:, :, 1])
+        assert np.array_equal(one["g"], ds.J_current_state_check[:, :, 0])
+    ds35 = hjbdp.Dynamic_Solver(precision=precision)
+    ds35.N, ds35.dx, ds35.du = 4, 35, 100
+    ds35.run()
+    assert ds35.J_current_state_check is None
+
+
+def test_progress_after_every_stage(env):
+    """Dynamic_Solver.m:101 prints one line per stage: hjb_solve_opts.progress_every_stage."""
+    hjbdp, _abi, c_oracle = env
+    ds = hjbdp.Dynamic_Solver(precision="double")
+    ds.N, ds.dx, ds.du = 12, 20, 30
+    seen = []
+    with hjbdp.Backup(ds.build_spec()) as bk:
+        out = bk.solve(11, progress=lambda k_s, e, e2, sec: seen.append((k_s, sec)), progress_every_stage=True)
+        ref = bk.solve(11)
+    assert [k for k, _ in seen] == list(range(11, 0, -1))
+    assert all(b[1] >= a[1] for a, b in zip(seen, seen[1:]))
+    assert np.array_equal(out["J"], ref["J"])

@@ -207,23 +207,27 @@ def test_rowwise_variant_pos_att_slab_and_f16(env):
     assert np.array_equal(oh["J"], rh["J"]) and np.array_equal(oh["idx"], rh["idx"])
 
 
+_COLSWEEP_FORMS = set()
 COLSWEEP = [
-    # n, nU, nonuniform, gax, cost, a1_amp, levels, j_storage, terminal
-    ((70, 9, 8, 11), 9, False, 3, "fast", 0.6, 5, None, True),       # two chunks of axis 0 (64 + 6)
-    ((64, 7, 9, 12), 9, True, 3, "fast", 0.6, 5, None, False),       # zero terminal: every first-stage total ties
-    ((33, 10, 12, 7), 9, True, 2, "fast", 0.5, 5, None, True),       # group axis = axis 2, window = the last axis
-    ((5, 4, 3, 4), 6, False, 3, "fast", 0.6, 3, None, True),         # tiny
-    ((40, 13, 6, 9), 9, True, 3, "fast", 1.8, 5, None, True),        # axis-1 cells jump: re-priming inside a column
-    ((37, 6, 7, 10), 12, False, 3, "multi", 0.6, 4, None, True),     # two control-only cost terms
-    ((37, 6, 7, 10), 9, True, 2, "step01", 0.6, 5, None, True),      # per-step cost term over (dim 0, dim 1)
-    ((20, 6, 7, 10), 7, False, 3, "ctrl_only", 0.6, 6, None, True),  # no state cost term; 6 groups
-    ((66, 8, 9, 10), 9, True, 3, "fast", 0.6, 5, "f16", True),       # float16 cost-to-go storage
-    ((30, 8, 9, 10), 16, False, 3, "fast", 0.6, 5, None, True),      # 16 controls: groups split at 3 members
+    # n, nU, nonuniform, gax, cost, a1_amp, levels, j_storage, terminal, dpp (a guess only: recorded, not asserted)
+    ((70, 9, 8, 11), 9, False, 3, "fast", 0.6, 5, None, True, True),       # two chunks of axis 0
+    ((130, 7, 5, 6), 9, False, 3, "fast", 0.6, 5, None, False, True),      # three chunks; zero terminal: every first-stage total ties
+    ((64, 7, 9, 12), 9, True, 3, "fast", 0.6, 5, None, False, False),      # uneven knots: both axis-0 neighbours loaded
+    ((33, 10, 12, 7), 9, True, 2, "fast", 0.5, 5, None, True, False),      # group axis = axis 2, window = the last axis
+    ((63, 10, 12, 7), 9, False, 2, "fast", 0.5, 5, None, True, True),
+    ((5, 4, 3, 4), 6, False, 3, "fast", 0.6, 3, None, True, True),         # tiny
+    ((40, 13, 6, 9), 9, False, 3, "fast", 1.8, 5, None, True, True),       # axis-1 cells jump: re-priming inside a column
+    ((37, 6, 7, 10), 12, False, 3, "multi", 0.6, 4, None, True, True),     # two control-only cost terms
+    ((37, 6, 7, 10), 9, True, 2, "step01", 0.6, 5, None, True, False),     # per-step cost term over (dim 0, dim 1)
+    ((20, 6, 7, 10), 7, False, 3, "ctrl_only", 0.6, 6, None, True, True),  # no state cost term; 6 groups
+    ((66, 8, 9, 10), 9, False, 3, "fast", 0.6, 5, "f16", True, True),      # float16 cost-to-go storage
+    ((66, 8, 9, 10), 9, True, 3, "fast", 0.6, 5, "f16", True, False),
+    ((30, 8, 9, 10), 16, False, 3, "fast", 0.6, 5, None, True, True),      # 16 controls: groups split when their slots are full
 ]
 
 
-@pytest.mark.parametrize("n,nU,nonuniform,gax,cost,a1_amp,levels,j_storage,terminal", COLSWEEP)
-def test_colsweep_variant_bit_exact(env, n, nU, nonuniform, gax, cost, a1_amp, levels, j_storage, terminal):
+@pytest.mark.parametrize("n,nU,nonuniform,gax,cost,a1_amp,levels,j_storage,terminal,dpp", COLSWEEP)
+def test_colsweep_variant_bit_exact(env, n, nU, nonuniform, gax, cost, a1_amp, levels, j_storage, terminal, dpp):
     """Variant 7 (column sweep, kernels_colsweep.h): the two control-independent lerps once per corner row, rolling
     along axis 1; controls grouped by the cell of the group axis.  Bit-exact J and argmin against the oracle."""
     hjbdp, _abi, c_oracle = env
@@ -234,14 +238,28 @@ def test_colsweep_variant_bit_exact(env, n, nU, nonuniform, gax, cost, a1_amp, l
     ref = c_oracle.sweep(_abi, spec, 3, terminal=term, keep_J=True, keep_idx=True)
     with hjbdp.Backup(spec, variant=7) as bk:
         assert bk.info()["kernel_variant"] == 7
+        dpp_on = bk.get_option("cs_dpp")                    # uneven knots usually rule the DPP form out (host check)
+        _COLSWEEP_FORMS.add((dpp_on, dpp))
+        assert bk.get_option("cs_group_axis") in (2, 3) and 1 <= bk.get_option("cs_groups") <= 6
         out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
-        for t2, t3 in ((1, 1), (5, 3)):                      # ragged traversal tiles give the same result
-            bk.set_option("cs_tile2", t2)
-            bk.set_option("cs_tile3", t3)
+        assert np.array_equal(out["J_stages"], ref["J_stages"])
+        assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+        for mod in (1, 3):                                   # any column -> XCD assignment gives the same result
+            bk.set_option("cs_xcd_mod", mod)
             o2 = bk.solve(3, terminal=term)
-            assert np.array_equal(o2["J"], ref["J"]) and np.array_equal(o2["idx"], ref["idx"]), (t2, t3)
-    assert np.array_equal(out["J_stages"], ref["J_stages"])
-    assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+            assert np.array_equal(o2["J"], ref["J"]) and np.array_equal(o2["idx"], ref["idx"]), mod
+        if dpp_on:                                           # the two-loads-per-row form on the same problem
+            bk.set_option("cs_dpp", 0)
+            assert bk.get_option("cs_dpp") == 0
+            o3 = bk.solve(3, terminal=term)
+            assert np.array_equal(o3["J"], ref["J"]) and np.array_equal(o3["idx"], ref["idx"])
+
+
+def test_colsweep_both_forms_were_exercised():
+    """Runs after the parametrised cases: the DPP form and the two-loads form must both have been selected by the
+    host check on some case (otherwise the table above no longer covers one of them)."""
+    forms = {f for f, _ in _COLSWEEP_FORMS}
+    assert forms == {0, 1}, _COLSWEEP_FORMS
 
 
 @pytest.mark.parametrize("gax", [2, 3])

@@ -177,25 +177,6 @@ def test_quaternion_model_restatement(orc):
         hjbdp.permute_state_axes(mspec, (1, 0, 2, 3, 4, 5))
 
 
-def test_dynamic_solver_debug_taps():
-    """Dynamic_Solver.m:212-219 restated on the host (no GPU): the tapped sub-blocks equal the reference's
-    formulas a_D_M (:184-188) and g_D (:196-200) evaluated directly at (50:55, 52:57, 105)."""
-    import hjbdp
-    ds = hjbdp.Dynamic_Solver()
-    spec = ds.build_spec()
-    ds._debug_taps(spec, 4)
-    s_r = ds.s_r.astype(np.float64)
-    U = ds._U_mesh[104]
-    X1, X2 = np.meshgrid(s_r[49:55], s_r[51:57], indexing="ij")
-    assert ds.J_current_state_check.shape == (6, 6, 4) and ds.J_current_state_check.dtype == np.float32
-    assert np.allclose(ds.X_next_M1_check[:, :, 2], ds.A[0, 0] * X1 + ds.A[0, 1] * X2 + ds.B[0, 0] * U, rtol=1e-6)
-    assert np.allclose(ds.X_next_M2_check[:, :, 0], ds.A[1, 0] * X1 + ds.A[1, 1] * X2 + ds.B[1, 0] * U, rtol=1e-6)
-    assert np.allclose(ds.J_current_state_check[:, :, 3], ds.Q[0, 0] * X1 ** 2 + ds.Q[1, 1] * X2 ** 2 + ds.R * U ** 2, rtol=1e-6)
-    ds.dx = 35
-    ds._debug_taps(ds.build_spec(), 4)
-    assert ds.J_current_state_check is None
-
-
 def test_orbit_routines_against_closed_forms():
     """hjbdp/orbit.py (position-control/private/*.m restated): one orbital period returns the state,
     energy and angular momentum are conserved, perigee/apogee radii match the elements, and the relative-motion

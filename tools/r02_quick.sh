@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r02d; mkdir -p $O; rm -f $O/quick.log
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_flat_api.py -x -q -k "colsweep or flat or probe or progress" --timeout 600 > $O/pytest_cs.log 2>&1; echo "pytest rc=$?"; tail -n 5 $O/pytest_cs.log
+timeout 900 python -m pytest tests/test_gpu_solvers.py -x -q -k "c4" --timeout 800 > $O/pytest_c4.log 2>&1; echo "pytest c4 rc=$?"; tail -n 5 $O/pytest_c4.log
+for m in 0 1; do ORDER=0,2,1,3 CS_XCD_MOD=$m timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep variant | sed "s/^/mod=$m: /" | tee -a $O/quick.log; done
+ORDER=0,2,3,1 CS_XCD_MOD=1 timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep variant | sed "s/^/xtwv mod1: /" | tee -a $O/quick.log
+ORDER=0,2,1,3 F16=1 CS_XCD_MOD=1 timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep variant | sed "s/^/f16 mod1: /" | tee -a $O/quick.log

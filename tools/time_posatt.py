@@ -1,7 +1,7 @@
 """Time one pos-att channel (Solver_pos_att) per stage kernel variant.
 usage: python tools/time_posatt.py [n=0 (reference grid 30,30,20,15) | n (n^4 grid)] [stages] [variants...]
 env: ORDER=0,2,1,3 relabels the state axes (new axis i = old axis ORDER[i]; old = x,v,theta,w), F16=1 stores J as
-float16, CS_TILE=t2,t3 sets the traversal tile of variant 7."""
+float16, CS_XCD_MOD=m sets the residue modulus of variant 7's column -> XCD assignment, CS_DPP=0 its two-loads form."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
@@ -32,11 +32,13 @@ for v in variants:
         with hjbdp.Backup(spec, variant=v % 10 if v >= 0 else None) as bk:
             if v >= 10:
                 bk.set_option("row_lean", 0)    # 16 = variant 6 without the lean form
-            if os.environ.get("CS_TILE"):
-                t2, t3 = (int(c) for c in os.environ["CS_TILE"].split(","))
-                bk.set_option("cs_tile2", t2)
-                bk.set_option("cs_tile3", t3)
+            if os.environ.get("CS_XCD_MOD"):
+                bk.set_option("cs_xcd_mod", int(os.environ["CS_XCD_MOD"]))
+            if os.environ.get("CS_DPP"):
+                bk.set_option("cs_dpp", int(os.environ["CS_DPP"]))
             info = bk.info()
+            if info["kernel_variant"] == 7:
+                print("variant 7: group axis %d, %d groups, dpp %d" % (bk.get_option("cs_group_axis"), bk.get_option("cs_groups"), bk.get_option("cs_dpp")))
             bk.solve(2)
             out = bk.solve(stages)
     except hjbdp.HjbError as e:
