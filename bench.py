@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py - the reference's headline metric on its named config, on MI355X.
+"""bench.py - the reference's headline metric on MI355X.
 
-Metric  : Bellman backups/s (state x control x stage)       [BASELINE.json `metric`]
-Workload: configs[1] "Solver_position 3-DOF, 101^3 state x 21^3 control grid,
-          100 stages, 1x MI355X" (SURVEY.md 8(d) C2), float32, synthetic/deterministic.
-Step    : ONE stage of the backward sweep = one fused backup kernel over the whole
-          grid (1,030,301 states x 9,261 controls = 9.54e9 backups).  Default
-          K=100 steps = the config's 100 stages.
-N GPUs  : one process per GPU (torchrun); the grid is sharded along its last state
-          axis, WEAK scaling: every rank owns 101 planes (global last axis 101*N),
-          with a per-stage neighbour halo exchange over RCCL (torch.distributed P2P).
+Metric  : Bellman backups/s (state x control x stage)                     [BASELINE.json `metric`]
+Workload: C4, the configuration the north-star target is quoted on ("the 6-D pos-att grid", BASELINE.json
+          configs[3]): ONE channel of Solver_pos_att (pos-att/Solver_pos_att.m:244-297) on a 120^4 = 2.07e8-cell
+          sym_linspace grid x the 9 thruster combinations, float32, zero terminal cost
+          (Solver_pos_att.m:264-265), state axes relabelled (x, theta, w, v) - see Solver_pos_att.FAST_AXIS_ORDER.
+          The other BASELINE configs are measured in the same run as extra keys of the line (`other_workloads`:
+          C5 = C4 with float16 cost-to-go storage, C2 = Solver_position 101^3 x 21^3); they are also parity tests.
+Step    : ONE stage of the backward sweep = one fused backup kernel over the whole grid (1.866e9 backups).
+N GPUs  : one process per GPU (torchrun), the FIXED grid sharded along its last state axis (v: next states move
+          < 1 plane, so the halo is one plane each side) = STRONG scaling; neighbour halo exchange per stage over RCCL
+          (torch.distributed P2P) overlapped with the interior planes' kernel.  A weak-scaling figure (120 planes of
+          the last axis per GPU) is an extra key.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the stage kernel with the
-ALGORITHMIC work of SURVEY.md 8(d): F_alg(3) = 41 flop/backup against the fp32
-vector peak (the binding roofline: every BASELINE config is VALU-bound) and
-(2*4+4) B/state/stage against HBM.  `cpu_baseline` times the oracle's C twin
-(oracle/hjb_oracle.c, OpenMP) on a bounded slab sample of the same workload.
+Prints ONE JSON line on rank 0.  `roofline`: the path is VALU-bound at every BASELINE config, so
+`achieved` = algorithmic flops F_alg(4) = 71 per backup / launch time against the 157.3 TFLOP/s fp32 vector peak; the
+executed-instruction view (`valu_issue_util`) and `traffic` come from rocprofv3 --pmc passes that THIS run makes on
+child processes of the same command (rank 0, N = 1; null when rocprofv3 is unavailable).  `cpu_baseline` times the
+oracle's C twin (oracle/hjb_oracle.c, OpenMP) on a bounded slab sample of the same workload.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -32,33 +40,68 @@ sys.path.insert(0, str(ROOT))
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (= f32-input MFMA rate)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_CYCLES_PER_WAVE_INSTR = 2.0   # wave64 on a SIMD-32 (MI355X_MICROARCH.md; profiles/r02_valu_rate.json)
+KERNEL_OF_VARIANT = {7: "k_backup_colsweep", 6: "k_backup_row", 5: "k_backup_tabled", 4: "k_backup_packed2",
+                     2: "k_backup_packed", 1: "k_backup_nested", 3: "k_backup_ctrlsplit", 0: "k_backup_generic"}
 
 
 def f_alg(D):
     return 3 * (2 ** D - 1) + 6 * D + 2   # SURVEY.md 8(d) "Algorithmic flops per backup"
 
 
+def build_spec(workload, n_last=None, n=120):
+    """-> (ProblemSpec, description).  n_last: planes of the last axis (weak scaling grows it); n: points per axis
+    of the pos-att grid (the configs are n = 120; smaller grids are for tests)."""
+    import numpy as np
+    import hjbdp
+    if workload in ("c4", "c5"):
+        pa = hjbdp.Solver_pos_att()
+        pa.cost_mode = "terms"
+        pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = n
+        sx, sv, st, sw = pa.grids()
+        if n_last and n_last != n:       # weak scaling: more v planes at the same spacing
+            from hjbdp.matlab_compat import sym_linspace_pos_att
+            sv = sym_linspace_pos_att(pa.v_min * n_last / float(n), pa.v_max * n_last / float(n), n_last)
+        spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                        pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+        spec, _ = hjbdp.permute_state_axes(spec, (0, 2, 3, 1))            # (x, theta, w, v): v last = the sharded axis
+        if workload == "c5":
+            spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32,
+                                     index_base=1, j_storage=np.float16)
+        name = "%s Solver_pos_att channel x: %s states (x,theta,w,v) x %d thruster combinations, %s, 1 stage per step" % (
+            workload.upper(), "x".join(str(k) for k in spec.n), spec.nU,
+            "float32" if workload == "c4" else "float32 arithmetic, float16 cost-to-go storage")
+        return spec, name
+    if workload == "c2":
+        from hjbdp.synthetic import position3d_spec
+        spec = position3d_spec(n=101, mu=21, n_last=n_last)
+        return spec, "C2 Solver_position 3-DOF: %s states x 21^3 controls, float32, 1 stage per step" % "x".join(str(k) for k in spec.n)
+    raise ValueError(workload)
+
+
 def cpu_baseline(spec, budget_s=15.0):
-    """Oracle C twin on this host's cores, on a slab sample (whole planes of the
-    last axis, mid-grid, with halos) of the SAME workload."""
+    """Oracle C twin on this host's cores, on a slab sample (whole planes of the last axis, mid-grid, with
+    halos) of the SAME workload."""
     import numpy as np
     from hjbdp import _abi
+    from hjbdp.sharded import required_halo
     from oracle import c_oracle
     c_oracle.build()
     lib = c_oracle.lib(_abi)
     cores = int(lib.orc_max_threads())
     inner = spec.nS // spec.n[-1]
+    hl, hh = required_halo(spec)
     mid = spec.n[-1] // 2
     rng = np.random.default_rng(0)
 
     def run(planes):
         b, e = mid, mid + planes
-        J = rng.random(inner * (planes + 2)).astype(spec.dtype)
+        J = rng.random(inner * (planes + hl + hh)).astype(spec.j_dtype)
         t0 = time.perf_counter()
-        c_oracle.backup_stage(_abi, spec, J, slab=(b, e, 1, 1), nthreads=cores)
+        c_oracle.backup_stage(_abi, spec, J, slab=(b, e, hl, hh), nthreads=cores)
         return time.perf_counter() - t0
     t1 = run(1)
-    planes = int(max(1, min(spec.n[-1] // 2 - 2, budget_s / max(t1, 1e-3))))
+    planes = int(max(1, min(spec.n[-1] // 2 - hh - 1, budget_s / max(t1, 1e-3))))
     t = run(planes) if planes > 1 else t1
     backups = inner * planes * spec.nU
     return {"value": backups / t, "unit": "backups/s", "cores": cores, "kind": "port",
@@ -66,56 +109,56 @@ def cpu_baseline(spec, budget_s=15.0):
                       "oracle/hjb_oracle.c, OpenMP" % (planes, spec.n[-1], inner * planes, spec.nU, t)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--grid-n", dest="n", type=int, default=101, help="state grid points per axis (config: 101)")
-    ap.add_argument("--grid-mu", dest="mu", type=int, default=21, help="control grid points per axis (config: 21)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=None, help="force a stage-kernel variant (testing)")
-    ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --share-gpu is a 1-GPU test mode")
-    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses cuda:0")
-    ap.add_argument("--weak-mult", type=int, default=1, help="testing: planes per rank = n * weak-mult")
-    ap.add_argument("--j-storage", default="f32", choices=["f32", "f16"],
-                    help="f16: cost-to-go stored as IEEE half, float32 arithmetic (BASELINE config 5; not the headline line)")
-    args = ap.parse_args()
+def collect_pmc(argv_child, kernel_filter, timeout_s=240):
+    """rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) on child processes running
+    `bench.py --pmc-child ...`; mean per launch of the stage kernel.  Runs BEFORE this process touches the GPU."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(rocprof).exists():
+        return None, "rocprofv3 not found"
+    sets = [["FETCH_SIZE"], ["WRITE_SIZE"],
+            ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]]
+    out, notes = {}, []
+    tmp = tempfile.mkdtemp(prefix="hjb_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for i, cs in enumerate(sets):
+            d = os.path.join(tmp, "p%d" % i)
+            cmd = [rocprof, "--pmc", *cs, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, str(ROOT / "bench.py"), "--pmc-child", *argv_child]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                notes.append("pass %d timed out" % i)
+                continue
+            if r.returncode != 0:
+                notes.append("pass %d rc=%d" % (i, r.returncode))
+                continue
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_filter in row["Kernel_Name"]:
+                            a = acc.setdefault(row["Counter_Name"], [0.0, 0])
+                            a[0] += float(row["Counter_Value"])
+                            a[1] += 1
+            for k, (s, n) in acc.items():
+                out[k] = s / n
+                out.setdefault("_launches", {})[k] = n
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return (out or None), "; ".join(notes)
 
-    import numpy as np
+
+def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=False):
+    """Times `steps` stages of `workload` on this rank's slab.  -> dict of measurements."""
     import torch
-    import hjbdp
     from hjbdp.sharded import ShardedSweep
-    from hjbdp.synthetic import position3d_spec
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a HIP device (no CPU fallback)")
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
-    # weak scaling: every rank owns args.n planes of the last axis
-    spec = position3d_spec(n=args.n, mu=args.mu, n_last=args.n * world * args.weak_mult,
-                           j_storage=np.float16 if args.j_storage == "f16" else None)
-    sw = ShardedSweep(spec, rank, world, dev)
+    n = args.grid_n if workload != "c2" else 101
+    spec, name = build_spec(workload, n_last=n * world if weak else None, n=args.grid_n)
+    sw = ShardedSweep(spec, rank, world, dev, overlap=not args.no_overlap)
     if args.variant is not None:
-        sw._handle.set_option("variant", args.variant)
-    info = sw._handle.info()
+        sw.set_option("variant", args.variant)
+    info = sw.info()
     sw.set_terminal(None)
 
     def barrier():
@@ -124,79 +167,157 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         sw.step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()                      # same stream the kernels are launched on
-    for _ in range(args.steps):
+    ev0.record()                      # the stream the stage kernels are launched on
+    for _ in range(steps):
         sw.step()
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    sw._handle.check_device_status()
+    sw.check_device_status()
     if world > 1:
         tt = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt[0])
-
-    states_per_rank = info["n_states"]
-    backups_per_launch = states_per_rank * spec.nU
-    total_backups = backups_per_launch * world * args.steps
-    value = total_backups / wall
-    launch_ms = dev_ms / args.steps                                 # one kernel per step
-    D = spec.D
-    alg_flops = f_alg(D) * backups_per_launch
-    alg_bytes = (2 * spec.j_dtype.itemsize + 4) * states_per_rank   # read J_{k+1}, write J_k + int32 argmin
-    tflops = alg_flops / (launch_ms * 1e-3) / 1e12
-    gbs = alg_bytes / (launch_ms * 1e-3) / 1e9
-    traffic = valu_util = None
-    pmc = ROOT / "profiles" / "pmc_traffic.json"                    # written from rocprofv3 --pmc passes
-    if pmc.exists():
-        try:
-            pj = json.loads(pmc.read_text())
-            traffic, valu_util = pj.get("hbm_bytes_per_launch"), pj.get("valu_busy_frac")
-        except Exception:
-            traffic = valu_util = None
-    J_final = sw.owned_J()
-    cs = J_final.double().sum().reshape(1)
+    cs = sw.owned_J().double().sum().reshape(1)
     if world > 1:
         cs = cs.cpu() if args.backend != "nccl" else cs
         dist.all_reduce(cs)
-    checksum = float(cs[0])
+    res = {"spec": spec, "name": name, "info": info, "wall": wall, "dev_ms": dev_ms, "steps": steps,
+           "states_rank": sw.owned * sw.inner, "halo": (sw.halo_lo, sw.halo_hi), "checksum": float(cs[0]),
+           "total_backups": spec.nS * spec.nU * steps}
+    sw.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c5", "c2"], help="headline workload (default: C4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs / the weak-scaling figure")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange halos, then compute (no overlap)")
+    ap.add_argument("--variant", type=int, default=None, help="force a stage-kernel variant (testing)")
+    ap.add_argument("--grid-n", type=int, default=120, help="points per axis of the pos-att grid (config: 120; smaller = testing)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --share-gpu is a 1-GPU test mode")
+    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses cuda:0")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    # ---- PMC passes on child processes, before this process initialises the GPU ------------------------------
+    pmc, pmc_note = None, "not collected"
+    if world == 1 and not args.pmc_child and not args.no_pmc:
+        child = ["--workload", args.workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-pmc",
+                 "--grid-n", str(args.grid_n)]
+        if args.variant is not None:
+            child += ["--variant", str(args.variant)]
+        pmc, pmc_note = collect_pmc(child, "k_backup_")
+
+    import numpy as np  # noqa: F401
+    import torch
+    import hjbdp  # noqa: F401
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    head = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist)
+    if args.pmc_child:
+        return
+    spec, info = head["spec"], head["info"]
+    value = head["total_backups"] / head["wall"]
+    launch_ms = head["dev_ms"] / args.steps                       # rank 0's stage time (one fused kernel; N > 1: + boundary launches)
+    D = spec.D
+    backups_per_launch = head["states_rank"] * spec.nU
+    alg_flops = f_alg(D) * backups_per_launch
+    alg_bytes = (2 * spec.j_dtype.itemsize + 4) * head["states_rank"]   # read J_{k+1}, write J_k + int32 argmin
+    tflops = alg_flops / (launch_ms * 1e-3) / 1e12
+    gbs = alg_bytes / (launch_ms * 1e-3) / 1e9
+    kname = KERNEL_OF_VARIANT.get(info["kernel_variant"], "k_backup")
+    traffic = valu_util = None
+    pmc_out = None
+    if pmc:
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # rocprofv3 reports KiB
+        if "SQ_INSTS_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
+            cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                                   # summed over the 8 XCDs
+            valu_util = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_WAVE_INSTR / (1024.0 * cyc)
+        pmc_out = {k: v for k, v in pmc.items() if not k.startswith("_")}
     out = {
         "metric": "bellman_backups_per_s", "value": value, "unit": "backups/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.j_storage == "f32" else "f32 (J stored as f16)", "data": "synthetic",
-        "config": {"workload": "C2 Solver_position 3-DOF: %d^2 x %d states x %d^3 controls, 1 stage per step"
-                               % (args.n, args.n * world, args.mu),
-                   "states_per_gpu": states_per_rank, "controls": spec.nU, "stages": args.steps,
-                   "sharding": "last state axis, %d planes per GPU, halo %d/%d planes exchanged per stage"
-                               % (args.n, sw.halo_lo, sw.halo_hi) if world > 1 else "none",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["wall"] * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if spec.j_dtype.itemsize == 4 else "f32 (J stored as f16)", "data": "synthetic",
+        "config": {"workload": head["name"], "states": spec.nS, "states_per_gpu": head["states_rank"], "controls": spec.nU,
+                   "stages": args.steps,
+                   "sharding": ("last state axis (v): %d of %d planes per GPU, halo %d/%d planes exchanged per stage over RCCL%s"
+                                % (head["states_rank"] // (spec.nS // spec.n[-1]), spec.n[-1], head["halo"][0], head["halo"][1],
+                                   "" if args.no_overlap else ", overlapped with the interior planes")) if world > 1 else "none",
                    "kernel_variant": info["kernel_variant"]},
-        "roofline": {"bound": "mfma", "pipe": "valu (v_pk_fma_f32; no MFMA applies: interpolation is a gather, K = D <= 6)",
-                     "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                     "kernel": {4: "k_backup_packed2<float, 3, 1>", 2: "k_backup_packed<3>", 1: "k_backup_nested<float,3,true>"}.get(info["kernel_variant"], "k_backup_generic<float,3>"),
-                     "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(D), "valu_issue_util_pmc": valu_util,
-                     "note": "compute roofline binds (SURVEY 8d), HBM does not; peak = dense f32 MFMA peak = fp32 vector peak "
-                             "(157.3 TFLOP/s); achieved = ALGORITHMIC flops (41 per backup, SURVEY 8d) / launch time.  The kernel EXECUTES "
-                             "fewer flops than that (axis-0/axis-1 lerps are shared between controls), so frac can exceed 1; "
-                             "valu_issue_util_pmc (SQ_INSTS_VALU x 4 / SIMD-cycles, profiles/pmc_traffic.json) is the executed-instruction view",
+                     "kernel": kname, "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(D),
+                     "valu_issue_util": valu_util,
+                     "pmc": pmc_out, "pmc_source": ("rocprofv3 --pmc passes made by this run on `bench.py --pmc-child --workload %s --steps 3` "
+                                                    "(mean per launch of %s*; FETCH_SIZE/WRITE_SIZE in KiB, dword-per-lane accesses count 1x)"
+                                                    % (args.workload, kname)) if pmc else pmc_note,
+                     "note": "fp32 VALU binds (SURVEY 8d), not HBM and not MFMA (interpolation is a gather; K = D <= 6); peak = fp32 vector "
+                             "peak = f32-input MFMA peak.  achieved = ALGORITHMIC flops (F_alg(4) = 71 per backup) / launch time; the "
+                             "kernel shares the two control-independent lerps between the 9 controls, so it executes fewer.  "
+                             "valu_issue_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8): the executed-instruction view",
                      "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                              "alg_bytes_per_state": 2 * spec.j_dtype.itemsize + 4}},
-        "checksum_sum_J": checksum,
+        "checksum_sum_J": head["checksum"],
     }
+    if not args.no_extras:
+        if world == 1:
+            others = {}
+            for w in ("c5", "c2"):
+                if w == args.workload:
+                    continue
+                r = run_workload(args, w, 20, 3, world, rank, dev, dist)
+                others[w] = {"workload": r["name"], "value": r["total_backups"] / r["wall"], "unit": "backups/s",
+                             "ms_per_step": r["wall"] * 1e3 / r["steps"], "kernel_variant": r["info"]["kernel_variant"],
+                             "alg_TFLOPs": f_alg(r["spec"].D) * r["total_backups"] / r["wall"] / 1e12,
+                             "checksum_sum_J": r["checksum"]}
+            out["other_workloads"] = others
+        else:
+            r = run_workload(args, args.workload, max(10, args.steps // 2), 3, world, rank, dev, dist, weak=True)
+            out["weak_scaling"] = {"workload": r["name"], "value": r["total_backups"] / r["wall"], "unit": "backups/s",
+                                   "ms_per_step": r["wall"] * 1e3 / r["steps"], "states_per_gpu": r["states_rank"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec)
     if world > 1:
         dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    sw.close()
     if world > 1:
         dist.destroy_process_group()
 

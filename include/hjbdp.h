@@ -261,6 +261,29 @@ int32_t hjb_solve_flat(hjb_handle h, int32_t n_stages, int32_t monitor_period, d
  * halo_needed_lo, halo_needed_hi */
 int32_t hjb_get_info_flat(hjb_handle h, int64_t *out8);
 
+/* ---- single-process multi-GPU sweep -------------------------------------------------------------------------------
+ * For a host that is ONE process (MATLAB): the stage loop of the reference (pos-att/Solver_pos_att.m:270-286,
+ * position-control/Solver_position.m:132-141) over a grid partitioned along its LAST state axis, slab i on device
+ * devices[i].  Per stage each slab gets the halo planes of J_{k+1} from its neighbours (hipMemcpyPeerAsync, xGMI), runs
+ * the interior planes while the copies are in flight and the two boundary strips after them; the early-stop monitor's
+ * sums are added over the slabs.  Choose WHICH axis is last by relabelling the state axes (the axis should move less
+ * than a slab per stage: pos-att shards x, v or theta, not w).  hjb_solve_opts: terminal / J_final / idx_final are
+ * whole-grid host arrays; J_stages, idx_stages and probe are not supported.  The same device may be listed more than
+ * once (several slabs on one GPU: testing).  One process per GPU with torch.distributed/RCCL is the other supported
+ * form (hjbdp/sharded.py, bench.py --gpus N). */
+typedef struct hjb_multi_s *hjb_multi;
+int32_t hjb_create_multi(const hjb_problem *problem, int32_t n_dev, const int32_t *devices, hjb_multi *out);
+int32_t hjb_create_multi_from(hjb_builder b, int32_t n_dev, const int32_t *devices, hjb_multi *out);
+int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *opts, hjb_result *result);
+int32_t hjb_solve_multi_flat(hjb_multi m, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
+                             void *J_final, int32_t *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms);
+/* planes [begin, end) of slab `slab`, its halo, whether it runs as interior + strips, its stage kernel (any out may be NULL) */
+int32_t hjb_multi_slab_info(hjb_multi m, int32_t slab, int32_t *begin, int32_t *end, int32_t *halo_lo, int32_t *halo_hi,
+                            int32_t *split, int32_t *kernel_variant);
+int32_t hjb_multi_set_option(hjb_multi m, const char *key, int64_t value);   /* hjb_set_option on every slab handle */
+int32_t hjb_destroy_multi(hjb_multi m);
+const char *hjb_multi_last_error(hjb_multi m);
+
 #ifdef __cplusplus
 }
 #endif

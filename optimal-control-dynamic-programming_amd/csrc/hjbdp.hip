@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
+#include <climits>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -1969,8 +1971,7 @@ int32_t hjb_problem_set_model(hjb_builder b, int32_t model, double model_h, cons
     return HJB_OK;
 }
 
-int32_t hjb_create_from(hjb_builder b, int32_t device, hjb_handle *out) {
-    if (!b || !out) return bfail(b, HJB_E_INVALID, "null argument");
+static int builder_bind(hjb_builder b, hjb_problem *out) {      // the builder's problem with its pointers bound
     hjb_problem p = b->p;
     for (int a = 0; a < p.D; ++a) {
         if (b->knots[(size_t)a].empty()) return bfail(b, HJB_E_INVALID, "knots of axis %d were not set", a);
@@ -1986,6 +1987,15 @@ int32_t hjb_create_from(hjb_builder b, int32_t device, hjb_handle *out) {
     }
     if (p.model != HJB_MODEL_NONE)
         for (int i = 0; i < 4; ++i) p.model_tables[i] = b->blobs[(size_t)(uintptr_t)b->p.model_tables[i] - 1].data();
+    *out = p;
+    return HJB_OK;
+}
+
+int32_t hjb_create_from(hjb_builder b, int32_t device, hjb_handle *out) {
+    if (!b || !out) return bfail(b, HJB_E_INVALID, "null argument");
+    hjb_problem p;
+    const int st0 = builder_bind(b, &p);
+    if (st0) return st0;
     const int st = hjb_create(&p, device, out);
     if (st) b->err = g_last_error;
     return st;
@@ -2024,6 +2034,338 @@ int32_t hjb_get_info_flat(hjb_handle h, int64_t *out8) {
     out8[0] = i.n_states; out8[1] = i.n_controls; out8[2] = i.j_elems; out8[3] = i.kernel_variant;
     out8[4] = i.lds_bytes; out8[5] = i.grid; out8[6] = i.halo_needed_lo; out8[7] = i.halo_needed_hi;
     return HJB_OK;
+}
+
+// ---- single-process multi-GPU sweep ------------------------------------------------------------------------------
+// The reference's stage loop (pos-att/Solver_pos_att.m:270-286) over a grid partitioned along its LAST state axis into
+// one slab per device.  Per stage and slab: the halo planes of J_{k+1} are copied from the neighbouring slabs
+// (hipMemcpyPeerAsync on a copy stream; xGMI between GPUs), the INTERIOR planes - whose next states stay inside the
+// owned planes - are backed up while the copies are in flight, the two boundary strips afterwards.  Interior and strips
+// are slab handles over the same buffers (a slab handle sees planes [begin - halo_lo, end + halo_hi)).
+struct hjb_multi_s {
+    struct Slab {
+        int device = 0, begin = 0, end = 0, hlo = 0, hhi = 0;
+        Handle *whole = nullptr;             // owns the J buffers (dJ[0], dJ[1]) and idx
+        Handle *part[3] = {nullptr, nullptr, nullptr};     // interior, low strip, high strip (null: no split)
+        int64_t part_row0[3] = {0, 0, 0};    // first plane of the part's view inside the slab's J buffer
+        int64_t part_own0[3] = {0, 0, 0};    // first owned plane of the part, relative to `begin`
+        hipStream_t sc = nullptr, sx = nullptr;
+        hipEvent_t done[2] = {nullptr, nullptr}, halo[2] = {nullptr, nullptr};
+    };
+    std::vector<Slab> slabs;
+    int need_lo = 0, need_hi = 0, nl = 0, dtype = HJB_F32;
+    int64_t inner = 0;
+    size_t esz = 4;
+    std::string err;
+};
+
+static int mfail(hjb_multi m, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (m) m->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+const char *hjb_multi_last_error(hjb_multi m) { return m ? m->err.c_str() : g_last_error.c_str(); }
+
+int32_t hjb_destroy_multi(hjb_multi m) {
+    if (!m) return HJB_OK;
+    for (auto &S : m->slabs) {
+        (void)hipSetDevice(S.device);
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < 2; ++i) {
+            if (S.done[i]) (void)hipEventDestroy(S.done[i]);
+            if (S.halo[i]) (void)hipEventDestroy(S.halo[i]);
+        }
+        if (S.sc) (void)hipStreamDestroy(S.sc);
+        if (S.sx) (void)hipStreamDestroy(S.sx);
+        for (int i = 0; i < 3; ++i) if (S.part[i]) (void)hjb_destroy((hjb_handle)S.part[i]);
+        if (S.whole) (void)hjb_destroy((hjb_handle)S.whole);
+    }
+    delete m;
+    return HJB_OK;
+}
+
+int32_t hjb_create_multi(const hjb_problem *p, int32_t n_dev, const int32_t *devices, hjb_multi *out) {
+    if (!p || !devices || !out) return mfail(nullptr, HJB_E_INVALID, "null argument");
+    *out = nullptr;
+    if (n_dev < 1 || n_dev > 64) return mfail(nullptr, HJB_E_INVALID, "n_dev=%d", n_dev);
+    if (p->slab_begin || p->slab_end || p->halo_lo || p->halo_hi) return mfail(nullptr, HJB_E_INVALID, "hjb_create_multi partitions the grid itself: pass the whole problem");
+    if (p->D < 1 || p->D > HJB_MAX_D) return mfail(nullptr, HJB_E_UNSUPPORTED, "D=%d", p->D);
+    const int nl = p->n[p->D - 1];
+    if (n_dev > nl) return mfail(nullptr, HJB_E_INVALID, "more devices (%d) than planes of the last axis (%d)", n_dev, nl);
+    // the halo the tables imply: from a handle on the whole grid (host arithmetic on the last axis' terms)
+    hjb_handle probe = nullptr;
+    int st = hjb_create(p, devices[0], &probe);
+    if (st) return st;
+    hjb_info pin{};
+    (void)hjb_get_info(probe, &pin);
+    (void)hjb_destroy(probe);
+    hjb_multi m = new hjb_multi_s();
+    m->need_lo = pin.halo_needed_lo;
+    m->need_hi = pin.halo_needed_hi;
+    m->nl = nl;
+    m->dtype = p->dtype;
+    m->esz = p->dtype == HJB_F16S ? 2 : (p->dtype == HJB_F32 ? 4 : 8);
+    m->inner = pin.n_states / nl;
+    m->slabs.resize((size_t)n_dev);
+    const int base = nl / n_dev, rem = nl % n_dev;
+    int b = 0;
+    for (int i = 0; i < n_dev; ++i) {
+        auto &S = m->slabs[(size_t)i];
+        S.device = devices[i];
+        S.begin = b;
+        S.end = b + base + (i < rem ? 1 : 0);
+        b = S.end;
+        S.hlo = std::min(m->need_lo, S.begin);
+        S.hhi = std::min(m->need_hi, nl - S.end);
+    }
+    for (int i = 0; i < n_dev; ++i) {       // a halo must come from the immediate neighbour only
+        const auto &S = m->slabs[(size_t)i];
+        if ((i > 0 && S.hlo > m->slabs[(size_t)i - 1].end - m->slabs[(size_t)i - 1].begin) ||
+            (i + 1 < n_dev && S.hhi > m->slabs[(size_t)i + 1].end - m->slabs[(size_t)i + 1].begin)) {
+            (void)hjb_destroy_multi(m);
+            return mfail(nullptr, HJB_E_INVALID, "halo (%d/%d planes) wider than a neighbouring slab: use fewer devices or relabel the "
+                         "state axes so that the last axis moves less", m->need_lo, m->need_hi);
+        }
+    }
+    auto make = [&](int dev, int sb, int se, int hl, int hh, Handle **hout) {
+        hjb_problem q = *p;
+        if (n_dev > 1) { q.slab_begin = sb; q.slab_end = se; q.halo_lo = hl; q.halo_hi = hh; }
+        hjb_handle h = nullptr;
+        const int s2 = hjb_create(&q, dev, &h);
+        *hout = (Handle *)h;
+        return s2;
+    };
+    for (int i = 0; i < n_dev && !st; ++i) {
+        auto &S = m->slabs[(size_t)i];
+        st = make(S.device, S.begin, S.end, S.hlo, S.hhi, &S.whole);
+        if (st) break;
+        const int lo_w = S.hlo ? m->need_lo : 0, hi_w = S.hhi ? m->need_hi : 0, owned = S.end - S.begin;
+        if (n_dev > 1 && owned - lo_w - hi_w >= 1 && (lo_w || hi_w)) {
+            const int view0 = S.begin - S.hlo;
+            auto sub = [&](int k, int sb, int se, int hl, int hh) {
+                S.part_row0[k] = (sb - hl) - view0;
+                S.part_own0[k] = sb - S.begin;
+                return make(S.device, sb, se, hl, hh, &S.part[k]);
+            };
+            st = sub(0, S.begin + lo_w, S.end - hi_w, std::min(m->need_lo, lo_w), std::min(m->need_hi, hi_w));
+            if (!st && lo_w) st = sub(1, S.begin, S.begin + lo_w, S.hlo, std::min(m->need_hi, S.end - (S.begin + lo_w)));
+            if (!st && hi_w) st = sub(2, S.end - hi_w, S.end, std::min(m->need_lo, (S.end - hi_w) - S.begin), S.hhi);
+        }
+        if (st) break;
+        if (hipSetDevice(S.device) != hipSuccess) { st = mfail(nullptr, HJB_E_DEVICE, "hipSetDevice(%d)", S.device); break; }
+        {
+            std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+            st = ensure_work(S.whole);
+        }
+        if (st) break;
+        bool ok = hipStreamCreateWithFlags(&S.sc, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&S.sx, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = hipEventCreateWithFlags(&S.done[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&S.halo[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { st = mfail(nullptr, HJB_E_DEVICE, "stream / event creation failed on device %d", S.device); break; }
+        for (int j = 0; j < n_dev; ++j)          // direct peer copies where the platform allows them (errors: staged copies still work)
+            if (devices[j] != S.device) { int can = 0; if (hipDeviceCanAccessPeer(&can, S.device, devices[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[j], 0); }
+        (void)hipGetLastError();
+    }
+    if (st) {
+        const std::string keep = g_last_error;
+        (void)hjb_destroy_multi(m);
+        g_last_error = keep;
+        return st;
+    }
+    *out = m;
+    return HJB_OK;
+}
+
+int32_t hjb_multi_slab_info(hjb_multi m, int32_t slab, int32_t *begin, int32_t *end, int32_t *halo_lo, int32_t *halo_hi,
+                            int32_t *split, int32_t *kernel_variant) {
+    if (!m || slab < 0 || slab >= (int)m->slabs.size()) return mfail(m, HJB_E_INVALID, "slab %d", slab);
+    const auto &S = m->slabs[(size_t)slab];
+    if (begin) *begin = S.begin;
+    if (end) *end = S.end;
+    if (halo_lo) *halo_lo = S.hlo;
+    if (halo_hi) *halo_hi = S.hhi;
+    if (split) *split = S.part[0] ? 1 : 0;
+    if (kernel_variant) *kernel_variant = (S.part[0] ? S.part[0] : S.whole)->variant;
+    return HJB_OK;
+}
+
+int32_t hjb_multi_set_option(hjb_multi m, const char *key, int64_t value) {
+    if (!m || !key) return mfail(m, HJB_E_INVALID, "null argument");
+    for (auto &S : m->slabs) {
+        Handle *hs[4] = {S.whole, S.part[0], S.part[1], S.part[2]};
+        for (Handle *h : hs)
+            if (h) {
+                const int st = hjb_set_option((hjb_handle)h, key, value);
+                if (st) return mfail(m, st, "%s", hjb_last_error((hjb_handle)h));
+            }
+    }
+    return HJB_OK;
+}
+
+int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
+    if (!m || !o) return mfail(m, HJB_E_INVALID, "null argument");
+    if (o->n_stages < 1) return mfail(m, HJB_E_INVALID, "n_stages=%d", o->n_stages);
+    if (o->J_stages || o->idx_stages || o->probe)
+        return mfail(m, HJB_E_UNSUPPORTED, "hjb_solve_multi keeps no per-stage planes and no probe block (use one device, or drive the slabs yourself)");
+    const int n = (int)m->slabs.size();
+    const int64_t inner = m->inner;
+    const size_t esz = m->esz, plane_b = (size_t)inner * esz;
+#define MULTI_TRY(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return mfail(m, HJB_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+    // terminal cost into buffer 0 of every slab (halo planes are filled by the first exchange)
+    for (auto &S : m->slabs) {
+        MULTI_TRY(hipSetDevice(S.device));
+        char *J0 = (char *)S.whole->dJ[0];
+        const size_t own_b = plane_b * (size_t)(S.end - S.begin);
+        if (o->terminal) MULTI_TRY(hipMemcpy(J0 + plane_b * S.hlo, (const char *)o->terminal + plane_b * S.begin, own_b, hipMemcpyHostToDevice));
+        else MULTI_TRY(hipMemset(J0, 0, plane_b * (size_t)(S.end - S.begin + S.hlo + S.hhi)));
+        MULTI_TRY(hipDeviceSynchronize());
+    }
+    auto stage_part = [&](hjb_multi_s::Slab &S, int k, int cur) -> int {
+        Handle *h = k < 0 ? S.whole : S.part[k];
+        const int64_t row0 = k < 0 ? 0 : S.part_row0[k], own0 = k < 0 ? 0 : S.part_own0[k];
+        const char *in = (const char *)S.whole->dJ[cur] + plane_b * row0;
+        char *outp = (char *)S.whole->dJ[cur ^ 1] + plane_b * row0;
+        const int st = launch_stage(h, in, outp, S.whole->d_idx + inner * own0, S.sc);
+        if (st) m->err = h->err;
+        return st;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    int cur = 0, done = 0, early = 0;
+    double fprev = 0, iprev = 0, e = 0, e2 = 0;
+    for (int k_s = o->n_stages; k_s >= 1; --k_s, ++done) {
+        const int par = done & 1, ppar = par ^ 1;
+        // ---- phase A: halo copies of J_{k+1} (buffer `cur`) on the copy streams ------------------------------------
+        for (int i = 0; i < n; ++i) {
+            auto &S = m->slabs[(size_t)i];
+            if (!S.hlo && !S.hhi) continue;
+            MULTI_TRY(hipSetDevice(S.device));
+            if (done > 0) {           // the data: the neighbours' previous-stage output; the target: halo planes my own previous stage read
+                MULTI_TRY(hipStreamWaitEvent(S.sx, S.done[ppar], 0));
+                if (i > 0) MULTI_TRY(hipStreamWaitEvent(S.sx, m->slabs[(size_t)i - 1].done[ppar], 0));
+                if (i + 1 < n) MULTI_TRY(hipStreamWaitEvent(S.sx, m->slabs[(size_t)i + 1].done[ppar], 0));
+            }
+            char *mine = (char *)S.whole->dJ[cur];
+            if (S.hlo) {
+                const auto &L = m->slabs[(size_t)i - 1];
+                const char *src = (const char *)L.whole->dJ[cur] + plane_b * (size_t)(L.hlo + (L.end - L.begin) - S.hlo);
+                MULTI_TRY(hipMemcpyPeerAsync(mine, S.device, src, L.device, plane_b * (size_t)S.hlo, S.sx));
+            }
+            if (S.hhi) {
+                const auto &R = m->slabs[(size_t)i + 1];
+                const char *src = (const char *)R.whole->dJ[cur] + plane_b * (size_t)R.hlo;
+                MULTI_TRY(hipMemcpyPeerAsync(mine + plane_b * (size_t)(S.hlo + S.end - S.begin), S.device, src, R.device, plane_b * (size_t)S.hhi, S.sx));
+            }
+            MULTI_TRY(hipEventRecord(S.halo[par], S.sx));
+        }
+        // ---- phase B: interior, then (halos landed) the strips, on the compute streams --------------------------------
+        for (int i = 0; i < n; ++i) {
+            auto &S = m->slabs[(size_t)i];
+            MULTI_TRY(hipSetDevice(S.device));
+            if (done > 0) {           // the neighbours read buffer cur^1 (my output now) as their halo source one stage ago
+                if (i > 0 && m->slabs[(size_t)i - 1].hhi) MULTI_TRY(hipStreamWaitEvent(S.sc, m->slabs[(size_t)i - 1].halo[ppar], 0));
+                if (i + 1 < n && m->slabs[(size_t)i + 1].hlo) MULTI_TRY(hipStreamWaitEvent(S.sc, m->slabs[(size_t)i + 1].halo[ppar], 0));
+            }
+            int st = HJB_OK;
+            if (S.part[0]) {
+                st = stage_part(S, 0, cur);
+                if (!st && (S.hlo || S.hhi)) MULTI_TRY(hipStreamWaitEvent(S.sc, S.halo[par], 0));
+                if (!st && S.part[1]) st = stage_part(S, 1, cur);
+                if (!st && S.part[2]) st = stage_part(S, 2, cur);
+            } else {
+                if (S.hlo || S.hhi) MULTI_TRY(hipStreamWaitEvent(S.sc, S.halo[par], 0));
+                st = stage_part(S, -1, cur);
+            }
+            if (st) return mfail(m, st, "stage launch on slab %d: %s", i, m->err.c_str());
+            MULTI_TRY(hipEventRecord(S.done[par], S.sc));
+        }
+        cur ^= 1;
+        // ---- the early-stop monitor (Solver_pos_att.m:273-285): per-slab sums, added on the host ----------------------
+        if (o->monitor_period > 0 && (k_s % o->monitor_period) == 0) {
+            double sj = 0, si = 0;
+            for (auto &S : m->slabs) {
+                MULTI_TRY(hipSetDevice(S.device));
+                const char *Jown = (const char *)S.whole->dJ[cur] + plane_b * S.hlo;
+                if (launch_monitor_sums(m->dtype, Jown, S.whole->d_idx, inner * (S.end - S.begin), S.whole->d_partials, S.whole->d_sums, S.sc) != HJB_OK)
+                    return mfail(m, HJB_E_DEVICE, "monitor reduction launch failed");
+            }
+            for (auto &S : m->slabs) {
+                double sums[2];
+                MULTI_TRY(hipSetDevice(S.device));
+                MULTI_TRY(hipMemcpyAsync(sums, S.whole->d_sums, sizeof sums, hipMemcpyDeviceToHost, S.sc));
+                MULTI_TRY(hipStreamSynchronize(S.sc));
+                sj += sums[0];
+                si += sums[1];
+            }
+            e = sj - fprev; e2 = si - iprev; fprev = sj; iprev = si;
+            if (o->progress) o->progress(o->progress_user, k_s, e, e2, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            if (std::fabs(e) < o->monitor_tol) { early = 1; ++done; break; }
+        }
+    }
+    for (auto &S : m->slabs) {
+        MULTI_TRY(hipSetDevice(S.device));
+        MULTI_TRY(hipStreamSynchronize(S.sc));
+        MULTI_TRY(hipStreamSynchronize(S.sx));
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (auto &S : m->slabs) {
+        Handle *hs[4] = {S.whole, S.part[0], S.part[1], S.part[2]};
+        MULTI_TRY(hipSetDevice(S.device));
+        for (Handle *h : hs)
+            if (h) {
+                const int st = check_status(h, S.sc);
+                if (st) return mfail(m, st, "%s", h->err.c_str());
+            }
+        const size_t own = (size_t)(S.end - S.begin);
+        if (o->J_final) MULTI_TRY(hipMemcpy((char *)o->J_final + plane_b * S.begin, (const char *)S.whole->dJ[cur] + plane_b * S.hlo, plane_b * own, hipMemcpyDeviceToHost));
+        if (o->idx_final) MULTI_TRY(hipMemcpy(o->idx_final + inner * S.begin, S.whole->d_idx, (size_t)inner * own * 4, hipMemcpyDeviceToHost));
+    }
+    if (res) {
+        res->stages_done = done;
+        res->stopped_early = early;
+        res->sweep_ms = ms;
+        res->last_e = e;
+        res->last_e2 = e2;
+    }
+    return HJB_OK;
+#undef MULTI_TRY
+}
+
+int32_t hjb_create_multi_from(hjb_builder b, int32_t n_dev, const int32_t *devices, hjb_multi *out) {
+    if (!b || !out) return bfail(b, HJB_E_INVALID, "null argument");
+    hjb_problem p;
+    const int st0 = builder_bind(b, &p);
+    if (st0) return st0;
+    const int st = hjb_create_multi(&p, n_dev, devices, out);
+    if (st) b->err = g_last_error;
+    return st;
+}
+
+int32_t hjb_solve_multi_flat(hjb_multi m, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
+                             void *J_final, int32_t *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms) {
+    hjb_solve_opts o{};
+    o.n_stages = n_stages;
+    o.monitor_period = monitor_period;
+    o.monitor_tol = monitor_tol;
+    o.terminal = terminal;
+    o.J_final = J_final;
+    o.idx_final = idx_final;
+    hjb_result r{};
+    const int st = hjb_solve_multi(m, &o, &r);
+    if (stages_done) *stages_done = r.stages_done;
+    if (stopped_early) *stopped_early = r.stopped_early;
+    if (sweep_ms) *sweep_ms = r.sweep_ms;
+    return st;
 }
 
 }  // extern "C"

@@ -147,6 +147,16 @@ SYMBOLS = {
     "hjb_solve_flat": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "hjb_get_info_flat": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]),
+    # single-process multi-GPU sweep
+    "hjb_create_multi": (C.c_int32, [C.POINTER(hjb_problem), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "hjb_create_multi_from": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "hjb_solve_multi": (C.c_int32, [C.c_void_p, C.POINTER(hjb_solve_opts), C.POINTER(hjb_result)]),
+    "hjb_solve_multi_flat": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "hjb_multi_slab_info": (C.c_int32, [C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 6),
+    "hjb_multi_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "hjb_destroy_multi": (C.c_int32, [C.c_void_p]),
+    "hjb_multi_last_error": (C.c_char_p, [C.c_void_p]),
 }
 HJB_LOOKUP_NEAREST = 0
 HJB_LOOKUP_LINEAR = 1

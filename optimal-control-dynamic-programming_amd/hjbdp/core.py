@@ -253,6 +253,78 @@ class Backup:
         return out
 
 
+class MultiBackup:
+    """A problem partitioned along its last state axis over several devices of THIS process (hjb_create_multi /
+    hjb_solve_multi): per stage the halo planes travel device to device while the interior planes are computed.
+    `devices` may repeat a device (several slabs on one GPU: how the path is tested on a 1-GPU box)."""
+
+    def __init__(self, spec: ProblemSpec, devices):
+        self.lib = load_library()
+        self.spec = spec
+        self._cprob, self._keep = spec.to_c()
+        self._m = C.c_void_p()
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        st = self.lib.hjb_create_multi(C.byref(self._cprob), len(devices), devs, C.byref(self._m))
+        if st != _abi.HJB_OK:
+            self._m = C.c_void_p()
+            msg = self.lib.hjb_multi_last_error(None)
+            raise HjbError(st, (msg or b"").decode() or self.lib.hjb_status_string(st).decode())
+        self.n_slabs = len(devices)
+
+    def _check(self, st):
+        if st != _abi.HJB_OK:
+            msg = self.lib.hjb_multi_last_error(self._m)
+            raise HjbError(st, (msg or b"").decode() or self.lib.hjb_status_string(st).decode())
+
+    def close(self):
+        if getattr(self, "_m", None) and self._m.value:
+            self.lib.hjb_destroy_multi(self._m)
+            self._m = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def slab_info(self, i):
+        v = [C.c_int32() for _ in range(6)]
+        self._check(self.lib.hjb_multi_slab_info(self._m, int(i), *[C.byref(x) for x in v]))
+        return dict(zip(("begin", "end", "halo_lo", "halo_hi", "split", "kernel_variant"), (x.value for x in v)))
+
+    def set_option(self, key, value):
+        self._check(self.lib.hjb_multi_set_option(self._m, key.encode(), int(value)))
+
+    def solve(self, n_stages, terminal=None, monitor_period=0, monitor_tol=0.0, progress=None):
+        nS, dt = self.spec.nS, self.spec.j_dtype
+        o = _abi.hjb_solve_opts()
+        o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
+        keep = []
+        if terminal is not None:
+            t = np.ascontiguousarray(np.asarray(terminal, dtype=dt).reshape(-1, order="F"))
+            if t.size != nS:
+                raise ValueError("terminal cost must have nS elements")
+            keep.append(t)
+            o.terminal = t.ctypes.data
+        J = np.empty(nS, dtype=dt)
+        idx = np.empty(nS, dtype=np.int32)
+        o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
+        if progress is not None:
+            cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
+            keep.append(cb)
+            o.progress = cb
+        res = _abi.hjb_result()
+        self._check(self.lib.hjb_solve_multi(self._m, C.byref(o), C.byref(res)))
+        return {"J": J, "idx": idx, "stages_done": res.stages_done, "stopped_early": bool(res.stopped_early),
+                "sweep_ms": res.sweep_ms, "last_e": res.last_e, "last_e2": res.last_e2}
+
+
 def solve_many(specs, n_stages, device=0, **solve_kw):
     """Independent sweeps (the three axis channels of Solver_position / Solver_attitude.simplified_run, the four
     runs of Solver_pos_att.simplified_run) in flight together: one handle and one host thread per sweep, each on

@@ -3,11 +3,18 @@
 
 Within a stage every backup is independent; J_{k+1} is read at x_next, which for
 the spacecraft models lies within a few cells of x, so each rank needs only
-`halo_lo`/`halo_hi` neighbouring planes of J_{k+1}.  Per stage:
+`halo_lo`/`halo_hi` neighbouring planes of J_{k+1}.  Per stage (overlap=True, GPUs):
 
-    1. neighbour halo exchange of the boundary planes of J_{k+1}
-       (torch.distributed P2P: RCCL send/recv over xGMI on GPUs, gloo on CPU);
-    2. one fused backup kernel on the owned planes (hjb_backup_stage_device).
+    1. the neighbour halo exchange of the boundary planes of J_{k+1} is STARTED
+       (torch.distributed P2P: RCCL send/recv over xGMI; its own stream);
+    2. the fused backup kernel runs on the INTERIOR planes - those whose next states
+       stay inside the owned planes - while the halos are in flight;
+    3. when the halos have landed, the kernel runs on the two boundary strips.
+
+Interior and strips are three libhjbdp slab handles over the SAME J buffers (a slab
+handle sees the planes [begin - halo_lo, end + halo_hi) of the last axis; sub-slabs of
+a rank's slab are pointer offsets into its buffers), so the split costs no copies.
+overlap=False (and every CPU test) exchanges first and runs one kernel on all owned planes.
 
 The reference has no distributed code at all; this is new design
 for the sweep loops of Solver_position.m:132-141 / Solver_pos_att.m:270-286.
@@ -70,7 +77,7 @@ def required_halo(spec: ProblemSpec):
 class ShardedSweep:
     """One rank's share of a sweep.  Buffers are torch tensors (HBM on GPUs)."""
 
-    def __init__(self, spec: ProblemSpec, rank, world, device, stage_fn=None, group=None):
+    def __init__(self, spec: ProblemSpec, rank, world, device, stage_fn=None, group=None, overlap=False):
         import torch
         self.torch = torch
         self.spec, self.rank, self.world, self.group = spec, int(rank), int(world), group
@@ -100,11 +107,29 @@ class ShardedSweep:
         self.cur = 0
         self.slab = (self.begin, self.end, self.halo_lo, self.halo_hi)
         self._handle = None
+        self._parts = None            # overlap: [(handle, first plane of its J view, first owned plane rel. to begin, planes)]
         if stage_fn is None:
             from .core import Backup  # raises loudly without the library / a GPU
             dev_index = self.device.index if self.device.index is not None else 0
             self._handle = Backup(spec, device=dev_index, slab=self.slab if world > 1 else None)
             stage_fn = self._hip_stage
+            # interior / boundary split: only when both strips and a non-empty interior exist
+            lo_w = need_lo if self.halo_lo else 0          # owned planes whose queries reach below `begin`
+            hi_w = need_hi if self.halo_hi else 0
+            if overlap and world > 1 and self.owned - lo_w - hi_w >= 1 and (lo_w or hi_w):
+                b, e = self.begin, self.end
+                view0 = b - self.halo_lo                   # global plane of row 0 of self.J[*]
+                self._parts = []
+
+                def sub(sb, se, hl, hh):
+                    h = Backup(spec, device=dev_index, slab=(sb, se, hl, hh))
+                    self._parts.append((h, (sb - hl) - view0, sb - b, se - sb, hl, hh))
+                sub(b + lo_w, e - hi_w, min(need_lo, lo_w), min(need_hi, hi_w))          # interior: reads owned planes only
+                if lo_w:
+                    sub(b, b + lo_w, self.halo_lo, min(need_hi, e - (b + lo_w)))
+                if hi_w:
+                    sub(e - hi_w, e, min(need_lo, (e - hi_w) - b), self.halo_hi)
+                self._comm_stream = torch.cuda.Stream(device=self.device)
         self.stage_fn = stage_fn
         # what my neighbours need from me
         self.up_needs = min(need_lo, self.end) if self.rank < world - 1 else 0     # my top planes -> rank+1's lower halo
@@ -114,6 +139,27 @@ class ShardedSweep:
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
         self._handle.backup_stage_device(J_in, J_out, idx, stream=stream)
 
+    def _hip_part(self, i, J_in, J_out, idx):
+        h, row0, own0, planes, hl, hh = self._parts[i]
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        n = planes + hl + hh
+        h.backup_stage_device(J_in[row0:row0 + n], J_out[row0:row0 + n], idx[own0:own0 + planes], stream=stream)
+
+    # -- the handle(s) behind this rank ------------------------------------------------------------------
+    def info(self):
+        return self._handle.info()
+
+    def set_option(self, key, value):
+        self._handle.set_option(key, value)
+        for p in self._parts or ():
+            p[0].set_option(key, value)
+
+    def check_device_status(self):
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        self._handle.check_device_status(stream)
+        for p in self._parts or ():
+            p[0].check_device_status(stream)
+
     def set_terminal(self, J_global=None):
         """J_N: None = zeros (Dynamic_Solver.m:83-84); else global [nS] column-major."""
         J = self.J[self.cur]
@@ -122,10 +168,11 @@ class ShardedSweep:
             g = self.torch.as_tensor(np.asarray(J_global, dtype=self.spec.j_dtype).reshape(self.spec.n[-1], self.inner))
             J[self.halo_lo:self.halo_lo + self.owned] = g[self.begin:self.end].to(self.device)
 
-    def exchange_halos(self):
-        """Fill the halo planes of the current J from the neighbouring ranks."""
+    def exchange_halos(self, wait=True):
+        """Fill the halo planes of the current J from the neighbouring ranks.  wait=False returns the
+        pending work objects instead of waiting (RCCL: the transfers run on the communicator's stream)."""
         if self.world == 1:
-            return
+            return []
         import torch.distributed as dist
         J = self.J[self.cur]
         ops, keep = [], []
@@ -158,15 +205,33 @@ class ShardedSweep:
                 for op, host in staged:
                     if op.op is dist.irecv:
                         op.tensor.copy_(host)
-                return
-            for w in dist.batch_isend_irecv(ops):
+                return []
+            works = dist.batch_isend_irecv(ops)
+            if not wait:
+                self._keep = keep
+                return works
+            for w in works:
                 w.wait()
+        return []
 
     def step(self):
-        """One backup of the owned planes: halo exchange, then the fused kernel."""
-        self.exchange_halos()
+        """One backup of the owned planes.  Without overlap: halo exchange, then the fused kernel.  With
+        overlap: start the exchange, run the interior planes, wait for the halos, run the boundary strips."""
         J_in, J_out = self.J[self.cur], self.J[1 - self.cur]
-        self.stage_fn(J_in, J_out, self.idx)
+        if self._parts is None:
+            self.exchange_halos()
+            self.stage_fn(J_in, J_out, self.idx)
+        else:
+            t = self.torch
+            main = t.cuda.current_stream(self.device)
+            self._comm_stream.wait_stream(main)            # the previous stage's output is the data to send
+            with t.cuda.stream(self._comm_stream):
+                works = self.exchange_halos(wait=False)
+            self._hip_part(0, J_in, J_out, self.idx)       # interior: independent of the halos
+            for w in works:
+                w.wait()                                   # the compute stream waits for the transfers
+            for i in range(1, len(self._parts)):
+                self._hip_part(i, J_in, J_out, self.idx)
         self.cur = 1 - self.cur
 
     def monitor_sums(self):
@@ -191,7 +256,7 @@ class ShardedSweep:
                 if abs(e) < monitor_tol:
                     break
         if self._handle is not None:
-            self._handle.check_device_status(self.torch.cuda.current_stream(self.device).cuda_stream)
+            self.check_device_status()
         return done
 
     def owned_J(self):
@@ -215,6 +280,9 @@ class ShardedSweep:
         return np.concatenate(outJ), np.concatenate(outI)
 
     def close(self):
+        for p in self._parts or ():
+            p[0].close()
+        self._parts = None
         if self._handle is not None:
             self._handle.close()
             self._handle = None

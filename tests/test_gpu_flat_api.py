@@ -148,3 +148,49 @@ def test_progress_after_every_stage(env):
     assert [k for k, _ in seen] == list(range(11, 0, -1))
     assert all(b[1] >= a[1] for a, b in zip(seen, seen[1:]))
     assert np.array_equal(out["J"], ref["J"])
+
+
+@pytest.mark.parametrize("case", ["colsweep", "nested3", "monitor", "f16"])
+def test_solve_multi_matches_single_device(env, case):
+    """hjb_create_multi / hjb_solve_multi (the single-process multi-GPU sweep a MATLAB host would call): the grid in
+    several slabs with per-stage device-to-device halo copies overlapped with the interior planes.  The 1-GPU box
+    gives every slab the same device (the copies are then plain device-to-device); bit-equal to the oracle's whole
+    grid sweep, including the early-stop monitor's decision."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, nested_problem, random_terminal
+    kw = {}
+    if case == "colsweep":        # window axis last: halo of one plane; interior + strips
+        spec, devs, stages = colsweep_problem(5, (36, 7, 9, 14), gax=2), [0, 0, 0], 5
+    elif case == "nested3":
+        spec, devs, stages = nested_problem(31, (7, 6, 13), (3, 4), dtype=np.float32, spread=0.12), [0, 0], 4
+    elif case == "monitor":
+        spec, devs, stages = colsweep_problem(6, (20, 6, 8, 12), gax=2, cost="multi"), [0, 0], 11
+        kw = {"monitor_period": 3, "monitor_tol": 1e12}      # stops at the first monitor point, k_s = 9, after 3 stages
+    else:
+        spec, devs, stages = colsweep_problem(7, (33, 6, 8, 15), gax=2, j_storage=np.float16), [0, 0, 0, 0], 3
+    term = random_terminal(spec, 4)
+    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, **kw)
+    with hjbdp.MultiBackup(spec, devs) as mb:
+        infos = [mb.slab_info(i) for i in range(len(devs))]
+        out = mb.solve(stages, terminal=term, **kw)
+        again = mb.solve(stages, terminal=term, **kw)            # a second sweep on the same object
+    assert infos[0]["begin"] == 0 and infos[-1]["end"] == spec.n[-1]
+    assert all(a["end"] == b["begin"] for a, b in zip(infos, infos[1:]))
+    if case != "nested3":
+        assert any(i["split"] for i in infos), infos          # the overlapped form was exercised
+    assert out["stages_done"] == ref["stages_done"] and out["stopped_early"] == ref["stopped_early"]
+    assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+    assert np.array_equal(again["J"], ref["J"]) and np.array_equal(again["idx"], ref["idx"])
+    if kw:
+        assert out["stopped_early"] and out["stages_done"] == 3
+        assert abs(out["last_e"] - ref["last_e"]) <= 1e-9 * abs(ref["last_e"])
+
+
+def test_solve_multi_refuses_what_it_cannot_do(env):
+    hjbdp, _abi, c_oracle = env
+    from problems import random_problem
+    spec = random_problem(5, (6, 5, 16), (3,), dtype=np.float32, spread=0.6)      # last axis moves several planes
+    with pytest.raises(hjbdp.HjbError):
+        hjbdp.MultiBackup(spec, [0] * 8)                      # halo wider than a 2-plane slab
+    with pytest.raises(hjbdp.HjbError):
+        hjbdp.MultiBackup(spec, [0] * 17)                     # more slabs than planes

@@ -667,10 +667,12 @@ def test_c2_full_size_properties(env):
     assert np.array_equal(u[(50 + 101 * (50 + 101 * 50))], [10, 10, 10])  # u*(0) = 0
 
 
-def test_two_rank_sharded_bench_matches_single_rank(env):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_rank_sharded_bench_matches_single_rank(env, overlap):
     """bench.py's multi-GPU path on ONE GPU: two torchrun ranks share cuda:0 and exchange halos over
-    gloo (the RCCL transport itself needs >1 GPU); the summed checksum must equal a single-rank run
-    on the same 2x-planes grid."""
+    gloo (the RCCL transport itself needs >1 GPU); strong scaling = the same grid, so the summed checksum must
+    equal a single-rank run.  Small pos-att grid, the column-sweep kernel forced (variant 7), with the
+    interior / boundary-strip split (three slab handles per rank) and without."""
     import json
     import socket
     import subprocess
@@ -678,20 +680,21 @@ def test_two_rank_sharded_bench_matches_single_rank(env):
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    common = ["--steps", "4", "--warmup", "1", "--grid-n", "33", "--grid-mu", "7", "--no-cpu-baseline"]
-    one = subprocess.run([sys.executable, str(root / "bench.py"), "--weak-mult", "2"] + common,
-                         capture_output=True, text=True, timeout=300)
+    common = ["--steps", "4", "--warmup", "1", "--grid-n", "34", "--variant", "7", "--no-cpu-baseline", "--no-pmc", "--no-extras"]
+    one = subprocess.run([sys.executable, str(root / "bench.py")] + common, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(root / "bench.py"),
-                          "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                          "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common + ([] if overlap else ["--no-overlap"]),
                          capture_output=True, text=True, timeout=300)
     assert two.returncode == 0, two.stderr[-2000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
     b = json.loads(two.stdout.strip().splitlines()[-1])
-    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and "halo" in b["config"]["sharding"]
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and "17 of 34 planes per GPU, halo 0/1" in b["config"]["sharding"]
+    assert ("overlapped" in b["config"]["sharding"]) == overlap
+    assert a["config"]["kernel_variant"] == 7 and b["config"]["kernel_variant"] == 7
     assert abs(a["checksum_sum_J"] - b["checksum_sum_J"]) <= 1e-12 * abs(a["checksum_sum_J"])
-    assert b["config"]["states_per_gpu"] * 2 == a["config"]["states_per_gpu"]
+    assert b["config"]["states_per_gpu"] * 2 == a["config"]["states_per_gpu"] == b["config"]["states"]
 
 
 F16 = [((9, 8), (3,), False), ((13, 11, 9), (4, 5), True), ((6, 5, 4, 5), (3, 4), False), ((7, 6), (70,), True)]

@@ -1,8 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r02d; mkdir -p $O; rm -f $O/quick.log
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_flat_api.py -x -q -k "colsweep or flat or probe or progress" --timeout 600 > $O/pytest_cs.log 2>&1; echo "pytest rc=$?"; tail -n 5 $O/pytest_cs.log
-timeout 900 python -m pytest tests/test_gpu_solvers.py -x -q -k "c4" --timeout 800 > $O/pytest_c4.log 2>&1; echo "pytest c4 rc=$?"; tail -n 5 $O/pytest_c4.log
-for m in 0 1; do ORDER=0,2,1,3 CS_XCD_MOD=$m timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep variant | sed "s/^/mod=$m: /" | tee -a $O/quick.log; done
-ORDER=0,2,3,1 CS_XCD_MOD=1 timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep variant | sed "s/^/xtwv mod1: /" | tee -a $O/quick.log
-ORDER=0,2,1,3 F16=1 CS_XCD_MOD=1 timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep variant | sed "s/^/f16 mod1: /" | tee -a $O/quick.log
+O=gpurun_out/r02f; mkdir -p $O
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate tools/valu_rate.hip && timeout 200 /tmp/valu_rate > $O/valu_rate.json 2> $O/valu_rate.err; echo "valu_rate rc=$?"
+timeout 900 python -m pytest tests/test_gpu_flat_api.py -x -q --timeout 600 > $O/pytest_flat.log 2>&1; echo "pytest flat rc=$?"; tail -n 6 $O/pytest_flat.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "two_rank" --timeout 600 > $O/pytest_two.log 2>&1; echo "pytest two rc=$?"; tail -n 6 $O/pytest_two.log
+timeout 900 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; tail -c 3000 $O/bench_n1.json; tail -n 5 $O/bench_n1.err

@@ -29,7 +29,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
     } while (0)
 
 enum Op { FMA = 0, PKFMA, MIN3, ADD, CNDMASK, DPPMOV, FMA_SALU, FMA_SGPR, PKADD, MUL, NOPS };
-static const char *kOpName[] = {"v_fma_f32", "v_pk_fma_f32", "v_min3_f32", "v_add_f32", "v_cmp_lt_f32 + v_cndmask_b32 (pair counted as one)",
+static const char *kOpName[] = {"v_fma_f32", "v_pk_fma_f32", "v_min3_f32", "v_add_f32", "v_cndmask_b32 (SGPR-pair mask)",
                                 "v_mov_b32_dpp(wave_shl:1)", "v_fma_f32 + s_add_u32 (1:1)", "v_fma_f32 (SGPR operand)",
                                 "v_pk_add_f32", "v_mul_f32"};
 
@@ -37,6 +37,7 @@ static const char *kOpName[] = {"v_fma_f32", "v_pk_fma_f32", "v_min3_f32", "v_ad
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_rate(float *out, int iters, unsigned long long *cyc) {
+    extern __shared__ float pad_lds[];            // sized by the host so that exactly W workgroups fit on a CU
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     float a[16];
     v2f p[16];
@@ -49,8 +50,11 @@ __global__ void __launch_bounds__(256) k_rate(float *out, int iters, unsigned lo
     v2f pb = v2f{b, b}, pc = v2f{c, c};
     float sb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(0.99991f + 1e-9f * (float)blockIdx.x)));
     unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane(iters), s1 = 3u;
+    const unsigned long long lanemask = __builtin_amdgcn_ballot_w64((threadIdx.x & 3) != 0);   // a lane mask in an SGPR pair
+    if (iters < 0) pad_lds[threadIdx.x] = b;      // keeps the allocation
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
         if (OP == FMA) {
 #define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(256) k_rate(float *out, int iters, unsigned lo
             REP16(X)
 #undef X
         } else if (OP == CNDMASK) {
-#define X(i) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc");
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(lanemask));
             REP16(X)
 #undef X
         } else if (OP == DPPMOV) {
@@ -95,11 +99,15 @@ __global__ void __launch_bounds__(256) k_rate(float *out, int iters, unsigned lo
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = (float)s0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y;
     out[tid] = s;
-    if ((threadIdx.x & 63) == 0) cyc[tid >> 6] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        cyc[2 * (tid >> 6)] = t1 - t0;            // shader clocks
+        cyc[2 * (tid >> 6) + 1] = r1 - r0;        // 100 MHz reference clocks
+    }
 }
 
 __global__ void k_dpp_probe(int *out) {
@@ -111,32 +119,46 @@ __global__ void k_dpp_probe(int *out) {
     out[64 + lane] = shr;
 }
 
+// W workgroups resident per CU (LDS-limited), kRounds times as many dispatched: every SIMD runs W waves for the whole
+// kernel, and dispatch imbalance averages out.  SIMD cycles per wave-instruction =
+//   kernel time x sustained shader clock / (instructions per SIMD), with the clock from s_memtime / s_memrealtime.
+constexpr int kRounds = 6;
+
 template <int OP>
 void run(int W, int iters, float *dout, unsigned long long *dcyc, int ncu, std::string &json) {
-    const int blocks = ncu * W;
+    const int blocks = ncu * W * kRounds;
+    const size_t lds = (size_t)(160 * 1024) / W - 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rate<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k_rate<OP>), dim3(blocks), dim3(256), 0, 0, dout, iters / 8, dcyc);   // warm-up
+    hipLaunchKernelGGL((k_rate<OP>), dim3(blocks), dim3(256), lds, 0, dout, iters / 8, dcyc);   // warm-up
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_rate<OP>), dim3(blocks), dim3(256), 0, 0, dout, iters, dcyc);
+    hipLaunchKernelGGL((k_rate<OP>), dim3(blocks), dim3(256), lds, 0, dout, iters, dcyc);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> cyc((size_t)blocks * 4);
+    std::vector<unsigned long long> cyc((size_t)blocks * 4 * 2);
     CHECK(hipMemcpy(cyc.data(), dcyc, cyc.size() * 8, hipMemcpyDeviceToHost));
-    std::sort(cyc.begin(), cyc.end());
-    const double med = (double)cyc[cyc.size() / 2];
-    const double n_inst = 16.0 * iters * (OP == FMA_SALU ? 1.0 : 1.0);   // vector instructions per wave
-    // W waves share a SIMD: SIMD cycles per wave-instruction = (wave's cycles) / (instructions of all W waves)
-    const double cyc_per_inst = med / (n_inst * W);
-    char buf[512];
+    std::vector<double> clk, wc;
+    for (size_t i = 0; i < cyc.size(); i += 2) {
+        clk.push_back((double)cyc[i] / (double)cyc[i + 1] * 100e6);
+        wc.push_back((double)cyc[i]);
+    }
+    std::sort(clk.begin(), clk.end());
+    std::sort(wc.begin(), wc.end());
+    const double clock = clk[clk.size() / 2], wave_cycles = wc[wc.size() / 2];
+    const double n_inst = 16.0 * iters;                                   // vector instructions per wave
+    const double per_simd = n_inst * (double)blocks * 4.0 / (ncu * 4.0);  // vector instructions per SIMD
+    const double cyc_per_inst = ms * 1e-3 * clock / per_simd;
+    char buf[640];
     snprintf(buf, sizeof buf,
-             "  {\"op\": \"%s\", \"waves_per_simd\": %d, \"iters\": %d, \"median_wave_cycles\": %.0f, "
-             "\"simd_cycles_per_wave_instr\": %.3f, \"kernel_ms\": %.4f, \"wall_cycles_per_wave_instr_at_2.4GHz\": %.3f},\n",
-             kOpName[OP], W, iters, med, cyc_per_inst, ms, ms * 1e-3 * 2.4e9 / (n_inst * W));
+             "  {\"op\": \"%s\", \"waves_per_simd\": %d, \"iters\": %d, \"kernel_ms\": %.4f, \"shader_clock_GHz\": %.3f, "
+             "\"simd_cycles_per_wave_instr\": %.3f, \"wave_cycles_per_own_instr\": %.3f, \"fp32_TFLOPs_if_fma\": %.1f},\n",
+             kOpName[OP], W, iters, ms, clock * 1e-9, cyc_per_inst, wave_cycles / n_inst,
+             per_simd * ncu * 4.0 * 64.0 * 2.0 * (OP == PKFMA ? 2.0 : 1.0) / (ms * 1e-3) * 1e-12);
     json += buf;
     fputs(buf, stderr);
     fflush(stderr);
@@ -155,11 +177,11 @@ int main() {
     const int ncu = prop.multiProcessorCount;
     float *dout;
     unsigned long long *dcyc;
-    CHECK(hipMalloc(&dout, (size_t)ncu * 8 * 256 * 4));
-    CHECK(hipMalloc(&dcyc, (size_t)ncu * 8 * 4 * 8));
+    CHECK(hipMalloc(&dout, (size_t)ncu * 8 * kRounds * 256 * 4));
+    CHECK(hipMalloc(&dcyc, (size_t)ncu * 8 * kRounds * 4 * 2 * 8));
     std::string json = "{\"device\": \"" + std::string(prop.gcnArchName) + "\", \"cus\": " + std::to_string(ncu) +
                        ", \"clock_khz\": " + std::to_string(prop.clockRate) + ",\n \"rates\": [\n";
-    const int iters = 20000;
+    const int iters = 6000;
     sweep<FMA>(iters, dout, dcyc, ncu, json);
     sweep<MUL>(iters, dout, dcyc, ncu, json);
     sweep<ADD>(iters, dout, dcyc, ncu, json);
