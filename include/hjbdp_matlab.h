@@ -1,0 +1,53 @@
+/* hjbdp_matlab.h - the flat part of include/hjbdp.h for MATLAB's loadlibrary.
+ *
+ * loadlibrary parses C prototypes but cannot marshal hjb_problem (arrays of structs holding pointers) or incomplete
+ * struct pointer types comfortably.  Every function below takes primitives, plain arrays and opaque `void *` handles
+ * only; the symbols are the same ones include/hjbdp.h declares (hjb_builder / hjb_handle / hjb_multi are pointers,
+ * spelled void * here).  Usage: matlab/hjbdp_solve.m; semantics: include/hjbdp.h.
+ *
+ *   loadlibrary('libhjbdp.so', 'hjbdp_matlab.h')
+ */
+#ifndef HJBDP_MATLAB_H
+#define HJBDP_MATLAB_H
+#include <stdint.h>
+
+const char *hjb_version(void);
+const char *hjb_status_string(int32_t status);
+int32_t hjb_device_count(void);
+
+/* problem description: replaces the table building of the reference's run methods (test/Dynamic_Solver.m:66-84) */
+int32_t hjb_problem_new(int32_t D, int32_t C, const int32_t *n, const int32_t *m, int32_t dtype, int32_t index_base, void **builder_out);
+int32_t hjb_problem_set_knots(void *builder, int32_t axis, const double *knots, int32_t len);
+int32_t hjb_problem_add_next_term(void *builder, int32_t axis, uint32_t mask, const void *data, int64_t count);
+int32_t hjb_problem_add_cost_term(void *builder, uint32_t mask, const void *data, int64_t count);
+int32_t hjb_problem_set_slab(void *builder, int32_t slab_begin, int32_t slab_end, int32_t halo_lo, int32_t halo_hi);
+int32_t hjb_problem_set_model(void *builder, int32_t model, double model_h, const void *t0, const void *t1, const void *t2, const void *t3);
+int32_t hjb_create_from(void *builder, int32_t device, void **handle_out);
+int32_t hjb_problem_free(void *builder);
+const char *hjb_problem_last_error(void *builder);
+
+/* the stage loops: test/Dynamic_Solver.m:86-102, Solver_position.m:132-141, Solver_attitude.m:236-247 / :280-287,
+ * Solver_pos_att.m:270-286 */
+int32_t hjb_solve_flat(void *handle, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
+                       void *J_final, int32_t *idx_final, void *J_stages, int32_t *idx_stages, int32_t *stages_done,
+                       int32_t *stopped_early, double *sweep_ms);
+/* one stage: [F.Values, idx] = min(J_stage + F(x_next...), [], ctrl_dim)  (Dynamic_Solver.m:207-210) */
+int32_t hjb_backup_stage(void *handle, const void *J_next, void *J_out, int32_t *idx_out);
+int32_t hjb_get_info_flat(void *handle, int64_t *out8);
+int32_t hjb_set_option(void *handle, const char *key, int64_t value);
+int32_t hjb_get_option(void *handle, const char *key, int64_t *value);
+const char *hjb_last_error(void *handle);
+int32_t hjb_destroy(void *handle);
+
+/* the same loop over several GPUs of this process (slabs of the last state axis) */
+int32_t hjb_create_multi_from(void *builder, int32_t n_dev, const int32_t *devices, void **multi_out);
+int32_t hjb_solve_multi_flat(void *multi, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
+                             void *J_final, int32_t *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms);
+int32_t hjb_multi_set_option(void *multi, const char *key, int64_t value);
+const char *hjb_multi_last_error(void *multi);
+int32_t hjb_destroy_multi(void *multi);
+
+/* griddedInterpolant(..., 'nearest' | 'linear') lookups of the results (Solver_position.m:144-146, Dynamic_Solver.m:132-135) */
+int32_t hjb_policy_lookup(int32_t device, int32_t dtype, int32_t D, const int32_t *n, const double *const *knots,
+                          const void *values, int64_t nq, const void *queries, int32_t method, void *out);
+#endif

@@ -704,6 +704,15 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
             }
             *ng_max = std::max(*ng_max, ng);
             q[0] = bad | (ng << 8);
+            // visit the groups in ascending order of their highest control: fewer slots then come after a higher-numbered
+            // control and need the (value, control number) comparison
+            auto gmax = [&](const Grp &G) { int mx = -1; for (int s = 0; s < kCsMMax; ++s) mx = std::max(mx, G.slot[s]); return mx; };
+            std::stable_sort(grp, grp + ng, [&](const Grp &a, const Grp &b) { return gmax(a) < gmax(b); });
+            for (int g = 0; g < ng; ++g) {              // ascending control numbers inside each window pair
+                std::sort(grp[g].slot, grp[g].slot + kCsMMax / 2, [](int a, int b) { return (unsigned)a < (unsigned)b; });
+                std::sort(grp[g].slot + kCsMMax / 2, grp[g].slot + kCsMMax, [](int a, int b) { return (unsigned)a < (unsigned)b; });
+            }
+            int seen_max = -1;
             for (int g = 0; g < kCsGMax; ++g) {
                 const Grp &G = grp[g < ng ? g : 0];                 // padding: a member-less copy of group 0's rows
                 const int64_t off = (gs * G.cg + ws * G.wmin) * (int64_t)h->esz;
@@ -716,6 +725,8 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
                         const int u = G.slot[sidx];
                         if (u < 0) continue;
                         usedbits |= 1 << sidx;
+                        if (u < seen_max) usedbits |= 0x10000 << sidx;
+                        seen_max = std::max(seen_max, u);
                         int32_t *sl = q + kCsPI + 8 * (g * kCsMMax + sidx);
                         sl[0] = bits(tt[wax - 2][u]);
                         sl[1] = bits(tt[gax - 2][u]);

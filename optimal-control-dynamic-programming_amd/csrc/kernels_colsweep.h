@@ -25,15 +25,16 @@
 // control cost and control number are wave-uniform plan data parked in LDS for the column.  The kernel is a template
 // over the number of groups NG (the maximum over the plans; plans with fewer are padded with member-less groups) and
 // straight-line over groups, rows and slots: the rolling A values sit in registers with static indices.  Groups are
-// visited in plan order, not control order, so the running minimum compares (value, control number)
-// lexicographically: the first-index-wins rule of MATLAB's min holds exactly.
+// visited in plan order, not control order, so a slot visited after a higher-numbered control compares (value, control
+// number) lexicographically: the first-index-wins rule of MATLAB's min holds exactly.
 //
 // The two axis-0 neighbours (c0, c0 + 1) of a corner row: the L1 path (64 B per clock per CU) is what bounds this
 // kernel (profiles/r02_c4_colsweep_v1_pmc.json: TA busy 87 %), and the two loads of a pair hit the same cache lines.
-// DPP form (template DPP, chosen on the host when every wave's axis-0 cells satisfy it): a wave carries 62 states
-// + 2 halo lanes, lane L loads knot kb + L ONCE, and the upper neighbour is the next lane's value (`wave_shl:1`, folded
-// by the compiler into the subtract); lanes whose cell sits one knot further (grid-edge clamping, uneven knots) take
-// the values one and two lanes up.  Same values, same arithmetic: bit-identical to every other variant.
+// One-load form (template DPP, chosen on the host when every wave's axis-0 cells satisfy it): a wave carries 62 states
+// + 2 halo lanes, lane L loads knot kb + L ONCE, and a state's neighbours are the values of lanes L and L + 1 - or
+// L + 1 and L + 2 where its cell sits one knot further (grid-edge clamping, uneven knots) - moved by DPP `wave_shl:1`.
+// (Fetching them through the LDS crossbar, ds_bpermute_b32, which takes no vector-ALU slot, was measured slower:
+// 2.90 vs 2.67 ms per stage on C4.)  Same values, same arithmetic: bit-identical to every other variant.
 #pragma once
 #include "hjbdp_dev.h"
 #include "kernels_generic.h"
@@ -50,7 +51,8 @@ constexpr int kCsMaxCu = kLeanMaxCu;
 constexpr int kCsFlush = 8;     // results are parked in LDS and written out every kCsFlush steps
 constexpr int kCsDppLanes = 62; // states per wave in the DPP form (+ 2 halo lanes)
 // The plan of one (i2, i3), 32-bit words:
-//   [0] halo violation flag | groups << 8   [1 + g] byte offset of group g's first corner row   [1 + GMAX + g] bit s = slot s is used | nw << 8
+//   [0] halo violation flag | groups << 8   [1 + g] byte offset of group g's first corner row
+//   [1 + GMAX + g] bit s = slot s is used, bit 16 + s = slot s is visited after a higher-numbered control
 //   [kCsPI + 8 s ...] member slot s' = g * MMAX + s: t_window, t_group, cu[0], control number, cu[1..3], 0
 constexpr int kCsPI = 16;
 constexpr int kCsSlots = kCsGMax * kCsMMax;
@@ -106,11 +108,10 @@ template <typename T, typename TJ> __device__ __forceinline__ T raw_to(uint32_t 
     return (T)__builtin_bit_cast(_Float16, (unsigned short)r);
 }
 
-#ifndef HJB_CS_OCCUPANCY
-#define HJB_CS_OCCUPANCY            // e.g. -DHJB_CS_OCCUPANCY='__attribute__((amdgpu_waves_per_eu(5, 5)))' (tuning experiments)
-#endif
+// Five waves per SIMD (<= 96 VGPRs) for the one-load form with up to five groups - the C4 / C5 kernel, which the
+// register allocator otherwise leaves at 98; the wider forms take what they need.
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP>
-__global__ void __launch_bounds__(256) HJB_CS_OCCUPANCY
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DPP && NG <= 5) ? 5 : 1, (DPP && NG <= 5) ? 5 : 4)))
 k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
                   const TJ *__restrict__ Jn, TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");
@@ -343,8 +344,11 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                             }
                         }
                         const T tot = (T)(gg + interp);
-                        // lexicographic (value, control number): groups are not visited in control order
-                        const bool take = (tot < best) | ((tot == best) & (u < best_u));
+                        // groups are not visited in control order: a slot that comes after a higher-numbered control (flag
+                        // from the plan) compares (value, control number) lexicographically, the others by value alone
+                        bool take;
+                        if (ug & (0x10000 << s)) take = (tot < best) | ((tot == best) & (u < best_u));
+                        else take = tot < best;
                         best = take ? tot : best;
                         best_u = take ? u : best_u;
                     }

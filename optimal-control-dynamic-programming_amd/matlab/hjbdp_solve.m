@@ -1,87 +1,99 @@
 function out = hjbdp_solve(prob, n_stages, varargin)
-%HJBDP_SOLVE  Backward Bellman sweep on an AMD MI355X through libhjbdp (C ABI: include/hjbdp.h).
+%HJBDP_SOLVE  Backward Bellman sweep on AMD MI355X GPUs through libhjbdp's FLAT C API (include/hjbdp_matlab.h:
+%   primitives, plain arrays and opaque handles only - everything calllib can marshal).
 %
-%   out = hjbdp_solve(prob, n_stages, 'keep_stages', true, 'monitor_period', 50, 'monitor_tol', 1e-2)
+%   out = hjbdp_solve(prob, n_stages, 'keep_stages', true, 'monitor_period', 50, 'monitor_tol', 1e-2, 'devices', 0)
 %
 %   Replaces the stage loops of the reference solvers
 %     test/Dynamic_Solver.m:86-102, position-control/Solver_position.m:132-141,
 %     attitude-control/Solver_attitude.m:236-247 / :280-287, pos-att/Solver_pos_att.m:270-286
-%   prob fields (all MATLAB-native, column-major, double unless stated):
+%   prob fields (all MATLAB-native, column-major):
 %     knots      cell{D} of grid vectors            m     [1xC] control grid sizes
 %     next_terms cell{D} of struct arrays (dims, data)    cost_terms struct array (dims, data)
 %                dims = 1-based grid dims the operand varies along (states 1..D, controls D+1..D+C),
 %                data = the reshaped operand exactly as the reference builds it before implicit
 %                expansion (Solver_pos_att.m:307-314), any singleton dims squeezed out
 %     single     logical: run in single (Dynamic_Solver.m:69) or double (test_coder.m) precision
+%     terminal   optional [nS] terminal cost (default zeros, Dynamic_Solver.m:83-84)
+%   'devices': a scalar runs on that GPU (hjb_create_from / hjb_solve_flat); a vector [0 1 .. 7] partitions the LAST
+%   state axis over those GPUs of this process (hjb_create_multi_from / hjb_solve_multi_flat; no per-stage planes).
 %   out: J (final values), idx (1-based argmin labels), and with keep_stages J_stages / idx_stages
 %        [nS x n_stages] with stage k_s in column k_s, stages_done, stopped_early, sweep_ms.
 %
-%   NOT executed in the build image (no MATLAB there); the tested twin of this file is
-%   hjbdp/core.py (ctypes).  See INTEGRATION.md.
+%   The same call sequence is exercised through ctypes by tests/test_gpu_flat_api.py (the build image has no MATLAB);
+%   where loadlibrary is unavailable, mex/hjbdp_mex.c is the same sequence as a MEX gateway.  See INTEGRATION.md.
     p = inputParser;
     addParameter(p, 'keep_stages', false);
     addParameter(p, 'monitor_period', 0);
     addParameter(p, 'monitor_tol', 0);
-    addParameter(p, 'device', 0);
+    addParameter(p, 'devices', 0);
     parse(p, varargin{:});
     o = p.Results;
-    if ~libisloaded('libhjbdp')
+    L = 'libhjbdp';
+    if ~libisloaded(L)
         here = fileparts(mfilename('fullpath'));
-        loadlibrary(fullfile(here, '..', 'hjbdp', 'libhjbdp.so'), fullfile(here, '..', '..', 'include', 'hjbdp.h'));
+        loadlibrary(fullfile(here, '..', 'hjbdp', 'libhjbdp.so'), fullfile(here, '..', '..', 'include', 'hjbdp_matlab.h'), 'alias', L);
     end
     D = numel(prob.knots);  C = numel(prob.m);
     if prob.single, cls = 'single'; ptr = 'singlePtr'; dt = 0; else, cls = 'double'; ptr = 'doublePtr'; dt = 1; end
-    s = libstruct('hjb_problem');
-    s.D = D;  s.C = C;  s.dtype = dt;  s.index_base = 1;
-    n = zeros(1, 6, 'int32');  m = zeros(1, 3, 'int32');
-    keep = {};
+    n = cellfun(@numel, prob.knots);
+    b = libpointer('voidPtrPtr');
+    check(calllib(L, 'hjb_problem_new', int32(D), int32(C), int32(n), int32(prob.m), int32(dt), int32(1), b), [], 'builder');
+    bv = b.Value;
+    freeb = onCleanup(@() calllib(L, 'hjb_problem_free', bv));
+    mask = @(dims) uint32(sum(bitshift(1, dims - 1)));
     for a = 1:D
-        n(a) = numel(prob.knots{a});
-        keep{end+1} = libpointer('doublePtr', double(prob.knots{a}(:))); %#ok<AGROW>
-        s.knots{a} = keep{end};
-    end
-    m(1:C) = int32(prob.m);
-    s.n = n;  s.m = m;
-    nt = zeros(1, 6, 'int32');
-    for a = 1:D
-        T = prob.next_terms{a};  nt(a) = numel(T);
-        for k = 1:numel(T)
-            keep{end+1} = libpointer(ptr, cast(T(k).data(:), cls)); %#ok<AGROW>
-            s.next_terms(a, k).mask = uint32(sum(bitshift(1, T(k).dims - 1)));
-            s.next_terms(a, k).data = keep{end};
+        check(calllib(L, 'hjb_problem_set_knots', bv, int32(a - 1), double(prob.knots{a}(:)), int32(n(a))), bv, 'builder');
+        T = prob.next_terms{a};
+        for k = 1:numel(T)           % MATLAB's left-to-right order of the sum, e.g. A(1)*X1 + A(3)*X2 + B(1)*U (:186)
+            v = cast(T(k).data(:), cls);
+            check(calllib(L, 'hjb_problem_add_next_term', bv, int32(a - 1), mask(T(k).dims), v, int64(numel(v))), bv, 'builder');
         end
     end
-    s.n_next_terms = nt;
-    s.n_cost_terms = numel(prob.cost_terms);
     for k = 1:numel(prob.cost_terms)
-        keep{end+1} = libpointer(ptr, cast(prob.cost_terms(k).data(:), cls)); %#ok<AGROW>
-        s.cost_terms(k).mask = uint32(sum(bitshift(1, prob.cost_terms(k).dims - 1)));
-        s.cost_terms(k).data = keep{end};
+        v = cast(prob.cost_terms(k).data(:), cls);
+        check(calllib(L, 'hjb_problem_add_cost_term', bv, mask(prob.cost_terms(k).dims), v, int64(numel(v))), bv, 'builder');
     end
-    h = libpointer('voidPtrPtr');
-    st = calllib('libhjbdp', 'hjb_create', s, int32(o.device), h);
-    if st ~= 0, error('hjbdp:create', '%s', calllib('libhjbdp', 'hjb_last_error', [])); end
-    cleanup = onCleanup(@() calllib('libhjbdp', 'hjb_destroy', h.Value));
-    nS = prod(double(n(1:D)));
-    so = libstruct('hjb_solve_opts');
-    so.n_stages = int32(n_stages);
-    so.monitor_period = int32(o.monitor_period);  so.monitor_tol = o.monitor_tol;
+    nS = prod(double(n));
+    term = [];
+    if isfield(prob, 'terminal') && ~isempty(prob.terminal), term = cast(prob.terminal(:), cls); end
     Jf = libpointer(ptr, zeros(nS, 1, cls));  If = libpointer('int32Ptr', zeros(nS, 1, 'int32'));
-    so.J_final = Jf;  so.idx_final = If;
-    if o.keep_stages
-        Js = libpointer(ptr, zeros(nS * n_stages, 1, cls));  Is = libpointer('int32Ptr', zeros(nS * n_stages, 1, 'int32'));
-        so.J_stages = Js;  so.idx_stages = Is;
+    done = libpointer('int32Ptr', int32(0));  early = libpointer('int32Ptr', int32(0));  ms = libpointer('doublePtr', 0);
+    h = libpointer('voidPtrPtr');
+    if isscalar(o.devices)
+        check(calllib(L, 'hjb_create_from', bv, int32(o.devices), h), bv, 'builder');
+        hv = h.Value;
+        freeh = onCleanup(@() calllib(L, 'hjb_destroy', hv));
+        Js = [];  Is = [];
+        if o.keep_stages
+            Js = libpointer(ptr, zeros(nS * n_stages, 1, cls));  Is = libpointer('int32Ptr', zeros(nS * n_stages, 1, 'int32'));
+        end
+        check(calllib(L, 'hjb_solve_flat', hv, int32(n_stages), int32(o.monitor_period), o.monitor_tol, term, Jf, If, Js, Is, ...
+                      done, early, ms), hv, 'handle');
+    else
+        if o.keep_stages, error('hjbdp:multi', 'keep_stages needs a single device'); end
+        check(calllib(L, 'hjb_create_multi_from', bv, int32(numel(o.devices)), int32(o.devices), h), bv, 'builder');
+        hv = h.Value;
+        freeh = onCleanup(@() calllib(L, 'hjb_destroy_multi', hv));
+        check(calllib(L, 'hjb_solve_multi_flat', hv, int32(n_stages), int32(o.monitor_period), o.monitor_tol, term, Jf, If, ...
+                      done, early, ms), hv, 'multi');
     end
-    r = libstruct('hjb_result');
-    st = calllib('libhjbdp', 'hjb_solve', h.Value, so, r);
-    if st ~= 0, error('hjbdp:solve', '%s', calllib('libhjbdp', 'hjb_last_error', h.Value)); end
-    shape = double(n(1:D));  if D == 1, shape = [shape 1]; end
+    shape = double(n);  if D == 1, shape = [shape 1]; end
     out.J = reshape(Jf.Value, shape);
-    out.idx = reshape(double(If.Value), shape);
+    out.idx = reshape(double(If.Value), shape);       % MATLAB's min returns double indices
     if o.keep_stages
         out.J_stages = reshape(Js.Value, [nS, n_stages]);
         out.idx_stages = reshape(double(Is.Value), [nS, n_stages]);
     end
-    out.stages_done = double(r.stages_done);  out.stopped_early = logical(r.stopped_early);
-    out.sweep_ms = r.sweep_ms;
+    out.stages_done = double(done.Value);  out.stopped_early = logical(early.Value);  out.sweep_ms = ms.Value;
+
+    function check(st, obj, kind)
+        if st == 0, return; end
+        switch kind
+            case 'builder', msg = calllib(L, 'hjb_problem_last_error', obj);
+            case 'multi',   msg = calllib(L, 'hjb_multi_last_error', obj);
+            otherwise,      msg = calllib(L, 'hjb_last_error', obj);
+        end
+        error('hjbdp:status', '%s (%s)', msg, calllib(L, 'hjb_status_string', int32(st)));
+    end
 end
