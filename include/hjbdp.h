@@ -191,7 +191,11 @@ int32_t hjb_get_info(hjb_handle h, hjb_info *info);
  * for local 2-D problems, kernels_tile2d.h: 0 off, 1 when applicable [default], 2 required), "row_lean" (0/1: lean form of
  * stage kernel 6), "lds_pad" (extra dynamic LDS bytes per workgroup: occupancy experiments) */
 int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
-/* read a knob back, plus what the column-sweep kernel (variant 7) settled on: "cs_dpp" (1: one load per corner row, the
+/* "prep_mfma" (set): rebuild the handle's stage-invariant (cell, weight) tables - 1: with v_mfma_f32_32x32x2_f32 where an
+ * axis' next-state sum splits into (all terms but the last) + (last term) over disjoint grid dims (the affine A x + B u
+ * of every reference solver; csrc/kernels_prep_mfma.h), 0: with the vector kernels.  Bit-identical tables either way;
+ * get: "prep_mfma", "prep_mfma_tables", "prep_tables", "prep_ns" (device time of the last rebuild), "table_hash".
+ * read a knob back, plus what the column-sweep kernel (variant 7) settled on: "cs_dpp" (1: one load per corner row, the
  * upper axis-0 neighbour taken from the next lane), "cs_groups", "cs_group_axis".  "cs_dpp" and "cs_xcd_mod" (residue
  * modulus of the column -> XCD assignment: 0/1 contiguous ranges, -1 the group spacing) are also settable (testing, tuning). */
 int32_t hjb_get_option(hjb_handle h, const char *key, int64_t *value);

@@ -30,6 +30,7 @@
 #include "kernels_tile2d.h"
 #include "kernels_colsweep.h"
 #include "kernels_probe.h"
+#include "kernels_prep_mfma.h"
 #include "kernels_reduce.h"
 
 using namespace hjb;
@@ -90,6 +91,12 @@ struct Handle {
     DTabled htb{};
     DTabled *dtb = nullptr;
     size_t nested_lds = 0;
+    // every stage-invariant (cell, weight) table of this handle: rebuilt by option "prep_mfma" (timing / equality tests)
+    struct PrepRec { int axis; int kind; const int32_t *dsz_d; std::vector<int32_t> dsz; int64_t n; void *tab; };
+    std::vector<PrepRec> preps;
+    int prep_mfma = 0;            // 1: tables were built with v_mfma_f32_32x32x2_f32 where the axis' terms allow it
+    int prep_mfma_axes = 0;       // ... number of tables the MFMA form applied to in the last rebuild
+    double prep_us = 0;           // device time of the last rebuild of all tables
     int cs_state = -1;            // variant 7 (column sweep, kernels_colsweep.h): -1 not examined, 0 does not apply, 1 plan built
     DColSweep hcs{};
     DColSweep *dcs = nullptr;
@@ -516,6 +523,7 @@ int build(Handle *h, const hjb_problem *p) {
                 if (st3) return st3;
                 const int grid = (int)std::min<int64_t>((nent[a] + 255) / 256, 65536);
                 launch_prep<T>(D, grid, h->dp, a, (const int32_t *)dsz_d, nent[a], (int2 *)tab);
+                h->preps.push_back({a, 0, (const int32_t *)dsz_d, dsz, nent[a], tab});
                 A.tab = tab;
             }
             HIP_TRY(h, hipGetLastError());
@@ -614,6 +622,7 @@ int ensure_tabled_t(Handle *h) {
         if (st3) return st3;
         const int grid = (int)std::min<int64_t>((h->dom_entries[a] + 255) / 256, 65536);
         launch_prep_t<T>(D, grid, h->dp, a, (const int32_t *)dsz_d, h->dom_entries[a], (TabEntry<T> *)tab);
+        h->preps.push_back({a, 1, (const int32_t *)dsz_d, dsz, h->dom_entries[a], tab});
         A.tab = tab;
     }
     HIP_TRY(h, hipGetLastError());
@@ -628,6 +637,96 @@ int ensure_tabled_t(Handle *h) {
 
 int ensure_tabled(Handle *h) {
     return h->dtype != HJB_F64 ? ensure_tabled_t<float>(h) : ensure_tabled_t<double>(h);
+}
+
+// Rebuild every (cell, weight) table of the handle, with the vector term-sum kernels or - where an axis' last term
+// is separable from the others - with the MFMA outer-sum kernel (kernels_prep_mfma.h).  Same bits either way.
+static bool prep_split(const Handle *h, const Handle::PrepRec &R, DPrepSplit *S) {
+    const hjb_problem &p = h->prob;
+    const int a = R.axis, nt = p.n_next_terms[a], G = p.D + p.C;
+    if (h->dtype == HJB_F64 || nt < 2) return false;
+    uint32_t others = 0;
+    for (int k = 0; k + 1 < nt; ++k) others |= p.next_terms[a][k].mask;
+    const uint32_t last = p.next_terms[a][nt - 1].mask;
+    if (!last || !others || (last & others)) return false;
+    memset(S, 0, sizeof *S);
+    int64_t stride = 1, nr = 1, nc = 1;
+    for (int d = 0; d < G; ++d) {
+        const int sz = R.dsz[(size_t)d];
+        const bool in_dom = ((last | others) >> d) & 1u;
+        if (!in_dom) { if (sz != 1) return false; continue; }
+        if ((last >> d) & 1u) {
+            S->col_dim[S->n_col_dims] = d; S->col_size[S->n_col_dims] = sz; S->col_estride[S->n_col_dims++] = (int32_t)stride;
+            nc *= sz;
+        } else {
+            S->row_dim[S->n_row_dims] = d; S->row_size[S->n_row_dims] = sz; S->row_estride[S->n_row_dims++] = (int32_t)stride;
+            nr *= sz;
+        }
+        stride *= sz;
+    }
+    if (nr * nc != R.n || nr >= ((int64_t)1 << 31) || nc >= ((int64_t)1 << 31)) return false;
+    S->n_rows = (int32_t)nr;
+    S->n_cols = (int32_t)nc;
+    return true;
+}
+
+int rebuild_tables(Handle *h, bool mfma) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipEventRecord(e0, nullptr));
+    const int D = h->hp.D;
+    int n_mfma = 0;
+    for (const auto &R : h->preps) {
+        DPrepSplit S;
+        if (mfma && prep_split(h, R, &S)) {
+            const int64_t tiles = (int64_t)((S.n_rows + 31) / 32) * ((S.n_cols + 31) / 32);
+            dim3 g((unsigned)std::min<int64_t>((tiles + 3) / 4, 65536)), b(256);
+            switch (D) {
+                case 1: hipLaunchKernelGGL((k_prep_axis_table_mfma<1>), g, b, 0, nullptr, h->dp, R.axis, S, (int2 *)R.tab); break;
+                case 2: hipLaunchKernelGGL((k_prep_axis_table_mfma<2>), g, b, 0, nullptr, h->dp, R.axis, S, (int2 *)R.tab); break;
+                case 3: hipLaunchKernelGGL((k_prep_axis_table_mfma<3>), g, b, 0, nullptr, h->dp, R.axis, S, (int2 *)R.tab); break;
+                case 4: hipLaunchKernelGGL((k_prep_axis_table_mfma<4>), g, b, 0, nullptr, h->dp, R.axis, S, (int2 *)R.tab); break;
+                case 5: hipLaunchKernelGGL((k_prep_axis_table_mfma<5>), g, b, 0, nullptr, h->dp, R.axis, S, (int2 *)R.tab); break;
+                default: hipLaunchKernelGGL((k_prep_axis_table_mfma<6>), g, b, 0, nullptr, h->dp, R.axis, S, (int2 *)R.tab); break;
+            }
+            ++n_mfma;
+            continue;
+        }
+        const int grid = (int)std::min<int64_t>((R.n + 255) / 256, 65536);
+        if (h->dtype == HJB_F64) {
+            if (R.kind == 0) launch_prep<double>(D, grid, h->dp, R.axis, R.dsz_d, R.n, (int2 *)R.tab);
+            else launch_prep_t<double>(D, grid, h->dp, R.axis, R.dsz_d, R.n, (TabEntry<double> *)R.tab);
+        } else {
+            if (R.kind == 0) launch_prep<float>(D, grid, h->dp, R.axis, R.dsz_d, R.n, (int2 *)R.tab);
+            else launch_prep_t<float>(D, grid, h->dp, R.axis, R.dsz_d, R.n, (TabEntry<float> *)R.tab);
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(e1, nullptr));
+    HIP_TRY(h, hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    h->prep_us = (double)ms * 1e3;
+    h->prep_mfma = mfma ? 1 : 0;
+    h->prep_mfma_axes = n_mfma;
+    return HJB_OK;
+}
+
+int table_hash(Handle *h, uint64_t *out) {      // FNV-1a over the bytes of every table, in registration order
+    uint64_t hsh = 1469598103934665603ull;
+    std::vector<unsigned char> buf;
+    for (const auto &R : h->preps) {
+        const size_t bytes = (size_t)R.n * ((h->dtype == HJB_F64 && R.kind == 1) ? 16 : 8);
+        buf.resize(bytes);
+        HIP_TRY(h, hipMemcpy(buf.data(), R.tab, bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < bytes; ++i) { hsh ^= buf[i]; hsh *= 1099511628211ull; }
+    }
+    *out = hsh;
+    return HJB_OK;
 }
 
 // ---- variant 7 (kernels_colsweep.h): eligibility + the per-(i2, i3) plan, built once on the host from the
@@ -1488,6 +1587,15 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         }
         return HJB_OK;
     }
+    if (!strcmp(key, "prep_mfma")) {       // rebuild every (cell, weight) table: 1 = MFMA outer-sum form where it applies
+        if (h->variant == 5 || h->variant == 6 || h->variant == 7) { const int tst = ensure_tabled(h); if (tst) return tst; }
+        HIP_TRY(h, hipSetDevice(h->device));
+        const int rst = rebuild_tables(h, value != 0);
+        if (rst) return rst;
+        if (h->cs_state == 1) {            // variant 7's plan is derived from the tables: same bits, nothing to redo
+        }
+        return HJB_OK;
+    }
     if (!strcmp(key, "cs_dpp")) {                                    // 0: variant 7 loads both axis-0 neighbours (testing)
         h->cs_dpp = value != 0;
         if (h->cs_state == 1) {
@@ -1545,6 +1653,18 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "row_lean")) *value = h->row_lean ? 1 : 0;
     else if (!strcmp(key, "lds_pad")) *value = (int64_t)h->lds_pad;
     else if (!strcmp(key, "cs_xcd_mod")) *value = h->cs_xcd_mod;
+    else if (!strcmp(key, "prep_mfma")) *value = h->prep_mfma;
+    else if (!strcmp(key, "prep_mfma_tables")) *value = h->prep_mfma_axes;
+    else if (!strcmp(key, "prep_tables")) *value = (int64_t)h->preps.size();
+    else if (!strcmp(key, "prep_ns")) *value = (int64_t)(h->prep_us * 1e3);          // device time of the last table rebuild
+    else if (!strcmp(key, "table_hash")) {
+        uint64_t hv = 0;
+        std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+        HIP_TRY(h, hipSetDevice(h->device));
+        const int hst = table_hash(h, &hv);
+        if (hst) return hst;
+        *value = (int64_t)(hv & 0x7fffffffffffffffull);
+    }
     else if (!strcmp(key, "cs_dpp")) *value = (h->variant == 7 && h->hcs.dpp) ? 1 : 0;          // the form in effect
     else if (!strcmp(key, "cs_groups")) *value = h->variant == 7 ? h->hcs.ng : 0;
     else if (!strcmp(key, "cs_group_axis")) *value = h->variant == 7 ? h->hcs.gax : -1;

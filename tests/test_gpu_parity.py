@@ -805,3 +805,46 @@ def test_randomised_stress_slice(env):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "20", "5"],
                        capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("case", ["c2_small", "pos_att", "kirk", "nested6", "colsweep_slab"])
+def test_mfma_table_build_is_bit_identical(env, case):
+    """BASELINE config 5's "batched-GEMM A.X path on MFMA": the only place the affine next-state sum over all grid
+    states exists in this design is the one-off table build; its MFMA form (v_mfma_f32_32x32x2_f32 as the outer sum
+    [f 1].[1; g], csrc/kernels_prep_mfma.h) must give the SAME tables as the vector build - the f32 MFMA is a k-ordered
+    fmaf chain, so fma(1, g, fma(f, 1, 0)) = round(f + g): equal bits, checked on the tables' hash and on a sweep."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, nested_problem, random_terminal
+    from hjbdp.synthetic import position3d_spec
+    slab, variant = None, None
+    if case == "c2_small":
+        spec = position3d_spec(n=23, mu=7)                                    # variant 4: axis tables built in hjb_create
+    elif case == "pos_att":
+        pa = hjbdp.Solver_pos_att()
+        pa.cost_mode = "terms"
+        pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 37, 9, 8, 11
+        sx, sv, st, sw = pa.grids()
+        spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                        pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+        variant = 5
+    elif case == "kirk":
+        spec, variant = _kirk(hjbdp, "single", 8, 45, 70).build_spec(), 5     # rows (x1, x2), columns u: 70 > one 32-wide tile
+    elif case == "nested6":
+        spec, variant = nested_problem(77, (4, 3, 4, 3, 3, 5), (3, 3, 3), dtype=np.float32), 5
+    else:
+        spec, variant, slab = colsweep_problem(9, (36, 7, 9, 14), gax=2), 7, (4, 9, 1, 1)
+    term = random_terminal(spec, 3)
+    with hjbdp.Backup(spec, slab=slab, variant=variant) as bk:
+        if slab is None:
+            ref = bk.solve(3, terminal=term)
+        bk.set_option("prep_mfma", 0)
+        h0, n_tab = bk.get_option("table_hash"), bk.get_option("prep_tables")
+        bk.set_option("prep_mfma", 1)
+        h1, n_mfma = bk.get_option("table_hash"), bk.get_option("prep_mfma_tables")
+        assert n_tab >= 1 and n_mfma >= 1, (n_tab, n_mfma)       # the MFMA form applied to at least one axis
+        assert h0 == h1
+        if slab is None:
+            out = bk.solve(3, terminal=term)
+            assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+            orc = c_oracle.sweep(_abi, spec, 3, terminal=term)
+            assert np.array_equal(out["J"], orc["J"]) and np.array_equal(out["idx"], orc["idx"])
