@@ -79,7 +79,7 @@ def build_spec(workload, n_last=None, n=120):
     raise ValueError(workload)
 
 
-def cpu_baseline(spec, budget_s=15.0):
+def cpu_baseline(spec, budget_s=15.0, dataflow_spec=None):
     """Oracle C twin on this host's cores, on a slab sample (whole planes of the last axis, mid-grid, with
     halos) of the SAME workload."""
     import numpy as np
@@ -104,9 +104,25 @@ def cpu_baseline(spec, budget_s=15.0):
     planes = int(max(1, min(spec.n[-1] // 2 - hh - 1, budget_s / max(t1, 1e-3))))
     t = run(planes) if planes > 1 else t1
     backups = inner * planes * spec.nU
-    return {"value": backups / t, "unit": "backups/s", "cores": cores, "kind": "port",
-            "sample": "%d of %d planes of the last state axis (%d states x %d controls, 1 stage) in %.1f s; "
-                      "oracle/hjb_oracle.c, OpenMP" % (planes, spec.n[-1], inner * planes, spec.nU, t)}
+    out = {"value": backups / t, "unit": "backups/s", "cores": cores, "kind": "port",
+           "sample": "%d of %d planes of the last state axis (%d states x %d controls, 1 stage) in %.1f s; "
+                     "oracle/hjb_oracle.c, OpenMP" % (planes, spec.n[-1], inner * planes, spec.nU, t)}
+    if dataflow_spec is not None:
+        # the reference's own dataflow restated in numpy (SURVEY 8d "CPU reference timing"): materialised
+        # next-state and cost tables over states x controls, vectorised N-linear interpolation, min over the control axis
+        from oracle import hjb_oracle
+        ds = dataflow_spec
+        prob = hjb_oracle.Problem(ds.knots, ds.m, [[hjb_oracle.Term(tm.dims, tm.data) for tm in ts] for ts in ds.next_terms],
+                                  [hjb_oracle.Term(tm.dims, tm.data) for tm in ds.cost_terms], dtype=ds.dtype)
+        Jn = rng.random(ds.nS).astype(ds.dtype)
+        t0 = time.perf_counter()
+        hjb_oracle.backup_stage(prob, Jn)
+        td = time.perf_counter() - t0
+        out["matlab_dataflow_numpy"] = {"value": ds.nS * ds.nU / td, "unit": "backups/s", "kind": "port",
+                                        "sample": "the same problem on a %s grid (%d states x %d controls, 1 stage) in %.1f s; "
+                                                  "oracle/hjb_oracle.py: materialised tables + vectorised interpolation + min, "
+                                                  "numpy (single process)" % ("x".join(str(k) for k in ds.n), ds.nS, ds.nU, td)}
+    return out
 
 
 def collect_pmc(argv_child, kernel_filter, timeout_s=240):
@@ -313,7 +329,8 @@ def main():
             out["weak_scaling"] = {"workload": r["name"], "value": r["total_backups"] / r["wall"], "unit": "backups/s",
                                    "ms_per_step": r["wall"] * 1e3 / r["steps"], "states_per_gpu": r["states_rank"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(spec)
+        small = build_spec(args.workload, n=32)[0] if args.workload in ("c4", "c5") else None
+        out["cpu_baseline"] = cpu_baseline(spec, dataflow_spec=small)
     if world > 1:
         dist.barrier()
     if rank == 0:

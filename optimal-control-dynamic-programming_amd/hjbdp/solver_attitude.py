@@ -244,3 +244,34 @@ class Solver_attitude:
         self.U2_Opt = self.U_vector[i2].astype(f32)
         self.U3_Opt = self.U_vector[i3].astype(f32)
         return self
+
+    # ------------------------------------------------------------------ closed-loop rollouts (hjbdp/rollout.py)
+    def grid_vectors_full(self):
+        """The six grid vectors of `run` in the reference's dim order (w1, w2, w3, yaw, pitch, roll), :177-183."""
+        nw, nq = self.n_mesh_w, self.n_mesh_q
+        sr = linspace(self.w_min, self.w_max, nw)
+        return [sr, sr, sr,
+                linspace(float(deg2rad(self.yaw_min)), float(deg2rad(self.yaw_max)), nq),
+                linspace(float(deg2rad(self.pitch_min)), float(deg2rad(self.pitch_max)), nq),
+                linspace(float(deg2rad(self.roll_min)), float(deg2rad(self.roll_max)), nq)]
+
+    def spacecraft_dynamics_list(self, X, U):
+        from . import rollout
+        return rollout.spacecraft_dynamics_list(self, X, U)                   # :600-620
+
+    def next_stage_states(self, X1, U, h, mode="RK4"):
+        from . import rollout
+        return rollout.next_stage_states(self, X1, U, h, mode)                # :670-696
+
+    def linear_control_response(self, X0=None, T_final=None, dt=None):
+        from . import rollout
+        return rollout.linear_control_response(self, X0, T_final, dt)         # :508-591
+
+    def get_optimal_path(self, X0=None, method="nearest", n_steps=None):
+        from . import rollout
+        return rollout.attitude_optimal_path(self, X0, method, n_steps)       # :744-833 (after run)
+
+    def get_optimal_path_simplified_testode45(self, X0=None, n_steps=None):
+        from . import rollout
+        return rollout.attitude_optimal_path_simplified(self, X0, n_steps)    # :835-925 (after simplified_run)
+

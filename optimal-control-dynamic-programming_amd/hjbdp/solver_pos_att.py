@@ -16,7 +16,7 @@ note 6 documents as unpinned by any reference artefact.  The stage cost is by
 default passed as ONE full-mask term holding single(double sum), which is exactly
 `J_current_M = single(...)` (:800-801); cost_mode='terms' passes the five
 separable operands instead (float32 sums, ~1 ulp different, no nS*nU table).
-Policy use / forward simulation (:404-730) is out of scope.
+Policy use / forward simulation (:404-847): hjbdp/rollout.py (host-side, get_optimal_path below).
 """
 from __future__ import annotations
 
@@ -217,3 +217,22 @@ class Solver_pos_att:
         for (args, name), (spec, combos), out, r in zip(jobs, built, outs, rel):
             self._store_controller(name, args[:4], spec.n, combos, self._map_back(out, r[1]))
         return self
+
+    # ------------------------------------------------------------------ closed-loop rollout (hjbdp/rollout.py)
+    def get_target_R0V0(self):
+        from . import rollout
+        return rollout.target_R0V0()                                          # :734-753
+
+    def to_Moments_Forces(self, f, R0, V0, q):
+        from . import rollout
+        return rollout.to_Moments_Forces(self, f, R0, V0, q)                  # :804-823
+
+    def get_thruster_on_off_optimal(self, x, v, t, w, R0, V0, q):
+        from . import rollout
+        return rollout.get_thruster_on_off_optimal(rollout.thruster_policies(self), x, v, t, w, R0, V0, q)   # :404-449
+
+    def get_optimal_path(self, X0=None, n_steps=None):
+        """:452-730 without the plots -> (T, X [N, 13], F_Th_Opt [N, 12], Force_Moment_log [N, 6])."""
+        from . import rollout
+        return rollout.pos_att_optimal_path(self, X0, n_steps)
+

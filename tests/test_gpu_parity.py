@@ -783,6 +783,38 @@ def test_temporal_blocking_2d_bit_exact(env, dtype, j_storage, n, stages):
         assert np.array_equal(out0["J"], ref["J"]) and np.array_equal(out0["idx"], ref["idx"])
 
 
+@pytest.mark.parametrize("dtype,j_storage,n,m,stages", [
+    (np.float64, None, (41, 37), (9,), 37),                 # 9 controls: more than the cached form keeps in registers
+    (np.float32, None, (70, 20), (3, 3), 100),              # two control dims (labels enumerate them column-major); graph replay
+    (np.float32, np.float16, (33, 50), (5, 2), 29),         # float16 storage, ragged tiles, stages % 8 != 0
+    (np.float64, None, (16, 16), (2, 2, 3), 16),            # three control dims
+    (np.float32, None, (5, 90), (17,), 70)])
+def test_temporal_blocking_2d_uncached_form_bit_exact(env, dtype, j_storage, n, m, stages):
+    """K9's general form `k_backup_tile2d` (more than 4 controls or more than one control dim: per-control table
+    look-ups inside the multi-stage kernel, label composition over the control dims) - the default for such local 2-D
+    problems, so it needs the same coverage as the cached form above."""
+    hjbdp, _abi, c_oracle = env
+    from problems import Term
+    rng = np.random.default_rng(n[0] + len(m))
+    kx, kv = np.linspace(-0.5, 0.5, n[0]), np.linspace(-0.4, 0.6, n[1])
+    hx, hv = kx[1] - kx[0], kv[1] - kv[0]
+    C = len(m)
+    # x+ = x + a(v) + a small control push, v+ = v + b(x) + sum of per-control-dim pushes: every query within one cell
+    us = [np.linspace(-1.0, 1.0, mc) if mc > 1 else np.zeros(1) for mc in m]
+    nxt = [[Term((0,), kx), Term((1,), 0.6 * hx * np.sin(3 * kv)), Term((2,), 0.3 * hx * us[0])],
+           [Term((1,), kv), Term((0,), 0.3 * hv * np.cos(5 * kx))] + [Term((2 + c,), (0.6 / C) * hv * us[c]) for c in range(C)]]
+    cost = [Term((0,), 6 * kx ** 2), Term((1,), 3 * kv ** 2)] + [Term((2 + c,), 0.1 * (1 + c) * np.round(us[c] * 2) ** 2) for c in range(C)]
+    cost.append(Term((0, 2), 0.05 * rng.random((n[0], m[0]))))
+    spec = hjbdp.ProblemSpec([kx, kv], list(m), nxt, cost, dtype=dtype, index_base=1, j_storage=j_storage)
+    term = (rng.random(spec.nS) * 2).astype(spec.j_dtype)
+    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, nthreads=8)
+    with hjbdp.Backup(spec) as bk:
+        bk.set_option("temporal", 2)                 # fail if the blocked path is not the one that runs
+        out = bk.solve(stages, terminal=term)
+        assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+        assert out["idx"].min() >= 1 and out["idx"].max() <= spec.nU
+
+
 def test_temporal_blocking_refused_when_not_local(env):
     """Kirk's dynamics move x2 by up to ~40 cells per stage: K9 must not be used (and says so when required)."""
     hjbdp, _abi, c_oracle = env

@@ -165,6 +165,54 @@ def test_c3_full_size_51_pow_6(env):
     assert np.array_equal(idx[ts].cpu().numpy(), ir)
 
 
+@pytest.mark.parametrize("form", ["tabulated", "on_the_fly"])
+def test_6d_24_pow_6_sampled_states(env, form):
+    """The 6-D figure DESIGN.md quotes next to C3: Solver_attitude.run's model on a 24^6 = 1.9e8-state grid x 11^3 torques
+    (SURVEY 8d), with the next angles tabulated as the reference does (`Solver_attitude.m:449-504`, K3 mode 2) and
+    computed on the fly (mode 3).  One backup from a separable J_k+1; a sample of states - corners, edges, random -
+    must agree with the oracle bit for bit."""
+    import torch
+    hjbdp, _abi, c_oracle = env
+    sa = hjbdp.Solver_attitude(n_mesh_w=24, n_mesh_q=24)
+    sa.U_vector = np.linspace(-0.11, 0.11, 11)
+    if form == "tabulated":
+        spec, _ = hjbdp.permute_state_axes(sa.build_spec_full(), sa.AXIS_ORDER)
+    else:
+        spec = sa.build_spec_model()
+    assert spec.nS == 24 ** 6 and spec.nU == 1331
+    rng = np.random.default_rng(24)
+    vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
+    dev = torch.device("cuda:0")
+    J = torch.empty(spec.nS, dtype=torch.float32, device=dev)
+    Jv = J.view(*reversed(spec.n))                      # torch dim 5-a <-> state axis a (axis 0 fastest)
+    for a, v in enumerate(vecs):
+        shape = [1] * 6
+        shape[5 - a] = -1
+        t = torch.from_numpy(v).to(dev).view(*shape)
+        if a == 0:
+            Jv.copy_(t.expand_as(Jv))
+        else:
+            Jv.add_(t)                                  # one float32 add per element, like the checker
+    Jo = torch.empty_like(J)
+    idx = torch.empty(spec.nS, dtype=torch.int32, device=dev)
+    with hjbdp.Backup(spec) as bk:
+        info = bk.info()
+        assert info["kernel_variant"] == 4 and info["n_states"] == 24 ** 6
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        bk.backup_stage_device(J, Jo, idx, stream=stream)
+        torch.cuda.synchronize()
+        bk.check_device_status(stream)
+    n = np.array(spec.n, dtype=np.int64)
+    sel = rng.integers(0, spec.nS, 400)
+    corners = [sum(int(c) * int(np.prod(n[:a])) for a, c in enumerate(cs))
+               for cs in ((0,) * 6, (23,) * 6, (23, 0, 23, 0, 23, 0), (0, 23, 0, 23, 0, 23), (12,) * 6, (23, 23, 23, 0, 0, 23))]
+    sel = np.unique(np.concatenate([sel, np.array(corners, dtype=np.int64), [spec.nS - 1]]))
+    Jr, ir = c_oracle.backup_states(_abi, spec, vecs, sel)
+    ts = torch.from_numpy(sel).to(dev)
+    assert np.array_equal(Jo[ts].cpu().numpy(), Jr)
+    assert np.array_equal(idx[ts].cpu().numpy(), ir)
+
+
 def test_solver_attitude_full_6d(env):
     """Solver_attitude.run semantics (6-D x 3-D, single) at a reduced size."""
     hjbdp, _abi, c_oracle = env
@@ -307,3 +355,33 @@ def test_solver_position_closed_loop_rollout(env):
     assert np.all(np.diff(X[0, :100]) > 0) and X[0, 300] > X[0, 0]
     assert X[3, 100] == pytest.approx(0.26 * 100 * sp.h, rel=1e-2)           # dv ~ a*t while the thrust is constant
     assert np.max(np.abs(X[2])) < 1e-12 and np.max(np.abs(F[2])) == 0.0      # z stays at the origin
+
+
+def test_attitude_and_pos_att_closed_loop_rollouts(env):
+    """the policies the sweeps leave drive the reference's forward simulators (hjbdp/rollout.py).
+    No reference artefact exists for them; pinned by invariants: unit quaternions, thrusters only at their two
+    levels, the attitude error and rates decay under the simplified attitude policies, the pos-att chaser moves
+    toward the target along x while its attitude error shrinks."""
+    hjbdp, _abi, c_oracle = env
+    sa = hjbdp.Solver_attitude(n_mesh_t=120, n_mesh_w_simplified=200)
+    sa.simplified_run(n_stages=600)
+    T, X, U = sa.get_optimal_path_simplified_testode45(n_steps=500)
+    assert X.shape == (501, 7) and np.allclose(np.linalg.norm(X[:, 3:], axis=1), 1.0, atol=1e-3)
+    assert set(np.unique(U)).issubset({-0.11, 0.0, 0.11}) and np.any(U != 0)
+    err0, err1 = np.linalg.norm(X[0, 3:6]), np.linalg.norm(X[500, 3:6])
+    assert err1 < err0                                         # 2.5 s of control already reduce the attitude error
+    # the 6-D policy of run() at a small size: one lookup per stage in the six-dimensional tables
+    sa6 = hjbdp.Solver_attitude(n_mesh_w=7, n_mesh_q=6)
+    sa6.run(n_stages=8)
+    X6, U6, XA = sa6.get_optimal_path(n_steps=50)
+    assert X6.shape == (7, 51) and np.allclose(np.linalg.norm(X6[3:, :], axis=0), 1.0, atol=1e-12)
+    assert set(np.unique(U6)).issubset({np.float32(-0.11), np.float32(0.0), np.float32(0.11)} | {-0.11, 0.0, 0.11})
+    # pos-att: three channels, 13-state closed loop
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = "terms"
+    pa.simplified_run(n_stages=300)
+    T, Xp, F, FM = pa.get_optimal_path(n_steps=200)
+    assert Xp.shape == (201, 13) and np.allclose(np.linalg.norm(Xp[:, 6:10], axis=1), 1.0, atol=1e-3)
+    assert set(np.unique(np.abs(F))).issubset({0.0, 0.13}) and np.any(F != 0)
+    assert Xp[200, 0] > Xp[0, 0]                               # from 100 m behind (-0.1 km) toward the target
+    assert np.all(np.abs(FM[:200, 0:3]) <= 2 * 0.13 / pa.Mass + 1e-12) and np.all(np.abs(FM[:200, 3:6]) <= 2 * 0.13 * pa.T_dist + 1e-12)

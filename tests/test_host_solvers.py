@@ -230,3 +230,49 @@ def test_orbit_routines_against_closed_forms():
                      np.concatenate([dr, dv]))
     assert abs((y2[3] - y1[3]) - 0.26 * 0.005) < 1e-9                  # dv = a t exactly (constant derivative)
     assert 0.5 < (y2[0] - y1[0]) / (0.26 * 0.005 ** 2 / 2) < 1.6      # dx = a t^2 / 2 up to the clipped-step error
+
+
+def test_rollout_kinematics_invariants():
+    """hjbdp/rollout.py (no reference artefact exists for the simulators, so invariants pin them):
+    the quaternion / Euler conversions are inverse to each other and agree with MATLAB's documented 'ZYX' formulas,
+    frame rotations are orthonormal, the torque-free rigid body conserves kinetic energy and |J w|, the PD reference
+    controller (Solver_attitude.m:508-591) drives the default initial state to rest with a unit quaternion."""
+    import hjbdp
+    from hjbdp import rollout
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        ypr = rng.uniform([-3, -1.5, -3], [3, 1.5, 3])
+        q = rollout.angle_to_quat(*ypr)
+        assert abs(np.linalg.norm(q) - 1) < 1e-14
+        assert np.allclose(rollout.quat_to_yaw_pitch_roll(q), ypr, atol=1e-12)
+    # MathWorks' documented example of angle2quat, and the reference's own default state: its quaternion (:160, stored
+    # scalar-last) is exactly yaw 5, pitch 10, roll -9 degrees under this convention
+    assert np.allclose(rollout.angle_to_quat(0.7854, 0.1, 0.0), [0.9227, -0.0191, 0.0462, 0.3822], atol=5e-5)
+    ypr = np.rad2deg(rollout.quat_to_yaw_pitch_roll(rollout.DEFAULT_X0_ATTITUDE[3:][::-1]))
+    assert np.allclose(ypr, [5.0, 10.0, -9.0], atol=1e-9)
+    R0, V0 = rollout.target_R0V0()
+    M = rollout.RSW2ECI(R0, V0)
+    assert np.allclose(M.T @ M, np.eye(3), atol=1e-13) and abs(np.linalg.det(M) - 1) < 1e-13
+    B = rollout.ECI2body(rollout.DEFAULT_X0_ATTITUDE[3:])
+    assert np.allclose(B.T @ B, np.eye(3), atol=1e-13) and abs(np.linalg.det(B) - 1) < 1e-13
+    sa = hjbdp.Solver_attitude()
+    # torque-free motion with the diagonal inertia of spacecraft_dynamics_list: energy and angular momentum
+    X = np.concatenate([[0.3, -0.2, 0.25], rollout.DEFAULT_X0_ATTITUDE[3:]])
+    Jd = np.array([sa.J1, sa.J2, sa.J3])
+    E0, L0 = 0.5 * np.sum(Jd * X[:3] ** 2), np.linalg.norm(Jd * X[:3])
+    for _ in range(2000):
+        X = sa.next_stage_states(X, np.zeros(3), 1e-3)
+    assert abs(0.5 * np.sum(Jd * X[:3] ** 2) - E0) < 1e-9 * E0 and abs(np.linalg.norm(Jd * X[:3]) - L0) < 1e-9 * L0
+    assert abs(np.linalg.norm(X[3:]) - 1) < 1e-14
+    Xs, Us, ang = sa.linear_control_response(T_final=60.0, dt=0.01)
+    assert np.allclose(np.linalg.norm(Xs[3:], axis=0), 1.0, atol=1e-12)
+    assert np.max(np.abs(Xs[:3, -1])) < 1e-3 and np.max(np.abs(Xs[3:6, -1])) < 2e-2      # at rest, near the identity attitude
+    assert np.max(np.abs(ang[:, -1])) < np.max(np.abs(ang[:, 0]))
+    # thrusters -> moments / accelerations (Solver_pos_att.m:804-823): a pure +x pair gives no moment about y
+    pa = hjbdp.Solver_pos_att()
+    f = np.zeros(12); f[0] = f[1] = 0.13
+    U_M, acc = pa.to_Moments_Forces(f, R0, V0, np.array([0.0, 0.0, 0.0, 1.0]))
+    assert np.allclose(U_M, 0.0) and abs(np.linalg.norm(acc) - 0.26 / pa.Mass) < 1e-15
+    f = np.zeros(12); f[0] = 0.13
+    U_M, acc = pa.to_Moments_Forces(f, R0, V0, np.array([0.0, 0.0, 0.0, 1.0]))
+    assert np.allclose(U_M, [0.0, 0.13 * pa.T_dist, 0.0])
