@@ -136,7 +136,9 @@ typedef struct hjb_probe {
 typedef struct hjb_solve_opts {
     int32_t n_stages;        /* number of backups: N-1 (Dynamic_Solver.m:86), N_stage-1 */
     int32_t monitor_period;  /* 0 = off; 50 in Solver_pos_att.m:273                     */
-    double monitor_tol;      /* 1e-2 in Solver_pos_att.m:269                            */
+    double monitor_tol;      /* 1e-2 in Solver_pos_att.m:269.  Deliberate deviation: the sums are exact float64 sums
+                                (fixed reduction tree, reproducible); MATLAB's sum() of the single array F.Values is
+                                a single-precision sum, so |e| < tol can first hold at a different monitor point there */
     const void *terminal;    /* J_N [nS] dtype, NULL = zeros (Dynamic_Solver.m:83-84)   */
     void *J_final;           /* out [nS] dtype: J of the last computed stage (may be NULL) */
     int32_t *idx_final;      /* out [nS]: argmin labels of the last computed stage      */
