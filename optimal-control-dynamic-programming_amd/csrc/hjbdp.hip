@@ -886,8 +886,8 @@ int colsweep_map(Handle *h, const std::vector<int32_t> &plan) {
     return HJB_OK;
 }
 
-// DPP form of variant 7: every wave of kCsDppLanes consecutive axis-0 states must have (cell - state index) within two
-// adjacent values, so that lane L's two neighbours are among the knots lanes L .. L + 2 load.
+// One-load form of variant 7: in every wave of kCsDppLanes consecutive axis-0 states, (cell - state index) is the same
+// for all states but at most one (a cell clamped at the grid edge; the kernel gives that state a lane pair of its own).
 template <typename T>
 int colsweep_dpp_ok(Handle *h, bool *ok) {
     const DParams &P = h->hp;
@@ -900,13 +900,18 @@ int colsweep_dpp_ok(Handle *h, bool *ok) {
     for (int i3 = 0; i3 < r3 && *ok; ++i3)
         for (int i2 = 0; i2 < r2 && *ok; ++i2)
             for (int c = 0; c < n0 && *ok; c += kCsDppLanes) {
-                int mn = INT32_MAX, mx = INT32_MIN;
-                for (int i0 = c; i0 < std::min(n0, c + kCsDppLanes); ++i0) {
-                    const int rel = tab[(size_t)(A0.sstride[0] * i0 + A0.sstride[2] * i2 + A0.sstride[3] * i3)].cell - i0;
-                    mn = std::min(mn, rel);
-                    mx = std::max(mx, rel);
-                }
-                if (mx - mn > 1) *ok = false;
+                const int e = std::min(n0, c + kCsDppLanes);
+                auto rel = [&](int i0) { return tab[(size_t)(A0.sstride[0] * i0 + A0.sstride[2] * i2 + A0.sstride[3] * i3)].cell - i0; };
+                // the common value is the one at least half of the states take (ties: the first state's, as in the kernel)
+                const int r0 = rel(c);
+                int same = 0;
+                for (int i0 = c; i0 < e; ++i0) same += rel(i0) == r0;
+                int kb = r0;
+                if (2 * same < e - c)
+                    for (int i0 = c; i0 < e; ++i0) if (rel(i0) != r0) { kb = rel(i0); break; }
+                int odd = 0;
+                for (int i0 = c; i0 < e; ++i0) odd += rel(i0) != kb;
+                if (odd > 1) *ok = false;
             }
     return HJB_OK;
 }

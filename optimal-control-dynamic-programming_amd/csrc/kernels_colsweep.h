@@ -30,9 +30,11 @@
 //
 // The two axis-0 neighbours (c0, c0 + 1) of a corner row: the L1 path (64 B per clock per CU) is what bounds this
 // kernel (profiles/r02_c4_colsweep_v1_pmc.json: TA busy 87 %), and the two loads of a pair hit the same cache lines.
-// One-load form (template DPP, chosen on the host when every wave's axis-0 cells satisfy it): a wave carries 62 states
-// + 2 halo lanes, lane L loads knot kb + L ONCE, and a state's neighbours are the values of lanes L and L + 1 - or
-// L + 1 and L + 2 where its cell sits one knot further (grid-edge clamping, uneven knots) - moved by DPP `wave_shl:1`.
+// One-load form (template DPP, chosen on the host when every wave's axis-0 cells satisfy it): a wave carries 60 states,
+// lane L loads knot kb + L ONCE, and a state's neighbours are the values of lanes L and L + 1, moved by DPP
+// `wave_shl:1` (lane 60 is the halo loader).  A wave with ONE state whose cell sits elsewhere (grid-edge clamping: half
+// of C4's waves) gives that state the spare lane pair 61, 62, so every state lane stays regular; with several, lanes
+// select between (L, L + 1) and (L + 1, L + 2).
 // (Fetching them through the LDS crossbar, ds_bpermute_b32, which takes no vector-ALU slot, was measured slower:
 // 2.90 vs 2.67 ms per stage on C4.)  Same values, same arithmetic: bit-identical to every other variant.
 #pragma once
@@ -49,7 +51,7 @@ constexpr int kCsNW = 3;        // window knots per group
 constexpr int kCsUMax = 16;     // controls
 constexpr int kCsMaxCu = kLeanMaxCu;
 constexpr int kCsFlush = 8;     // results are parked in LDS and written out every kCsFlush steps
-constexpr int kCsDppLanes = 62; // states per wave in the DPP form (+ 2 halo lanes)
+constexpr int kCsDppLanes = 60; // states per wave in the one-load form (+ a halo lane + a spare lane pair + 1)
 // The plan of one (i2, i3), 32-bit words:
 //   [0] halo violation flag | groups << 8   [1 + g] byte offset of group g's first corner row
 //   [1 + GMAX + g] bit s = slot s is used, bit 16 + s = slot s is visited after a higher-numbered control
@@ -66,7 +68,7 @@ struct DColSweep {
     int32_t npre_col;       // leading state-only cost terms that do not depend on state dim 1: summed once per column
     int32_t step_uniform;   // the remaining state-only cost terms do not depend on state dim 0 (wave-uniform per step)
     int32_t ncu;            // control-only cost terms
-    int32_t dpp;            // every wave of 62 states has axis-0 cells within one knot of a common shift: DPP form
+    int32_t dpp;            // one-load form: every wave of kCsDppLanes states shares one (cell - index) but for one state at most
     uint32_t g_bytes;       // J byte stride of the group axis
     uint32_t w_bytes;       // J byte stride of the window axis
     uint32_t s1_bytes;      // J byte stride of axis 1
@@ -83,6 +85,25 @@ struct DColSweep {
 
 __device__ __forceinline__ float lane_up(float x) {      // value of lane + 1 (lane 63 reads 0: a halo lane, never used)
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+// (value of lane + 1) - (own value): written so that the DPP move folds into the subtraction (v_sub_f32_dpp)
+__device__ __forceinline__ float lane_up_minus(float x) {
+    float d = lane_up(x) - x;
+    asm volatile("" : "+v"(d));          // stays a scalar subtraction: packed with its twin it could not take the DPP operand
+    return d;
+}
+// The running minimum over the controls, (best, best_u) <- (tot, u) if tot < best; a slot visited after a higher-numbered
+// control first takes over a TIE (take_tie).  Written out because hipcc turns the wave-uniform choice between the two
+// forms into selects and computes every compare for every slot.
+__device__ __forceinline__ void take_less(float &best, int &best_u, float tot, int u) {          // tot < best
+    asm volatile("v_cmp_lt_f32 vcc, %2, %0\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %3, vcc"
+                 : "+v"(best), "+v"(best_u) : "v"(tot), "v"(u) : "vcc");
+}
+__device__ __forceinline__ void take_tie(float best, int &best_u, float tot, int u) {      // tot == best and u < best_u
+    unsigned long long m;
+    asm volatile("v_cmp_eq_f32 %1, %2, %4\n\tv_cmp_lt_i32 vcc, %3, %0\n\ts_and_b64 vcc, vcc, %1\n\t"
+                 "v_cndmask_b32 %0, %0, %3, vcc"
+                 : "+v"(best_u), "=&s"(m) : "v"(tot), "v"(u), "v"(best) : "vcc");
 }
 // The corner-row gathers of the column loop are issued by hand and waited for by hand.  hipcc's wait insertion is
 // path-insensitive: a load that sits behind a wave-uniform guard (a column has ng <= NG groups), or any store that may
@@ -140,7 +161,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         i3 = GAX == 3 ? ig : iw;
     }
     int i0 = chunk * LANES + lane;
-    const bool valid = lane < LANES && i0 < n0;
+    bool valid = lane < LANES && i0 < n0;                   // this lane carries a state (see the one-load form below)
     if (!valid) i0 = n0 - 1;                                // halo / tail lanes: duplicate work, no store
     // ---- the plan of this column: header words in scalar registers, member slots parked in LDS ------------
     cptr<int32_t> pl = as_const<int32_t>(CS->plan) + (size_t)(i2 + n2 * i3) * kCsPlanWords;
@@ -155,22 +176,35 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     // ---- axis 0: the thread's own (cell, t) for the whole column ------------------------------------------
     uint32_t voff0;
     T t0;
-    bool dl = false;              // DPP form: this lane's cell sits one knot above the wave's common shift
-    bool mixed = false;           // ... and some lane of the wave does (wave-uniform)
     {
         const DTabled::Axis &A0 = TB->ax[0];
         const int off = A0.sstride[0] * i0 + A0.sstride[2] * i2 + A0.sstride[3] * i3;
         const int c0 = as_global<TabEntry<T>>(A0.tab)[off].cell;
         t0 = as_global<TabEntry<T>>(A0.tab)[off].t;
         if (DPP) {
-            // rel = cell - state index takes at most two adjacent values over the wave's states (verified on the host)
+            // rel = cell - state index takes at most two adjacent values over the wave's states (verified on the host).
+            // kb = the value most states share: lane L loads knot chunk start + L + kb, a state with rel == kb finds its
+            // neighbours in its own lane and the next one.
             const int rel = c0 - i0;
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
             const int r0 = __builtin_amdgcn_readfirstlane(rel);                 // lane 0 is always a state
-            const bool less = __builtin_amdgcn_ballot_w64(valid && rel < r0) != 0;
-            const int kb = less ? r0 - 1 : r0;
-            dl = valid && rel != kb;
-            mixed = __builtin_amdgcn_ballot_w64(dl) != 0;
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(valid && rel == r0);
+            int kb = r0;
+            if (2 * __builtin_popcountll(same) < __builtin_popcountll(vm))
+                kb = __builtin_amdgcn_readlane(rel, __builtin_ctzll(vm & ~same));
+            const unsigned long long ex = __builtin_amdgcn_ballot_w64(valid && rel != kb);
             int knot = chunk * LANES + lane + kb;                               // the knot this lane loads
+            if (ex != 0) {
+                // ONE odd state (a cell clamped at the grid edge, typically): it moves to the spare lane pair behind the
+                // halo lane - lane LANES + 1 takes the state and loads its cell's lower knot, lane LANES + 2 the upper one -
+                // and its old lane stays as the loader its lower neighbour needs.  Every state lane is then regular.
+                const int pe = __builtin_ctzll(ex);
+                const int c0e = __builtin_amdgcn_readlane(c0, pe);
+                const T t0e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t0), pe));
+                if (lane == pe) valid = false;
+                if (lane == LANES + 1) { i0 = chunk * LANES + pe; t0 = t0e; knot = c0e; valid = true; }
+                if (lane == LANES + 2) knot = c0e + 1;
+            }                                                                   // (the host admits no more than one)
             knot = knot < 0 ? 0 : (knot > n0 - 1 ? n0 - 1 : knot);              // clamped lanes are never referenced
             voff0 = (uint32_t)knot * (uint32_t)sizeof(TJ);
         } else {
@@ -218,15 +252,10 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     const int index_base = P->index_base;
     __builtin_amdgcn_wave_barrier();
 
-    // the axis-0 lerp of one corner row from the value(s) a lane loaded, general form
+    // the axis-0 lerp of one corner row from the value(s) a lane loaded
     auto xl = [&](T a, T b) -> T {
-        if (DPP) {                                   // a = the knot this lane loaded
-            const T k1 = lane_up(a);
-            const T k2 = lane_up(k1);
-            const T lo = dl ? k1 : a, hi = dl ? k2 : k1;
-            return fma_t<T>(t0, (T)(hi - lo), lo);
-        }
-        return fma_t<T>(t0, (T)(b - a), a);          // a, b = the lower / upper neighbour
+        if (DPP) return fma_t<T>(t0, lane_up_minus(a), a);      // a = the knot this lane loaded
+        return fma_t<T>(t0, (T)(b - a), a);                      // a, b = the lower / upper neighbour
     };
 
     // ---- the column loop ------------------------------------------------------------------------------------------
@@ -280,6 +309,9 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     static_assert(NG - (NG + 1) / 2 <= 3 && (NG + 1) / 2 <= 3, "await_groups counts up to three younger groups");
     T best, gstep, t1;
     int best_u;
+    typedef __attribute__((address_space(3))) const f4 lds_f4;
+    lds_f4 *slots = (lds_f4 *)&s_slots[wave][0];
+    asm volatile("" : "+v"(slots));          // one address register for the column, not one re-made per read
     // The arithmetic is written on PAIRS (lower, upper group row) of one window knot: v_pk_add_f32 / v_pk_fma_f32 are
     // IEEE per component, and with the pair as the unit of data no value ever has to be moved between registers.
     auto compute_groups = [&](int g0, int g1) {
@@ -291,52 +323,62 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                 int ug = used[g];
                 asm volatile("" : "+s"(ug));
                 const f2 t0p = {t0, t0}, t1p = {t1, t1};
+                // knot 1 of the window serves both pairs; knot 0 only pair 0's slots, knot 2 only pair 1's
+                const bool pair0 = (ug & ((1 << (MM / 2)) - 1)) != 0, pair1 = (ug & (((1 << (MM / 2)) - 1) << (MM / 2))) != 0;
                 f2 Bv[NW];
-                auto roll = [&](int w, f2 l, f2 h) {        // axis-0 lerp of the new row, axis-1 lerp with the previous row
-                    const f2 an = __builtin_elementwise_fma(t0p, h - l, l);
+                auto roll = [&](int w) {        // axis-0 lerp of the new row, axis-1 lerp with the previous row
+                    const f2 l = {raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
+                    f2 an;
+                    if (DPP) {                   // (value of the next lane) - (own value): one DPP subtraction each
+                        const f2 d = {lane_up_minus(l.x), lane_up_minus(l.y)};
+                        an = __builtin_elementwise_fma(t0p, d, l);
+                    } else {
+                        const f2 h = {raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])};
+                        an = __builtin_elementwise_fma(t0p, h - l, l);
+                    }
                     Bv[w] = __builtin_elementwise_fma(t1p, an - A[g][w], A[g][w]);
                     A[g][w] = an;
                 };
-                if (DPP && mixed) {            // wave-uniform: some lanes take the values one and two lanes up
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const f2 lo = {raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
-                        const f2 k1 = {lane_up(lo.x), lane_up(lo.y)};
-                        const f2 k2 = {lane_up(k1.x), lane_up(k1.y)};
-                        roll(w, dl ? k1 : lo, dl ? k2 : k1);
-                    }
-                } else {
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const f2 lo = {raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
-                        const f2 hi = DPP ? f2{lane_up(lo.x), lane_up(lo.y)}
-                                          : f2{raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])};
-                        roll(w, lo, hi);
-                    }
+                // the member-independent half of a member's first lerp:
+                //   GAX == 3 (window = axis 2 is lerped first, both group rows at once): Ew[p] = B[p + 1] - B[p]
+                //   GAX == 2 (group = axis 2 is lerped first): Dg[w] = B[w].upper - B[w].lower
+                f2 Ew[2];
+                T Dg[NW];
+                roll(1);
+                if (GAX == 2) Dg[1] = (T)(Bv[1].y - Bv[1].x);
+                if (pair0) {
+                    roll(0);
+                    if (GAX == 3) Ew[0] = Bv[1] - Bv[0];
+                    else Dg[0] = (T)(Bv[0].y - Bv[0].x);
+                }
+                if (pair1) {
+                    roll(2);
+                    if (GAX == 3) Ew[1] = Bv[2] - Bv[1];
+                    else Dg[2] = (T)(Bv[2].y - Bv[2].x);
                 }
 #pragma unroll
                 for (int s = 0; s < MM; ++s) {
                     if (ug & (1 << s)) {
                         const int off = s / (MM / 2);                // slots 0-2: window knots (0, 1); slots 3-5: (1, 2)
-                        const f4 ms = s_slots[wave][(g * MM + s) * 2];       // broadcast read of the slot's plan data
+                        const f4 ms = slots[(g * MM + s) * 2];       // broadcast read of the slot's plan data
                         const T tw = ms.x, tg = ms.y;
                         const int u = __float_as_int(ms.w);
                         T interp;
-                        if (GAX == 3) {          // window = axis 2 (lerped first, both group rows at once), group = axis 3
+                        if (GAX == 3) {
                             const f2 twp = {tw, tw};
-                            const f2 v = __builtin_elementwise_fma(twp, Bv[off + 1] - Bv[off], Bv[off]);
+                            const f2 v = __builtin_elementwise_fma(twp, Ew[off], Bv[off]);
                             interp = fma_t<T>(tg, (T)(v.y - v.x), v.x);
-                        } else {                 // group = axis 2 (lerped first, both window knots at once), window = axis 3
-                            const f2 b0 = {Bv[off].x, Bv[off + 1].x}, b1 = {Bv[off].y, Bv[off + 1].y};
-                            const f2 tgp = {tg, tg};
-                            const f2 v = __builtin_elementwise_fma(tgp, b1 - b0, b0);
-                            interp = fma_t<T>(tw, (T)(v.y - v.x), v.x);
+                        } else {
+                            T v0 = fma_t<T>(tg, Dg[off], Bv[off].x);
+                            asm volatile("" : "+v"(v0));             // two plain fmas: packed, their operands would need moving
+                            const T v1 = fma_t<T>(tg, Dg[off + 1], Bv[off + 1].x);
+                            interp = fma_t<T>(tw, (T)(v1 - v0), v0);
                         }
                         T gg;
                         if (FASTCOST) {                              // the usual shape: state terms + ONE control term
                             gg = (T)(gstep + ms.z);
                         } else {
-                            const f4 mx = s_slots[wave][(g * MM + s) * 2 + 1];
+                            const f4 mx = slots[(g * MM + s) * 2 + 1];
                             gg = gstep;
                             for (int k = 0; k < ncu; ++k) {
                                 const T x = k == 0 ? ms.z : (k == 1 ? mx.x : (k == 2 ? mx.y : mx.z));
@@ -345,12 +387,9 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                         }
                         const T tot = (T)(gg + interp);
                         // groups are not visited in control order: a slot that comes after a higher-numbered control (flag
-                        // from the plan) compares (value, control number) lexicographically, the others by value alone
-                        bool take;
-                        if (ug & (0x10000 << s)) take = (tot < best) | ((tot == best) & (u < best_u));
-                        else take = tot < best;
-                        best = take ? tot : best;
-                        best_u = take ? u : best_u;
+                        // from the plan) also wins a tie if its control number is the lower one: first index wins, exactly
+                        if (ug & (0x10000 << s)) take_tie(best, best_u, tot, u);
+                        take_less(best, best_u, tot, u);
                     }
                 }
             }
@@ -359,6 +398,10 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     int prev_c1 = -2;
     int c1n = tab1[0].cell;
     T t1n = tab1[0].t;
+    // Everything hipcc loaded for the set-up has landed before the loop starts: a value still "pending" at the loop
+    // header would make its first use INSIDE the loop a `vmcnt(0)` on every step - a drain of the gathers in flight.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" : "+v"(gcol), "+v"(t0), "+v"(voff0));
     load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // prologue: H0 of step 0
     for (int i1 = 0; i1 < n1; ++i1) {
         const int c1 = c1n;
@@ -405,8 +448,8 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                 }
             }
         }
-        best = __builtin_inff();
-        best_u = 0x7fffffff;
+        best = __builtin_inff();                 // (inf, control 0): what an all-infinite column of totals yields as well
+        best_u = 0;
         await_groups(0, NGH, ng > NGH ? ng - NGH : 0);                    // H0 landed; H1 may still be in flight
         compute_groups(0, NGH);
         load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // H0 of the next step
