@@ -29,6 +29,7 @@
 #include "kernels_rowwise.h"
 #include "kernels_tile2d.h"
 #include "kernels_colsweep.h"
+#include "kernels_colcoop.h"
 #include "kernels_probe.h"
 #include "kernels_prep_mfma.h"
 #include "kernels_reduce.h"
@@ -102,6 +103,11 @@ struct Handle {
     DColSweep *dcs = nullptr;
     int cs_xcd_mod = 0;           // option "cs_xcd_mod": 0 = automatic (see colsweep_map)
     int cs_dpp = 1;               // option "cs_dpp": allow the DPP form of variant 7 when the axis-0 cells permit it
+    int cs_rows_mid = 0;          // corner rows per step the mid-grid column needs (get_option "cs_rows")
+    int cs_xcd_axis = 0;          // option "cs_xcd_axis": 0 = the XCDs split the group axis, 1 = the window axis
+    int cs_coop = 0;              // option "cs_coop": allow the cooperative form (kernels_colcoop.h) where it applies
+    int cs_coop_epl = 0;          // ... it applies: elements per staging load (0 = does not apply)
+    int cc_grid = 0;              // its launch grid
     int variant = 0;
     int launch_status = HJB_OK;   // status of the table build inside choose_launch
     int forced_variant = -1;
@@ -733,7 +739,7 @@ int table_hash(Handle *h, uint64_t *out) {      // FNV-1a over the bytes of ever
 // variant-5 tables of axes 2 and 3 (tiny: n2 * n3 * nU entries) --------------------------------------------------
 template <typename T>
 bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2], const std::vector<std::vector<T>> &cu,
-                   std::vector<int32_t> &plan, int64_t *rows_total, int *ng_max) {
+                   std::vector<int32_t> &plan, int64_t *rows_total, int *ng_max, std::vector<int32_t> &cells) {
     static_assert(sizeof(T) == 4, "plan words are 32-bit");
     const DParams &P = h->hp;
     const int n2 = P.n[2], n3 = P.n[3], nU = (int)h->nU, wax = 5 - gax;
@@ -741,8 +747,10 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
     const int nwk = wax == 3 ? h->nplanes : P.n[wax];        // knots of the window axis present in this handle's J buffers
     if (nwk < 3) return false;
     plan.assign((size_t)n2 * n3 * kCsPlanWords, 0);
+    cells.assign((size_t)n2 * n3 * kCsGMax * 2, 0);         // (group-axis cell, first window knot) of every group
     *rows_total = 0;
     *ng_max = 1;
+    int mid_rows = 0;
     auto bits = [](T x) { int32_t b; memcpy(&b, &x, 4); return b; };
     for (int i3 = 0; i3 < n3; ++i3) {
         for (int i2 = 0; i2 < n2; ++i2) {
@@ -818,6 +826,8 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
                 const int nw = 3;
                 int usedbits = 0;
                 q[1 + g] = (int32_t)(uint32_t)off;
+                cells[((size_t)(i2 + n2 * i3) * kCsGMax + g) * 2] = G.cg;
+                cells[((size_t)(i2 + n2 * i3) * kCsGMax + g) * 2 + 1] = G.wmin;
                 if (g < ng) {
                     *rows_total += 2 * nw;
                     for (int sidx = 0; sidx < kCsMMax; ++sidx) {
@@ -834,9 +844,12 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
                     }
                 }
                 q[1 + kCsGMax + g] = usedbits | (nw << 8);
+                if (i2 == n2 / 2 && i3 == n3 / 2 && g < ng)
+                    mid_rows += 2 * (1 + ((usedbits & 7) != 0) + ((usedbits & 0x38) != 0));
             }
         }
     }
+    h->cs_rows_mid = mid_rows;
     return true;
 }
 
@@ -847,8 +860,9 @@ int colsweep_map(Handle *h, const std::vector<int32_t> &plan) {
     const DParams &P = h->hp;
     DColSweep &CSh = h->hcs;
     const int gax = CSh.gax, n2 = P.n[2], n3 = P.n[3];
-    const int ngx = P.n[gax];
-    int M = h->cs_xcd_mod;
+    CSh.xcd_win = h->cs_xcd_axis ? 1 : 0;
+    const int ngx = CSh.xcd_win ? P.n[5 - gax] : P.n[gax];          // indices of the axis the XCDs split
+    int M = CSh.xcd_win ? 1 : h->cs_xcd_mod;
     if (M == 0) M = 1;           // measured on C4 (120^4 x 9): contiguous ranges 2.67 ms per stage, residue classes of the
                                  // group spacing (cs_xcd_mod = -1) 2.84 ms
     if (M < 0) {
@@ -916,6 +930,90 @@ int colsweep_dpp_ok(Handle *h, bool *ok) {
     return HJB_OK;
 }
 
+// Cooperative form of variant 7 (kernels_colcoop.h): a workgroup = kCcW columns that are neighbours along the window
+// axis.  It applies when axis 1's cell does not depend on the window-axis index (the workgroup steps through one
+// sequence of axis-1 knots), every workgroup's columns need at most `ng` distinct group-axis cells with window knots
+// inside kCcNV staged ones, and their axis-0 cells inside kCcXW staged knots.  Fills plan word [1 + 2 GMAX + g] (the
+// group's first corner row among the staged rows) and the per-workgroup words; sets h->cs_coop_epl.
+template <typename T>
+int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_t> &cells, std::vector<int32_t> &wgw) {
+    h->cs_coop_epl = 0;
+    const DParams &P = h->hp;
+    const DColSweep &CSh = h->hcs;
+    const int gax = CSh.gax, wax = 5 - gax, n0 = P.n[0], n2 = P.n[2], n3 = P.n[3];
+    if (CSh.ng > kCcNCG) return HJB_OK;
+    if (h->dom_mask[1] & (1u << wax)) return HJB_OK;
+    const int epl = h->esz == 4 ? (n0 % 4 == 0 ? 4 : 0) : (h->esz == 2 ? (n0 % 8 == 0 ? 8 : 0) : 0);
+    if (!epl || n0 < epl) return HJB_OK;
+    const int nwk = wax == 3 ? h->nplanes : P.n[wax];
+    const int ngx = P.n[gax], nwax = P.n[wax];
+    const int chunks = (n0 + 63) / 64, nblk = (nwax + kCcW - 1) / kCcW;
+    const int rowb = kCcXW * (int)h->esz;
+    const DTabled::Axis &A0 = h->htb.ax[0];
+    std::vector<TabEntry<T>> tab0((size_t)h->dom_entries[0]);
+    HIP_TRY(h, hipMemcpy(tab0.data(), A0.tab, tab0.size() * sizeof(TabEntry<T>), hipMemcpyDeviceToHost));
+    wgw.assign((size_t)ngx * chunks * nblk * kCcWgWords, 0);
+    auto col = [&](int ig, int iw) { return gax == 3 ? (size_t)(iw + n2 * ig) : (size_t)(ig + n2 * iw); };
+    for (int ig = 0; ig < ngx; ++ig)
+        for (int blk = 0; blk < nblk; ++blk) {
+            // distinct group-axis cells of the block's columns, the window knots each needs
+            int cg[kCcNCG], vmin[kCcNCG], vmax[kCcNCG], ncg = 0;
+            for (int j = 0; j < kCcW; ++j) {
+                const int iw = std::min(blk * kCcW + j, nwax - 1);
+                const size_t c = col(ig, iw);
+                const int ng = plan[c * kCsPlanWords] >> 8;
+                for (int g = 0; g < ng; ++g) {
+                    const int cgv = cells[(c * kCsGMax + g) * 2], wm = cells[(c * kCsGMax + g) * 2 + 1];
+                    int ci = 0;
+                    while (ci < ncg && cg[ci] != cgv) ++ci;
+                    if (ci == ncg) {
+                        if (ncg == CSh.ng) return HJB_OK;
+                        cg[ncg] = cgv; vmin[ncg] = wm; vmax[ncg] = wm + 2; ++ncg;
+                    } else {
+                        vmin[ci] = std::min(vmin[ci], wm);
+                        vmax[ci] = std::max(vmax[ci], wm + 2);
+                    }
+                }
+            }
+            for (int ci = 0; ci < ncg; ++ci)
+                if (vmax[ci] - vmin[ci] + 1 > kCcNV) return HJB_OK;
+            for (int j = 0; j < kCcW; ++j) {
+                const int iw = blk * kCcW + j;
+                if (iw >= nwax) break;
+                const size_t c = col(ig, iw);
+                for (int g = 0; g < kCsGMax; ++g) {         // padded groups repeat group 0's rows, like their global offsets
+                    const int cgv = cells[(c * kCsGMax + g) * 2], wm = cells[(c * kCsGMax + g) * 2 + 1];
+                    int ci = 0;
+                    while (ci < ncg && cg[ci] != cgv) ++ci;
+                    plan[c * kCsPlanWords + 1 + 2 * kCsGMax + g] = ((ci * 2) * kCcNV + (wm - vmin[ci])) * rowb;
+                }
+            }
+            for (int chunk = 0; chunk < chunks; ++chunk) {
+                int32_t *q = &wgw[((size_t)(ig * chunks + chunk) * nblk + blk) * kCcWgWords];
+                int cmin = INT32_MAX, cmax = INT32_MIN;
+                for (int j = 0; j < kCcW; ++j) {
+                    const int iw = std::min(blk * kCcW + j, nwax - 1);
+                    const int i2 = gax == 3 ? iw : ig, i3 = gax == 3 ? ig : iw;
+                    for (int i0 = chunk * 64; i0 < std::min(n0, chunk * 64 + 64); ++i0) {
+                        const int c0 = tab0[(size_t)(A0.sstride[0] * i0 + A0.sstride[2] * i2 + A0.sstride[3] * i3)].cell;
+                        cmin = std::min(cmin, c0);
+                        cmax = std::max(cmax, c0);
+                    }
+                }
+                const int xlo = cmin / 8 * 8;
+                if (cmin < 0 || cmax + 1 - xlo > kCcXW - 1) return HJB_OK;
+                q[0] = xlo;
+                q[1] = ncg;
+                for (int ci = 0; ci < ncg; ++ci) {
+                    q[2 + ci] = (int32_t)(uint32_t)((P.jstride[gax] * (int64_t)cg[ci] + P.jstride[wax] * (int64_t)vmin[ci]) * (int64_t)h->esz);
+                    q[2 + kCcNCG + ci] = std::min(kCcNV, nwk - vmin[ci]);
+                }
+            }
+        }
+    h->cs_coop_epl = epl;
+    return HJB_OK;
+}
+
 template <typename T>
 int ensure_colsweep_t(Handle *h) {
     if (h->cs_state >= 0) return HJB_OK;
@@ -947,23 +1045,35 @@ int ensure_colsweep_t(Handle *h) {
     std::vector<int32_t> plan[2];
     int64_t rows[2] = {0, 0};
     int ngm[2] = {1, 1};
-    const bool ok3 = colsweep_plan<T>(h, 3, tab, cu, plan[1], &rows[1], &ngm[1]);
-    const bool ok2 = colsweep_plan<T>(h, 2, tab, cu, plan[0], &rows[0], &ngm[0]);
+    std::vector<int32_t> cells[2];
+    const bool ok3 = colsweep_plan<T>(h, 3, tab, cu, plan[1], &rows[1], &ngm[1], cells[1]);
+    const bool ok2 = colsweep_plan<T>(h, 2, tab, cu, plan[0], &rows[0], &ngm[0], cells[0]);
     if (!ok2 && !ok3) return HJB_OK;
     const int pick = (ok3 && (!ok2 || ngm[1] < ngm[0] || (ngm[1] == ngm[0] && rows[1] <= rows[0]))) ? 1 : 0;
     DColSweep &CSh = h->hcs;
     memset(&CSh, 0, sizeof CSh);
     CSh.gax = pick ? 3 : 2;
     CSh.ng = ngm[pick];
+    CSh.g_bytes = (uint32_t)(P.jstride[CSh.gax] * (int64_t)h->esz);
+    CSh.w_bytes = (uint32_t)(P.jstride[5 - CSh.gax] * (int64_t)h->esz);
     void *d = nullptr;
+    {
+        std::vector<int32_t> wgw;
+        st = colcoop_plan<T>(h, plan[pick], cells[pick], wgw);      // fills the plans' staged-row offsets
+        if (st) return st;
+        if (h->cs_coop_epl) {
+            st = upload(h, wgw, &d);
+            if (st) return st;
+            CSh.wg = (const int32_t *)d;
+        }
+        CSh.coop = h->cs_coop ? h->cs_coop_epl : 0;
+    }
     st = upload(h, plan[pick], &d);
     if (st) return st;
     CSh.plan = (const int32_t *)d;
     CSh.npre_col = npre_col;
     CSh.step_uniform = step_uniform ? 1 : 0;
     CSh.ncu = ncu;
-    CSh.g_bytes = (uint32_t)(P.jstride[CSh.gax] * (int64_t)h->esz);
-    CSh.w_bytes = (uint32_t)(P.jstride[5 - CSh.gax] * (int64_t)h->esz);
     CSh.s1_bytes = (uint32_t)(P.jstride[1] * (int64_t)h->esz);
     st = colsweep_map(h, plan[pick]);
     if (st) return st;
@@ -1088,8 +1198,16 @@ void choose_launch(Handle *h) {
         const int64_t chunks = (P.n[0] + lanes - 1) / lanes;
         const int64_t nwax = P.n[5 - h->hcs.gax];
         int64_t most = 0;
-        for (int x = 0; x < 8; ++x) most = std::max<int64_t>(most, (int64_t)h->hcs.xcd_cnt[x] * chunks * nwax);
+        const int64_t nfull = h->hcs.xcd_win ? P.n[h->hcs.gax] : nwax;      // the axis every XCD walks in full
+        for (int x = 0; x < 8; ++x) most = std::max<int64_t>(most, (int64_t)h->hcs.xcd_cnt[x] * chunks * nfull);
         h->grid = (int)(8 * ((most + 3) / 4));
+        h->cc_grid = 0;
+        if (h->hcs.coop && !h->hcs.xcd_win) {       // cooperative form: one workgroup of kCcW waves per (group-axis index, 64-state chunk, kCcW columns)
+            const int64_t c64 = (P.n[0] + 63) / 64, nblk = (nwax + kCcW - 1) / kCcW;
+            int64_t mostc = 0;
+            for (int x = 0; x < 8; ++x) mostc = std::max<int64_t>(mostc, (int64_t)h->hcs.xcd_cnt[x] * c64 * nblk);
+            h->cc_grid = (int)(8 * mostc);
+        }
     }
     if (h->grid < 1) h->grid = 1;
 }
@@ -1114,6 +1232,28 @@ int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t
         break;
             const bool fastcost = h->hcs.ncu == 1 && h->hp.n_cost_prefix > 0;    // state terms + one control term
             const bool dppf = h->hcs.dpp != 0;
+            // cooperative form: its staging loads are 16 bytes wide (a J pointer handed in unaligned runs the other form)
+            if (h->hcs.coop && h->cc_grid > 0 && h->hcs.ng <= kCcNCG && ((uintptr_t)dJn & 15u) == 0) {
+                constexpr int EPL = 16 / (int)sizeof(TJ);
+                dim3 gc(h->cc_grid), bc(kCcW * 64);
+#define HJB_LAUNCH_CC2(NG, FC)                                                                                         \
+    do {                                                                                                               \
+        if (h->hcs.gax == 3) hipLaunchKernelGGL((k_backup_colcoop<T, TJ, 3, NG, FC, EPL>), gc, bc, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
+        else hipLaunchKernelGGL((k_backup_colcoop<T, TJ, 2, NG, FC, EPL>), gc, bc, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
+    } while (0)
+#define HJB_LAUNCH_CC(NG)                                                                                              \
+    case NG:                                                                                                           \
+        if (fastcost) HJB_LAUNCH_CC2(NG, true); else HJB_LAUNCH_CC2(NG, false);                                        \
+        break;
+                switch (h->hcs.ng) {
+                    HJB_LAUNCH_CC(1) HJB_LAUNCH_CC(2) HJB_LAUNCH_CC(3) HJB_LAUNCH_CC(4) HJB_LAUNCH_CC(5)
+                    default: return fail(h, HJB_E_DEVICE, "variant 7: %d groups", h->hcs.ng);
+                }
+#undef HJB_LAUNCH_CC2
+#undef HJB_LAUNCH_CC
+                HIP_TRY(h, hipGetLastError());
+                return HJB_OK;
+            }
             switch (h->hcs.ng) {
                 HJB_LAUNCH_CS(1) HJB_LAUNCH_CS(2) HJB_LAUNCH_CS(3) HJB_LAUNCH_CS(4) HJB_LAUNCH_CS(5) HJB_LAUNCH_CS(6)
                 default: return fail(h, HJB_E_DEVICE, "variant 7: %d groups", h->hcs.ng);
@@ -1613,6 +1753,28 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         }
         return HJB_OK;
     }
+    if (!strcmp(key, "cs_coop")) {                                   // 0: variant 7 runs one wave per column (testing)
+        h->cs_coop = value != 0;
+        if (h->cs_state == 1) {
+            h->hcs.coop = h->cs_coop ? h->cs_coop_epl : 0;
+            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            choose_launch(h);
+        }
+        return HJB_OK;
+    }
+    if (!strcmp(key, "cs_xcd_axis")) {     // variant 7: which axis the XCDs split (0 = group axis, 1 = window axis)
+        if (value < 0 || value > 1) return fail(h, HJB_E_INVALID, "%s out of range", key);
+        h->cs_xcd_axis = (int)value;
+        if (h->cs_state == 1) {
+            std::vector<int32_t> plan((size_t)h->hp.n[2] * h->hp.n[3] * kCsPlanWords);
+            HIP_TRY(h, hipMemcpy(plan.data(), h->hcs.plan, plan.size() * 4, hipMemcpyDeviceToHost));
+            const int cst = colsweep_map(h, plan);
+            if (cst) return cst;
+            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            choose_launch(h);
+        }
+        return HJB_OK;
+    }
     if (!strcmp(key, "cs_xcd_mod")) {      // variant 7: residue modulus of the column -> XCD assignment (0 = automatic)
         if (value < -1 || value > 4096) return fail(h, HJB_E_INVALID, "%s out of range", key);
         h->cs_xcd_mod = (int)value;
@@ -1658,6 +1820,8 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "row_lean")) *value = h->row_lean ? 1 : 0;
     else if (!strcmp(key, "lds_pad")) *value = (int64_t)h->lds_pad;
     else if (!strcmp(key, "cs_xcd_mod")) *value = h->cs_xcd_mod;
+    else if (!strcmp(key, "cs_xcd_axis")) *value = h->cs_xcd_axis;
+    else if (!strcmp(key, "cs_rows")) *value = h->variant == 7 ? h->cs_rows_mid : 0;
     else if (!strcmp(key, "prep_mfma")) *value = h->prep_mfma;
     else if (!strcmp(key, "prep_mfma_tables")) *value = h->prep_mfma_axes;
     else if (!strcmp(key, "prep_tables")) *value = (int64_t)h->preps.size();
@@ -1671,6 +1835,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
         *value = (int64_t)(hv & 0x7fffffffffffffffull);
     }
     else if (!strcmp(key, "cs_dpp")) *value = (h->variant == 7 && h->hcs.dpp) ? 1 : 0;          // the form in effect
+    else if (!strcmp(key, "cs_coop")) *value = (h->variant == 7 && h->hcs.coop && h->cc_grid > 0) ? 1 : 0;   // the form in effect
     else if (!strcmp(key, "cs_groups")) *value = h->variant == 7 ? h->hcs.ng : 0;
     else if (!strcmp(key, "cs_group_axis")) *value = h->variant == 7 ? h->hcs.gax : -1;
     else return fail(h, HJB_E_INVALID, "unknown option '%s'", key);

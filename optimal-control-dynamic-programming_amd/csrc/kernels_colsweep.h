@@ -56,10 +56,11 @@ constexpr int kCsDppLanes = 60; // states per wave in the one-load form (+ a hal
 //   [0] halo violation flag | groups << 8   [1 + g] byte offset of group g's first corner row
 //   [1 + GMAX + g] bit s = slot s is used, bit 16 + s = slot s is visited after a higher-numbered control
 //   [kCsPI + 8 s ...] member slot s' = g * MMAX + s: t_window, t_group, cu[0], control number, cu[1..3], 0
-constexpr int kCsPI = 16;
+//   [1 + 2 GMAX + g] cooperative form (kernels_colcoop.h): byte offset of group g's first corner row in the staged rows
+constexpr int kCsPI = 24;
 constexpr int kCsSlots = kCsGMax * kCsMMax;
 constexpr int kCsPlanWords = kCsPI + 8 * kCsSlots;
-static_assert(1 + 2 * kCsGMax <= kCsPI, "plan header");
+static_assert(1 + 3 * kCsGMax <= kCsPI && kCsPI % 4 == 0, "plan header; the slots are read as 16-byte vectors");
 
 struct DColSweep {
     const int32_t *plan;
@@ -80,7 +81,9 @@ struct DColSweep {
     const int32_t *xcd_ig;  // [8][xcd_stride]
     int32_t xcd_cnt[8];
     int32_t xcd_stride;
-    int32_t pad;
+    int32_t xcd_win;        // the XCDs split the WINDOW axis instead (xcd_ig then lists window-axis indices)
+    int32_t coop;           // cooperative form (kernels_colcoop.h): 0 = off, else elements per staging load (1, 4, 8)
+    const int32_t *wg;      // its per-workgroup words, [(ig * chunks + chunk) * blocks + block][kCcWgWords]
 };
 
 __device__ __forceinline__ float lane_up(float x) {      // value of lane + 1 (lane 63 reads 0: a halo lane, never used)
@@ -129,6 +132,84 @@ template <typename T, typename TJ> __device__ __forceinline__ T raw_to(uint32_t 
     return (T)__builtin_bit_cast(_Float16, (unsigned short)r);
 }
 
+// One group of one step, shared by the column-sweep kernels: roll the group's three window knots (the axis-1 lerp of the
+// new corner rows with the previous ones), then visit its member slots.  row0(w) returns, for window knot w, the
+// (lower, upper group row) pair of axis-0 lerps of the new corner rows - each kernel gets at the neighbours its own way.
+typedef float cs_f4 __attribute__((ext_vector_type(4)));
+typedef float cs_f2 __attribute__((ext_vector_type(2)));
+template <typename T, int GAX, bool FASTCOST, typename FA, typename SP>
+__device__ __forceinline__ void cs_group(int ug, int g, FA row0, cs_f2 (&Ag)[kCsNW], T t1, SP slots, T gstep, int ncu, int npre,
+                                         T &best, int &best_u) {
+    typedef cs_f2 f2;
+    typedef cs_f4 f4;
+    constexpr int NW = kCsNW, MM = kCsMMax;
+    // the slot bits as a value of THIS block: tested with s_bitcmp; hoisted out of the loop each test would become a
+    // 64-bit lane mask held in two scalar registers for the whole column
+    asm volatile("" : "+s"(ug));
+    const f2 t1p = {t1, t1};
+    // knot 1 of the window serves both pairs; knot 0 only pair 0's slots, knot 2 only pair 1's
+    const bool pair0 = (ug & ((1 << (MM / 2)) - 1)) != 0, pair1 = (ug & (((1 << (MM / 2)) - 1) << (MM / 2))) != 0;
+    f2 Bv[NW];
+    auto roll = [&](int w) {
+        const f2 an = row0(w);
+        Bv[w] = __builtin_elementwise_fma(t1p, an - Ag[w], Ag[w]);
+        Ag[w] = an;
+    };
+    // the member-independent half of a member's first lerp:
+    //   GAX == 3 (window = axis 2 is lerped first, both group rows at once): Ew[p] = B[p + 1] - B[p]
+    //   GAX == 2 (group = axis 2 is lerped first): Dg[w] = B[w].upper - B[w].lower
+    f2 Ew[2];
+    T Dg[NW];
+    roll(1);
+    if (GAX == 2) Dg[1] = (T)(Bv[1].y - Bv[1].x);
+    if (pair0) {
+        roll(0);
+        if (GAX == 3) Ew[0] = Bv[1] - Bv[0];
+        else Dg[0] = (T)(Bv[0].y - Bv[0].x);
+    }
+    if (pair1) {
+        roll(2);
+        if (GAX == 3) Ew[1] = Bv[2] - Bv[1];
+        else Dg[2] = (T)(Bv[2].y - Bv[2].x);
+    }
+#pragma unroll
+    for (int s = 0; s < MM; ++s) {
+        if (ug & (1 << s)) {
+            const int off = s / (MM / 2);                // slots 0-2: window knots (0, 1); slots 3-5: (1, 2)
+            const f4 ms = slots[(g * MM + s) * 2];       // broadcast read of the slot's plan data
+            const T tw = ms.x, tg = ms.y;
+            const int u = __float_as_int(ms.w);
+            T interp;
+            if (GAX == 3) {
+                const f2 twp = {tw, tw};
+                const f2 v = __builtin_elementwise_fma(twp, Ew[off], Bv[off]);
+                interp = fma_t<T>(tg, (T)(v.y - v.x), v.x);
+            } else {
+                T v0 = fma_t<T>(tg, Dg[off], Bv[off].x);
+                asm volatile("" : "+v"(v0));             // two plain fmas: packed, their operands would need moving
+                const T v1 = fma_t<T>(tg, Dg[off + 1], Bv[off + 1].x);
+                interp = fma_t<T>(tw, (T)(v1 - v0), v0);
+            }
+            T gg;
+            if (FASTCOST) {                              // the usual shape: state terms + ONE control term
+                gg = (T)(gstep + ms.z);
+            } else {
+                const f4 mx = slots[(g * MM + s) * 2 + 1];
+                gg = gstep;
+                for (int k = 0; k < ncu; ++k) {
+                    const T x = k == 0 ? ms.z : (k == 1 ? mx.x : (k == 2 ? mx.y : mx.z));
+                    gg = (npre == 0 && k == 0) ? x : (T)(gg + x);
+                }
+            }
+            const T tot = (T)(gg + interp);
+            // groups are not visited in control order: a slot that comes after a higher-numbered control (flag from the
+            // plan) also wins a tie if its control number is the lower one: first index wins, exactly
+            if (ug & (0x10000 << s)) take_tie(best, best_u, tot, u);
+            take_less(best, best_u, tot, u);
+        }
+    }
+}
+
 // Five waves per SIMD (<= 96 VGPRs) for the one-load form with up to five groups - the C4 / C5 kernel, which the
 // register allocator otherwise leaves at 98; the wider forms take what they need.
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP>
@@ -151,12 +232,21 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     {
         const unsigned xcd = blockIdx.x & 7u, item = (blockIdx.x >> 3) * 4u + (unsigned)wave;
         const unsigned cnt = (unsigned)CS->xcd_cnt[xcd];
-        const unsigned nwax = (unsigned)(GAX == 3 ? n2 : n3);                 // columns along the window axis
-        if (item >= cnt * (unsigned)chunks * nwax) return;                    // uniform over the wave
-        const unsigned r = item / cnt;
-        const int ig = as_const<int32_t>(CS->xcd_ig)[xcd * (unsigned)CS->xcd_stride + item % cnt];
-        chunk = (int)(r % (unsigned)chunks);
-        const int iw = (int)(r / (unsigned)chunks);
+        const unsigned nfull = (unsigned)((GAX == 3) != (CS->xcd_win != 0) ? n2 : n3);   // the axis every XCD walks in full
+        if (item >= cnt * (unsigned)chunks * nfull) return;                   // uniform over the wave
+        int ig, iw;
+        if (CS->xcd_win) {               // the XCD owns window-axis indices: the group axis is walked in full, fastest
+            const unsigned ngx = (unsigned)(GAX == 3 ? n3 : n2);
+            ig = (int)(item % ngx);
+            const unsigned r = item / ngx;
+            chunk = (int)(r % (unsigned)chunks);
+            iw = as_const<int32_t>(CS->xcd_ig)[xcd * (unsigned)CS->xcd_stride + r / (unsigned)chunks];
+        } else {
+            const unsigned r = item / cnt;
+            ig = as_const<int32_t>(CS->xcd_ig)[xcd * (unsigned)CS->xcd_stride + item % cnt];
+            chunk = (int)(r % (unsigned)chunks);
+            iw = (int)(r / (unsigned)chunks);
+        }
         i2 = GAX == 3 ? iw : ig;
         i3 = GAX == 3 ? ig : iw;
     }
@@ -270,9 +360,19 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int w = 0; w < NW; ++w) A[g][w] = f2{(T)0, (T)0};
-    constexpr int LPG = DPP ? 6 : 12;                        // gathers per group
+    constexpr int LPK = DPP ? 2 : 4;                         // gathers per window knot of a group
     int ngs = ng;                                            // the group count as a value of the current step (below)
     uint32_t rlo[NG][2][NW], rhi[NG][2][NW];
+    // Window knot 1 serves both slot pairs of a group, knot 0 only pair 0's slots, knot 2 only pair 1's: a knot no slot
+    // uses is neither gathered nor lerped.  How many gathers each half issues is therefore a property of the column.
+    const int pairmask = (1 << (MM / 2)) - 1;
+    int nH0 = 0, nH1 = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        if (g < ng) {
+            const int n = LPK * (1 + ((used[g] & pairmask) != 0) + ((used[g] & (pairmask << (MM / 2))) != 0));
+            if (g < NGH) nH0 += n; else nH1 += n;
+        }
     auto load_groups = [&](int g0, int g1, uint32_t vrow) {
         uint32_t vb[NW];
 #pragma unroll
@@ -280,8 +380,12 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
             if (g < ngs) {
+                int ug = used[g];
+                asm volatile("" : "+s"(ug));                 // tested here, per step (see cs_group)
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
+                    if (w == 0 && !(ug & pairmask)) continue;
+                    if (w == 2 && !(ug & (pairmask << (MM / 2)))) continue;
                     const uint32_t o = vb[w] + rog[g];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
@@ -292,13 +396,19 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
             }
         }
     };
-    // wait until at most `younger` groups' gathers are outstanding, then release groups [g0, g1) to the arithmetic
+    // wait until at most `younger` gathers (a multiple of LPK) are outstanding, then release groups [g0, g1) to the arithmetic
     auto await_groups = [&](int g0, int g1, int younger) {
-        switch (younger) {
+        switch (younger / LPK) {
             case 0: wait_gathers<0>(); break;
-            case 1: wait_gathers<LPG>(); break;
-            case 2: wait_gathers<2 * LPG>(); break;
-            default: wait_gathers<3 * LPG>(); break;
+            case 1: wait_gathers<1 * LPK>(); break;
+            case 2: wait_gathers<2 * LPK>(); break;
+            case 3: wait_gathers<3 * LPK>(); break;
+            case 4: wait_gathers<4 * LPK>(); break;
+            case 5: wait_gathers<5 * LPK>(); break;
+            case 6: wait_gathers<6 * LPK>(); break;
+            case 7: wait_gathers<7 * LPK>(); break;
+            case 8: wait_gathers<8 * LPK>(); break;
+            default: wait_gathers<9 * LPK>(); break;
         }
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
@@ -306,92 +416,26 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
             if (!DPP) tie6(rhi[g]);
         }
     };
-    static_assert(NG - (NG + 1) / 2 <= 3 && (NG + 1) / 2 <= 3, "await_groups counts up to three younger groups");
+    static_assert(NG - (NG + 1) / 2 <= 3 && (NG + 1) / 2 <= 3, "await_groups counts up to nine younger window knots");
     T best, gstep, t1;
     int best_u;
     typedef __attribute__((address_space(3))) const f4 lds_f4;
     lds_f4 *slots = (lds_f4 *)&s_slots[wave][0];
     asm volatile("" : "+v"(slots));          // one address register for the column, not one re-made per read
-    // The arithmetic is written on PAIRS (lower, upper group row) of one window knot: v_pk_add_f32 / v_pk_fma_f32 are
-    // IEEE per component, and with the pair as the unit of data no value ever has to be moved between registers.
+    // The arithmetic (cs_group) is written on PAIRS (lower, upper group row) of one window knot: v_pk_add_f32 /
+    // v_pk_fma_f32 are IEEE per component, and with the pair as the unit of data no value has to be moved between registers.
     auto compute_groups = [&](int g0, int g1) {
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
             if (g < ngs) {
-                // the slot bits as a value of THIS block: tested with s_bitcmp; hoisted out of the loop each test would
-                // become a 64-bit lane mask held in two scalar registers for the whole column
-                int ug = used[g];
-                asm volatile("" : "+s"(ug));
-                const f2 t0p = {t0, t0}, t1p = {t1, t1};
-                // knot 1 of the window serves both pairs; knot 0 only pair 0's slots, knot 2 only pair 1's
-                const bool pair0 = (ug & ((1 << (MM / 2)) - 1)) != 0, pair1 = (ug & (((1 << (MM / 2)) - 1) << (MM / 2))) != 0;
-                f2 Bv[NW];
-                auto roll = [&](int w) {        // axis-0 lerp of the new row, axis-1 lerp with the previous row
+                const f2 t0p = {t0, t0};
+                auto row0 = [&](int w) {
                     const f2 l = {raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
-                    f2 an;
-                    if (DPP) {                   // (value of the next lane) - (own value): one DPP subtraction each
-                        const f2 d = {lane_up_minus(l.x), lane_up_minus(l.y)};
-                        an = __builtin_elementwise_fma(t0p, d, l);
-                    } else {
-                        const f2 h = {raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])};
-                        an = __builtin_elementwise_fma(t0p, h - l, l);
-                    }
-                    Bv[w] = __builtin_elementwise_fma(t1p, an - A[g][w], A[g][w]);
-                    A[g][w] = an;
+                    const f2 d = DPP ? f2{lane_up_minus(l.x), lane_up_minus(l.y)}      // (next lane) - (own): one DPP subtraction each
+                                     : f2{raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])} - l;
+                    return __builtin_elementwise_fma(t0p, d, l);
                 };
-                // the member-independent half of a member's first lerp:
-                //   GAX == 3 (window = axis 2 is lerped first, both group rows at once): Ew[p] = B[p + 1] - B[p]
-                //   GAX == 2 (group = axis 2 is lerped first): Dg[w] = B[w].upper - B[w].lower
-                f2 Ew[2];
-                T Dg[NW];
-                roll(1);
-                if (GAX == 2) Dg[1] = (T)(Bv[1].y - Bv[1].x);
-                if (pair0) {
-                    roll(0);
-                    if (GAX == 3) Ew[0] = Bv[1] - Bv[0];
-                    else Dg[0] = (T)(Bv[0].y - Bv[0].x);
-                }
-                if (pair1) {
-                    roll(2);
-                    if (GAX == 3) Ew[1] = Bv[2] - Bv[1];
-                    else Dg[2] = (T)(Bv[2].y - Bv[2].x);
-                }
-#pragma unroll
-                for (int s = 0; s < MM; ++s) {
-                    if (ug & (1 << s)) {
-                        const int off = s / (MM / 2);                // slots 0-2: window knots (0, 1); slots 3-5: (1, 2)
-                        const f4 ms = slots[(g * MM + s) * 2];       // broadcast read of the slot's plan data
-                        const T tw = ms.x, tg = ms.y;
-                        const int u = __float_as_int(ms.w);
-                        T interp;
-                        if (GAX == 3) {
-                            const f2 twp = {tw, tw};
-                            const f2 v = __builtin_elementwise_fma(twp, Ew[off], Bv[off]);
-                            interp = fma_t<T>(tg, (T)(v.y - v.x), v.x);
-                        } else {
-                            T v0 = fma_t<T>(tg, Dg[off], Bv[off].x);
-                            asm volatile("" : "+v"(v0));             // two plain fmas: packed, their operands would need moving
-                            const T v1 = fma_t<T>(tg, Dg[off + 1], Bv[off + 1].x);
-                            interp = fma_t<T>(tw, (T)(v1 - v0), v0);
-                        }
-                        T gg;
-                        if (FASTCOST) {                              // the usual shape: state terms + ONE control term
-                            gg = (T)(gstep + ms.z);
-                        } else {
-                            const f4 mx = slots[(g * MM + s) * 2 + 1];
-                            gg = gstep;
-                            for (int k = 0; k < ncu; ++k) {
-                                const T x = k == 0 ? ms.z : (k == 1 ? mx.x : (k == 2 ? mx.y : mx.z));
-                                gg = (npre == 0 && k == 0) ? x : (T)(gg + x);
-                            }
-                        }
-                        const T tot = (T)(gg + interp);
-                        // groups are not visited in control order: a slot that comes after a higher-numbered control (flag
-                        // from the plan) also wins a tie if its control number is the lower one: first index wins, exactly
-                        if (ug & (0x10000 << s)) take_tie(best, best_u, tot, u);
-                        take_less(best, best_u, tot, u);
-                    }
-                }
+                cs_group<T, GAX, FASTCOST>(used[g], g, row0, A[g], t1, slots, gstep, ncu, npre, best, best_u);
             }
         }
     };
@@ -404,6 +448,10 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     asm volatile("" : "+v"(gcol), "+v"(t0), "+v"(voff0));
     load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // prologue: H0 of step 0
     for (int i1 = 0; i1 < n1; ++i1) {
+        // The four waves of the workgroup (neighbours along the group axis: half their corner rows are the same) take every
+        // step together, so that what one of them misses in L1 the others find there: 2.31 -> 2.26 ms per stage on C4.
+        // (A wave that has left - no column - does not count for the barrier.)
+        __builtin_amdgcn_s_barrier();
         const int c1 = c1n;
         t1 = t1n;
         ngs = ng;
@@ -450,10 +498,10 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         }
         best = __builtin_inff();                 // (inf, control 0): what an all-infinite column of totals yields as well
         best_u = 0;
-        await_groups(0, NGH, ng > NGH ? ng - NGH : 0);                    // H0 landed; H1 may still be in flight
+        await_groups(0, NGH, nH1);                                        // H0 landed; H1 may still be in flight
         compute_groups(0, NGH);
         load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // H0 of the next step
-        await_groups(NGH, NG, ng < NGH ? ng : NGH);                       // H1 landed; the next H0 in flight
+        await_groups(NGH, NG, nH0);                                       // H1 landed; the next H0 in flight
         compute_groups(NGH, NG);
         // ---- results: parked in LDS, written out every kCsFlush steps ------------------------------------
         const int slot = i1 % kCsFlush;

@@ -1,7 +1,7 @@
 """Time one pos-att channel (Solver_pos_att) per stage kernel variant.
 usage: python tools/time_posatt.py [n=0 (reference grid 30,30,20,15) | n (n^4 grid)] [stages] [variants...]
 env: ORDER=0,2,1,3 relabels the state axes (new axis i = old axis ORDER[i]; old = x,v,theta,w), F16=1 stores J as
-float16, CS_XCD_MOD=m sets the residue modulus of variant 7's column -> XCD assignment, CS_DPP=0 its two-loads form."""
+float16, CS_XCD_MOD=m sets the residue modulus of variant 7's column -> XCD assignment, CS_DPP=0 its two-loads form, CS_COOP=0 its one-wave-per-column form."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
@@ -15,6 +15,9 @@ pa = hjbdp.Solver_pos_att()
 pa.cost_mode = "terms"
 if n:
     pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = n
+for k in ("x", "v", "t", "w"):          # N_X / N_V / N_T / N_W override one axis
+    if os.environ.get("N_" + k.upper()):
+        setattr(pa, "n_mesh_" + k, int(os.environ["N_" + k.upper()]))
 sx, sv, st, sw = pa.grids()
 spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1,
                                 pa.Qw1, pa.R1, pa.J2)
@@ -36,9 +39,13 @@ for v in variants:
                 bk.set_option("cs_xcd_mod", int(os.environ["CS_XCD_MOD"]))
             if os.environ.get("CS_DPP"):
                 bk.set_option("cs_dpp", int(os.environ["CS_DPP"]))
+            if os.environ.get("CS_XCD_AXIS"):
+                bk.set_option("cs_xcd_axis", int(os.environ["CS_XCD_AXIS"]))
+            if os.environ.get("CS_COOP"):
+                bk.set_option("cs_coop", int(os.environ["CS_COOP"]))
             info = bk.info()
             if info["kernel_variant"] == 7:
-                print("variant 7: group axis %d, %d groups, dpp %d" % (bk.get_option("cs_group_axis"), bk.get_option("cs_groups"), bk.get_option("cs_dpp")))
+                print("variant 7: group axis %d, %d groups, dpp %d, coop %d, rows %d" % (bk.get_option("cs_group_axis"), bk.get_option("cs_groups"), bk.get_option("cs_dpp"), bk.get_option("cs_coop"), bk.get_option("cs_rows")))
             bk.solve(2)
             out = bk.solve(stages)
     except hjbdp.HjbError as e:
