@@ -106,6 +106,7 @@ struct Handle {
     int cs_rows_mid = 0;          // corner rows per step the mid-grid column needs (get_option "cs_rows")
     int cs_xcd_axis = 0;          // option "cs_xcd_axis": 0 = the XCDs split the group axis, 1 = the window axis
     int cs_coop = 0;              // option "cs_coop": allow the cooperative form (kernels_colcoop.h) where it applies
+    int cs_coop_why = 0;          // why it does not: 1 groups, 2 axis 1 sees the window axis, 3 n0 / storage, 4 cells, 5 window knots, 6 axis-0 knots
     int cs_coop_epl = 0;          // ... it applies: elements per staging load (0 = does not apply)
     int cc_grid = 0;              // its launch grid
     int variant = 0;
@@ -941,14 +942,18 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
     const DParams &P = h->hp;
     const DColSweep &CSh = h->hcs;
     const int gax = CSh.gax, wax = 5 - gax, n0 = P.n[0], n2 = P.n[2], n3 = P.n[3];
+    h->cs_coop_why = 1;
     if (CSh.ng > kCcNCG) return HJB_OK;
+    h->cs_coop_why = 2;
     if (h->dom_mask[1] & (1u << wax)) return HJB_OK;
+    h->cs_coop_why = 3;
     const int epl = h->esz == 4 ? (n0 % 4 == 0 ? 4 : 0) : (h->esz == 2 ? (n0 % 8 == 0 ? 8 : 0) : 0);
     if (!epl || n0 < epl) return HJB_OK;
     const int nwk = wax == 3 ? h->nplanes : P.n[wax];
     const int ngx = P.n[gax], nwax = P.n[wax];
     const int chunks = (n0 + 63) / 64, nblk = (nwax + kCcW - 1) / kCcW;
-    const int rowb = kCcXW * (int)h->esz;
+    const int xw = h->esz == 2 ? kCcXWh : kCcXW;
+    const int rowb = xw * (int)h->esz;
     const DTabled::Axis &A0 = h->htb.ax[0];
     std::vector<TabEntry<T>> tab0((size_t)h->dom_entries[0]);
     HIP_TRY(h, hipMemcpy(tab0.data(), A0.tab, tab0.size() * sizeof(TabEntry<T>), hipMemcpyDeviceToHost));
@@ -967,7 +972,7 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
                     int ci = 0;
                     while (ci < ncg && cg[ci] != cgv) ++ci;
                     if (ci == ncg) {
-                        if (ncg == CSh.ng) return HJB_OK;
+                        if (ncg == CSh.ng) { h->cs_coop_why = 4; return HJB_OK; }
                         cg[ncg] = cgv; vmin[ncg] = wm; vmax[ncg] = wm + 2; ++ncg;
                     } else {
                         vmin[ci] = std::min(vmin[ci], wm);
@@ -976,7 +981,7 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
                 }
             }
             for (int ci = 0; ci < ncg; ++ci)
-                if (vmax[ci] - vmin[ci] + 1 > kCcNV) return HJB_OK;
+                if (vmax[ci] - vmin[ci] + 1 > kCcNV) { h->cs_coop_why = 5; return HJB_OK; }
             for (int j = 0; j < kCcW; ++j) {
                 const int iw = blk * kCcW + j;
                 if (iw >= nwax) break;
@@ -1000,8 +1005,8 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
                         cmax = std::max(cmax, c0);
                     }
                 }
-                const int xlo = cmin / 8 * 8;
-                if (cmin < 0 || cmax + 1 - xlo > kCcXW - 1) return HJB_OK;
+                const int xlo = cmin / epl * epl;
+                if (cmin < 0 || cmax + 1 - xlo > xw - 1) { h->cs_coop_why = 6; return HJB_OK; }
                 q[0] = xlo;
                 q[1] = ncg;
                 for (int ci = 0; ci < ncg; ++ci) {
@@ -1010,6 +1015,7 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
                 }
             }
         }
+    h->cs_coop_why = 0;
     h->cs_coop_epl = epl;
     return HJB_OK;
 }
@@ -1821,6 +1827,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "lds_pad")) *value = (int64_t)h->lds_pad;
     else if (!strcmp(key, "cs_xcd_mod")) *value = h->cs_xcd_mod;
     else if (!strcmp(key, "cs_xcd_axis")) *value = h->cs_xcd_axis;
+    else if (!strcmp(key, "cs_coop_why")) *value = h->cs_coop_why;
     else if (!strcmp(key, "cs_rows")) *value = h->variant == 7 ? h->cs_rows_mid : 0;
     else if (!strcmp(key, "prep_mfma")) *value = h->prep_mfma;
     else if (!strcmp(key, "prep_mfma_tables")) *value = h->prep_mfma_axes;

@@ -22,15 +22,13 @@
 // every workgroup's columns must fit the staged ranges, n0 must be a multiple of the staging load width.
 #pragma once
 #include "kernels_colsweep.h"
-#ifndef HJB_CC_EXPERIMENT
-#define HJB_CC_EXPERIMENT 0
-#endif
 
 namespace hjb {
 
 constexpr int kCcW = 8;                 // columns (waves) per workgroup
 constexpr int kCcNV = kCcW + 3;         // window knots staged per group-axis cell
-constexpr int kCcXW = 72;               // axis-0 knots staged per row
+constexpr int kCcXW = 72;               // axis-0 knots staged per row: 64 states' cells + the upper neighbour, the spread of the
+constexpr int kCcXWh = 80;              // columns' shifts and the alignment of the first one to a staging load (float16: 8 knots)
 constexpr int kCcNCG = 5;               // group-axis cells per workgroup (= the largest NG this form is built for)
 // Per-workgroup words: [0] first staged axis-0 knot  [1] group-axis cells in use
 //   [2 + c] byte offset (in J, at axis-1 knot 0) of cell c's lower group row at its first staged window knot
@@ -44,7 +42,7 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
                  const TJ *__restrict__ Jn, TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");
     static_assert(NG <= kCcNCG, "staged group-axis cells");
-    constexpr int D = 4, NW = kCsNW, MM = kCsMMax, W = kCcW, NV = kCcNV, XW = kCcXW;
+    constexpr int D = 4, NW = kCsNW, MM = kCsMMax, W = kCcW, NV = kCcNV, XW = sizeof(TJ) == 2 ? kCcXWh : kCcXW;
     constexpr int ESZ = (int)sizeof(TJ);
     constexpr int ROWB = XW * ESZ;                          // bytes of a staged row
     constexpr int KB = NV * ROWB;                           // lower -> upper group row of a cell
@@ -225,9 +223,7 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
             __syncthreads();
         }
         prev_c1 = c1;
-#if HJB_CC_EXPERIMENT != 1 && HJB_CC_EXPERIMENT != 4 && HJB_CC_EXPERIMENT != 5 && HJB_CC_EXPERIMENT != 11
         stage_load(c1n + 1);                                  // the rows of the next step: a whole step to land
-#endif
         if (i1 > 0 && valid) {                                // the previous step's results
             stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)(i1 - 1)), best);
             if (idx_out) idx_out[idx_col + (uint32_t)n0 * (uint32_t)(i1 - 1)] = best_u + index_base;
@@ -256,10 +252,6 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
         TJ cv[2][2][NW][2];                                   // [buffer][group row][window knot][lower, upper neighbour]
         auto read_group = [&](int g, int q) {
             const uint32_t ga = lanebase + (lrow[g] + (uint32_t)(b * SB));
-#if HJB_CC_EXPERIMENT == 5
-            for (int w = 0; w < NW; ++w) for (int k = 0; k < 2; ++k) { cv[q][k][w][0] = (TJ)__uint_as_float(ga + w); cv[q][k][w][1] = (TJ)__uint_as_float(ga + k); }
-            return;
-#endif
 #pragma unroll
             for (int w = 0; w < NW; ++w)
 #pragma unroll
@@ -270,7 +262,7 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
         };
         read_group(0, 0);                                     // every column has a group 0
 #pragma unroll
-        for (int g = 0; g < (HJB_CC_EXPERIMENT == 2 ? 1 : NG); ++g) {
+        for (int g = 0; g < NG; ++g) {
             if (g < ngs) {
                 if (g + 1 < NG) read_group(g + 1, (g + 1) & 1);     // unconditionally (a padded group repeats group 0's rows): the
                                                                     // waits for group g then count exactly the younger reads
@@ -286,14 +278,8 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
                 cs_group<T, GAX, FASTCOST>(used[g], g, row0, A[g], t1, slots, gstep, ncu, npre, best, best_u);
             }
         }
-#if HJB_CC_EXPERIMENT == 10
-        for (int q = 0; q < NQ; ++q) asm volatile("" : : "v"(R4[q]));
-#elif HJB_CC_EXPERIMENT != 1 && HJB_CC_EXPERIMENT != 4 && HJB_CC_EXPERIMENT != 5
         stage_park(b ^ 1);
-#endif
-#if HJB_CC_EXPERIMENT != 3 && HJB_CC_EXPERIMENT != 4 && HJB_CC_EXPERIMENT != 5
         __syncthreads();
-#endif
     }
     if (valid) {
         stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)(n1 - 1)), best);

@@ -101,14 +101,15 @@ def nested_problem(seed, n, m, dtype=np.float32, nonuniform=False, spread=0.2, m
 
 
 def colsweep_problem(seed, n, nU=9, nonuniform=False, gax=3, big=2.7, small=0.6, cost="fast", a1_amp=0.6, levels=5,
-                     dtype=np.float32, index_base=1, j_storage=None):
+                     dtype=np.float32, index_base=1, j_storage=None, a1_axis=None):
     """The shape of the column-sweep stage kernel (variant 7, kernels_colsweep.h; pos-att with the axes relabelled
     (x, theta, v, w)): D = 4, one control dim; axes 0 and 1 move with the state only (axis 0 over dims {0,2,3}, axis 1
     over dims {1,2,3}); axes 2 and 3 move with the control - the "group" axis `gax` by `big` cells times one of
     `levels` distinct values, the other ("window") axis by less than `small` < 1 cells.  a1_amp > 1 makes the axis-1
     cell jump irregularly along a column (re-priming path).  cost: 'fast' (state terms, the dim-1 term last, one
     control term), 'step01' (first term over dims (0,1): nothing is column-invariant, per-step term not uniform),
-    'multi' (two control-only terms), 'ctrl_only' (no state term at all)."""
+    'multi' (two control-only terms), 'ctrl_only' (no state term at all).  a1_axis=d: axis 1 moves with dim 1 and
+    dim d only, as pos-att's theta+ = theta + h w does (the cooperative form wants d = the group axis the plan picks)."""
     rng = np.random.default_rng(seed)
     assert len(n) == 4
     knots = []
@@ -129,6 +130,8 @@ def colsweep_problem(seed, n, nU=9, nonuniform=False, gax=3, big=2.7, small=0.6,
               Term((3,), 0.25 * hs[0] * rng.uniform(-1, 1, n[3]))]
     nxt[1] = [Term((1,), knots[1].copy()), Term((3,), a1_amp * hs[1] * rng.uniform(-1, 1, n[3])),
               Term((2,), 0.2 * hs[1] * rng.uniform(-1, 1, n[2]))]
+    if a1_axis is not None:
+        nxt[1] = [Term((1,), knots[1].copy()), Term((a1_axis,), a1_amp * hs[1] * rng.uniform(-1, 1, n[a1_axis]))]
     nxt[gax] = [Term((gax,), knots[gax].copy()), Term((4,), big * hs[gax] * d)]
     nxt[wax] = [Term((wax,), knots[wax].copy()), Term((4,), small * hs[wax] * c)]
     cu = 0.3 * np.round(rng.uniform(0, 3, nU)) ** 2             # repeated values: exact ties between controls

@@ -248,11 +248,61 @@ def test_colsweep_variant_bit_exact(env, n, nU, nonuniform, gax, cost, a1_amp, l
             bk.set_option("cs_xcd_mod", mod)
             o2 = bk.solve(3, terminal=term)
             assert np.array_equal(o2["J"], ref["J"]) and np.array_equal(o2["idx"], ref["idx"]), mod
+        bk.set_option("cs_xcd_mod", 0)
+        bk.set_option("cs_xcd_axis", 1)                      # the XCDs split the window axis instead of the group axis
+        o4 = bk.solve(3, terminal=term)
+        assert np.array_equal(o4["J"], ref["J"]) and np.array_equal(o4["idx"], ref["idx"])
+        bk.set_option("cs_xcd_axis", 0)
         if dpp_on:                                           # the two-loads-per-row form on the same problem
             bk.set_option("cs_dpp", 0)
             assert bk.get_option("cs_dpp") == 0
             o3 = bk.solve(3, terminal=term)
             assert np.array_equal(o3["J"], ref["J"]) and np.array_equal(o3["idx"], ref["idx"])
+
+
+COLCOOP = [
+    # n, nU, nonuniform, gax, a1_amp, j_storage, terminal     (n0 a multiple of 4 - of 8 for float16 storage)
+    ((64, 9, 8, 19), 9, False, 3, 0.6, None, True),         # three blocks of columns, the last one 3 wide
+    ((72, 7, 11, 6), 9, False, 2, 0.5, None, True),         # group axis = axis 2; two chunks of axis 0; one partial block
+    ((136, 6, 5, 9), 9, False, 3, 0.6, None, False),        # three chunks; zero terminal: every first-stage total ties
+    ((64, 8, 9, 12), 9, True, 3, 0.6, None, True),          # uneven knots: any axis-0 cell pattern is fine here
+    ((40, 13, 6, 9), 9, False, 3, 1.8, None, True),         # axis-1 cells jump: the workgroup re-primes together
+    ((64, 8, 9, 10), 9, False, 3, 0.6, "f16", True),        # float16 cost-to-go storage (8 knots per staging load)
+    ((8, 4, 3, 4), 6, False, 3, 0.6, None, True),           # tiny: one workgroup per group-axis index
+]
+_COLCOOP_RAN = []
+
+
+@pytest.mark.parametrize("n,nU,nonuniform,gax,a1_amp,j_storage,terminal", COLCOOP)
+def test_colsweep_cooperative_form_bit_exact(env, n, nU, nonuniform, gax, a1_amp, j_storage, terminal):
+    """Variant 7, cooperative form (kernels_colcoop.h, option cs_coop): eight neighbouring columns share their corner
+    rows through LDS.  Same plans, same arithmetic: bit-exact J and argmin against the oracle, every stage."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, random_terminal
+    for a1_axis in (gax, 5 - gax):          # axis 1 may see the group axis only - and the plan picks the group axis
+        spec = colsweep_problem(900 + n[0] + nU, n, nU=nU, nonuniform=nonuniform, gax=gax, cost="fast", a1_amp=a1_amp,
+                                levels=5 if nU == 9 else 3, j_storage=np.float16 if j_storage else None, a1_axis=a1_axis)
+        with hjbdp.Backup(spec, variant=7) as bk:
+            bk.set_option("cs_coop", 1)
+            if bk.get_option("cs_coop") or bk.get_option("cs_coop_why") != 2:
+                break
+    term = random_terminal(spec, 13) if terminal else None
+    ref = c_oracle.sweep(_abi, spec, 3, terminal=term, keep_J=True, keep_idx=True)
+    with hjbdp.Backup(spec, variant=7) as bk:
+        assert bk.info()["kernel_variant"] == 7 and bk.get_option("cs_coop") == 0      # off unless asked for
+        bk.set_option("cs_coop", 1)
+        on = bk.get_option("cs_coop")                        # the form in effect: the host check may rule it out
+        _COLCOOP_RAN.append((on, bk.get_option("cs_coop_why")))
+        out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
+        assert np.array_equal(out["J_stages"], ref["J_stages"])
+        assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+        bk.set_option("cs_coop", 0)
+        assert bk.get_option("cs_coop") == 0
+
+
+def test_colsweep_cooperative_form_was_exercised():
+    """Runs after the parametrised cases: the host check must have admitted the cooperative form on most of them."""
+    assert sum(on for on, _ in _COLCOOP_RAN) >= len(COLCOOP) - 2, _COLCOOP_RAN
 
 
 def test_colsweep_both_forms_were_exercised():
