@@ -830,6 +830,10 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
                 cells[((size_t)(i2 + n2 * i3) * kCsGMax + g) * 2] = G.cg;
                 cells[((size_t)(i2 + n2 * i3) * kCsGMax + g) * 2 + 1] = G.wmin;
                 if (g < ng) {
+                    // the kernels stop at a pair's first empty slot: used slots are a prefix of each pair
+                    for (int pr = 0; pr < 2; ++pr)
+                        for (int sidx = pr * (kCsMMax / 2) + 1; sidx < (pr + 1) * (kCsMMax / 2); ++sidx)
+                            if (G.slot[sidx] >= 0 && G.slot[sidx - 1] < 0) return false;
                     *rows_total += 2 * nw;
                     for (int sidx = 0; sidx < kCsMMax; ++sidx) {
                         const int u = G.slot[sidx];

@@ -275,7 +275,7 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
                     const T a1 = fma_t<T>(t0, (T)((T)cv[g & 1][1][w][1] - l1), l1);
                     return f2{a0, a1};
                 };
-                cs_group<T, GAX, FASTCOST>(used[g], g, row0, A[g], t1, slots, gstep, ncu, npre, best, best_u);
+                cs_group<T, GAX, FASTCOST>(used[g], g, row0, A[g], A[g], t1, slots, gstep, ncu, npre, best, best_u);
             }
         }
         stage_park(b ^ 1);

@@ -135,11 +135,13 @@ template <typename T, typename TJ> __device__ __forceinline__ T raw_to(uint32_t 
 // One group of one step, shared by the column-sweep kernels: roll the group's three window knots (the axis-1 lerp of the
 // new corner rows with the previous ones), then visit its member slots.  row0(w) returns, for window knot w, the
 // (lower, upper group row) pair of axis-0 lerps of the new corner rows - each kernel gets at the neighbours its own way.
+// Aold = those lerps of the previous step, Anew receives this step's: the same array in both kernels.  (Two arrays
+// swapping roles in a loop unrolled by two would save the copy of each row, but keep both sets alive: 92 -> 124 VGPRs.)
 typedef float cs_f4 __attribute__((ext_vector_type(4)));
 typedef float cs_f2 __attribute__((ext_vector_type(2)));
 template <typename T, int GAX, bool FASTCOST, typename FA, typename SP>
-__device__ __forceinline__ void cs_group(int ug, int g, FA row0, cs_f2 (&Ag)[kCsNW], T t1, SP slots, T gstep, int ncu, int npre,
-                                         T &best, int &best_u) {
+__device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&Aold)[kCsNW], cs_f2 (&Anew)[kCsNW], T t1, SP slots,
+                                         T gstep, int ncu, int npre, T &best, int &best_u) {
     typedef cs_f2 f2;
     typedef cs_f4 f4;
     constexpr int NW = kCsNW, MM = kCsMMax;
@@ -152,8 +154,8 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, cs_f2 (&Ag)[kCs
     f2 Bv[NW];
     auto roll = [&](int w) {
         const f2 an = row0(w);
-        Bv[w] = __builtin_elementwise_fma(t1p, an - Ag[w], Ag[w]);
-        Ag[w] = an;
+        Bv[w] = __builtin_elementwise_fma(t1p, an - Aold[w], Aold[w]);
+        Anew[w] = an;
     };
     // the member-independent half of a member's first lerp:
     //   GAX == 3 (window = axis 2 is lerped first, both group rows at once): Ew[p] = B[p + 1] - B[p]
@@ -172,40 +174,49 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, cs_f2 (&Ag)[kCs
         if (GAX == 3) Ew[1] = Bv[2] - Bv[1];
         else Dg[2] = (T)(Bv[2].y - Bv[2].x);
     }
+    auto member = [&](int s) {
+        const int off = s / (MM / 2);                // slots 0-2: window knots (0, 1); slots 3-5: (1, 2)
+        const f4 ms = slots[(g * MM + s) * 2];       // broadcast read of the slot's plan data
+        const T tw = ms.x, tg = ms.y;
+        const int u = __float_as_int(ms.w);
+        T interp;
+        if (GAX == 3) {
+            const f2 twp = {tw, tw};
+            const f2 v = __builtin_elementwise_fma(twp, Ew[off], Bv[off]);
+            interp = fma_t<T>(tg, (T)(v.y - v.x), v.x);
+        } else {
+            T v0 = fma_t<T>(tg, Dg[off], Bv[off].x);
+            asm volatile("" : "+v"(v0));             // two plain fmas: packed, their operands would need moving
+            const T v1 = fma_t<T>(tg, Dg[off + 1], Bv[off + 1].x);
+            interp = fma_t<T>(tw, (T)(v1 - v0), v0);
+        }
+        T gg;
+        if (FASTCOST) {                              // the usual shape: state terms + ONE control term
+            gg = (T)(gstep + ms.z);
+        } else {
+            const f4 mx = slots[(g * MM + s) * 2 + 1];
+            gg = gstep;
+            for (int k = 0; k < ncu; ++k) {
+                const T x = k == 0 ? ms.z : (k == 1 ? mx.x : (k == 2 ? mx.y : mx.z));
+                gg = (npre == 0 && k == 0) ? x : (T)(gg + x);
+            }
+        }
+        const T tot = (T)(gg + interp);
+        // groups are not visited in control order: a slot that comes after a higher-numbered control (flag from the
+        // plan) also wins a tie if its control number is the lower one: first index wins, exactly
+        if (ug & (0x10000 << s)) take_tie(best, best_u, tot, u);
+        take_less(best, best_u, tot, u);
+    };
+    // the slots of a pair are filled from its first one (the plan builder's order): an empty slot ends the pair
+    static_assert(MM == 6, "three slots per window pair");
 #pragma unroll
-    for (int s = 0; s < MM; ++s) {
-        if (ug & (1 << s)) {
-            const int off = s / (MM / 2);                // slots 0-2: window knots (0, 1); slots 3-5: (1, 2)
-            const f4 ms = slots[(g * MM + s) * 2];       // broadcast read of the slot's plan data
-            const T tw = ms.x, tg = ms.y;
-            const int u = __float_as_int(ms.w);
-            T interp;
-            if (GAX == 3) {
-                const f2 twp = {tw, tw};
-                const f2 v = __builtin_elementwise_fma(twp, Ew[off], Bv[off]);
-                interp = fma_t<T>(tg, (T)(v.y - v.x), v.x);
-            } else {
-                T v0 = fma_t<T>(tg, Dg[off], Bv[off].x);
-                asm volatile("" : "+v"(v0));             // two plain fmas: packed, their operands would need moving
-                const T v1 = fma_t<T>(tg, Dg[off + 1], Bv[off + 1].x);
-                interp = fma_t<T>(tw, (T)(v1 - v0), v0);
+    for (int p = 0; p < 2; ++p) {
+        if (ug & (1 << (3 * p))) {
+            member(3 * p);
+            if (ug & (2 << (3 * p))) {
+                member(3 * p + 1);
+                if (ug & (4 << (3 * p))) member(3 * p + 2);
             }
-            T gg;
-            if (FASTCOST) {                              // the usual shape: state terms + ONE control term
-                gg = (T)(gstep + ms.z);
-            } else {
-                const f4 mx = slots[(g * MM + s) * 2 + 1];
-                gg = gstep;
-                for (int k = 0; k < ncu; ++k) {
-                    const T x = k == 0 ? ms.z : (k == 1 ? mx.x : (k == 2 ? mx.y : mx.z));
-                    gg = (npre == 0 && k == 0) ? x : (T)(gg + x);
-                }
-            }
-            const T tot = (T)(gg + interp);
-            // groups are not visited in control order: a slot that comes after a higher-numbered control (flag from the
-            // plan) also wins a tie if its control number is the lower one: first index wins, exactly
-            if (ug & (0x10000 << s)) take_tie(best, best_u, tot, u);
-            take_less(best, best_u, tot, u);
         }
     }
 }
@@ -373,7 +384,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
             const int n = LPK * (1 + ((used[g] & pairmask) != 0) + ((used[g] & (pairmask << (MM / 2))) != 0));
             if (g < NGH) nH0 += n; else nH1 += n;
         }
-    auto load_groups = [&](int g0, int g1, uint32_t vrow) {
+    auto load_groups = [&](int g0, int g1, uint32_t vrow) __attribute__((always_inline)) {
         uint32_t vb[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) vb[w] = voff0 + (vrow + (uint32_t)w * w_bytes);
@@ -397,7 +408,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         }
     };
     // wait until at most `younger` gathers (a multiple of LPK) are outstanding, then release groups [g0, g1) to the arithmetic
-    auto await_groups = [&](int g0, int g1, int younger) {
+    auto await_groups = [&](int g0, int g1, int younger) __attribute__((always_inline)) {
         switch (younger / LPK) {
             case 0: wait_gathers<0>(); break;
             case 1: wait_gathers<1 * LPK>(); break;
@@ -424,7 +435,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     asm volatile("" : "+v"(slots));          // one address register for the column, not one re-made per read
     // The arithmetic (cs_group) is written on PAIRS (lower, upper group row) of one window knot: v_pk_add_f32 /
     // v_pk_fma_f32 are IEEE per component, and with the pair as the unit of data no value has to be moved between registers.
-    auto compute_groups = [&](int g0, int g1) {
+    auto compute_groups = [&](int g0, int g1) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
             if (g < ngs) {
@@ -435,7 +446,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                                      : f2{raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])} - l;
                     return __builtin_elementwise_fma(t0p, d, l);
                 };
-                cs_group<T, GAX, FASTCOST>(used[g], g, row0, A[g], t1, slots, gstep, ncu, npre, best, best_u);
+                cs_group<T, GAX, FASTCOST>(used[g], g, row0, A[g], A[g], t1, slots, gstep, ncu, npre, best, best_u);
             }
         }
     };

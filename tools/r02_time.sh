@@ -1,6 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r02j; mkdir -p $O
-ORDER=0,2,1,3 timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep "ran 7" | sed "s/^/xtvw: /" | tee -a $O/quick.log
-ORDER=0,2,3,1 timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep "ran 7" | sed "s/^/xtwv: /" | tee -a $O/quick.log
-ORDER=0,2,3,1 F16=1 timeout 300 python3 tools/time_posatt.py 120 10 7 2>&1 | grep "ran 7" | sed "s/^/xtwv f16: /" | tee -a $O/quick.log
+ORDER=0,2,3,1 timeout 300 python3 tools/time_posatt.py 120 50 7 2>&1 | grep "ran 7" | sed "s/^/xtwv: /"
+ORDER=0,2,1,3 timeout 300 python3 tools/time_posatt.py 120 50 7 2>&1 | grep "ran 7" | sed "s/^/xtvw: /"
+ORDER=0,2,3,1 F16=1 timeout 300 python3 tools/time_posatt.py 120 50 7 2>&1 | grep "ran 7" | sed "s/^/xtwv f16: /"
