@@ -94,19 +94,30 @@ def cpu_baseline(spec, budget_s=15.0, dataflow_spec=None):
     mid = spec.n[-1] // 2
     rng = np.random.default_rng(0)
 
-    def run(planes):
+    def run(planes, impl):
         b, e = mid, mid + planes
         J = rng.random(inner * (planes + hl + hh)).astype(spec.j_dtype)
         t0 = time.perf_counter()
-        c_oracle.backup_stage(_abi, spec, J, slab=(b, e, hl, hh), nthreads=cores)
+        c_oracle.backup_stage(_abi, spec, J, slab=(b, e, hl, hh), nthreads=cores, impl=impl)
         return time.perf_counter() - t0
-    t1 = run(1)
-    planes = int(max(1, min(spec.n[-1] // 2 - hh - 1, budget_s / max(t1, 1e-3))))
-    t = run(planes) if planes > 1 else t1
-    backups = inner * planes * spec.nU
-    out = {"value": backups / t, "unit": "backups/s", "cores": cores, "kind": "port",
-           "sample": "%d of %d planes of the last state axis (%d states x %d controls, 1 stage) in %.1f s; "
-                     "oracle/hjb_oracle.c, OpenMP" % (planes, spec.n[-1], inner * planes, spec.nU, t)}
+
+    def timed(impl, budget):
+        t1 = run(1, impl)
+        planes = int(max(1, min(spec.n[-1] // 2 - hh - 1, budget / max(t1, 1e-3))))
+        t = run(planes, impl) if planes > 1 else t1
+        return {"value": inner * planes * spec.nU / t, "unit": "backups/s", "cores": cores, "kind": "port",
+                "sample": "%d of %d planes of the last state axis (%d states x %d controls, 1 stage) in %.1f s" % (
+                    planes, spec.n[-1], inner * planes, spec.nU, t)}
+    # two forms of the C twin, same results bit for bit (tests/test_oracle_golden.py): the scalar one every parity
+    # test compares against, and its AVX2 + FMA row-vectorised form - the faster CPU baseline
+    scalar = timed("scalar", budget_s * 0.4)
+    scalar["sample"] += "; oracle/hjb_oracle.c backup_f32, scalar, OpenMP"
+    try:
+        out = timed("avx2", budget_s * 0.6)
+        out["sample"] += "; oracle/hjb_oracle.c backup_f32_avx2 (8 states per vector), OpenMP"
+        out["scalar_c_openmp"] = scalar
+    except RuntimeError:                  # float64 problems: the vector form is float32 only
+        out = scalar
     if dataflow_spec is not None:
         # the reference's own dataflow restated in numpy (SURVEY 8d "CPU reference timing"): materialised
         # next-state and cost tables over states x controls, vectorised N-linear interpolation, min over the control axis

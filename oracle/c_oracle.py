@@ -33,6 +33,8 @@ def lib(abi):
         l = C.CDLL(str(SO))
         l.orc_backup_stage.restype = C.c_int
         l.orc_backup_stage.argtypes = [C.POINTER(abi.hjb_problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        l.orc_backup_stage_avx2.restype = C.c_int
+        l.orc_backup_stage_avx2.argtypes = l.orc_backup_stage.argtypes
         l.orc_sweep.restype = C.c_int
         l.orc_sweep.argtypes = [C.POINTER(abi.hjb_problem), C.POINTER(abi.hjb_solve_opts), C.POINTER(abi.hjb_result), C.c_int]
         l.orc_max_threads.restype = C.c_int
@@ -75,8 +77,9 @@ def canon_eval(abi, kind, a, b=None):
     return out
 
 
-def backup_stage(abi, spec, J_next, slab=None, nthreads=0):
-    """One canonical-arithmetic backup on the CPU.  Returns (J_out flat, idx)."""
+def backup_stage(abi, spec, J_next, slab=None, nthreads=0, impl="scalar"):
+    """One canonical-arithmetic backup on the CPU.  Returns (J_out flat, idx).  impl: "scalar" (the twin every test
+    compares against) or "avx2" (its row-vectorised form, float32 arithmetic only: the faster CPU baseline)."""
     l = lib(abi)
     p, keep = spec.to_c(slab)
     Jn = np.ascontiguousarray(np.asarray(J_next, dtype=spec.j_dtype).reshape(-1, order="F"))
@@ -87,7 +90,8 @@ def backup_stage(abi, spec, J_next, slab=None, nthreads=0):
         n_owned = spec.nS // spec.n[-1] * (slab[1] - slab[0])
     idx = np.empty(n_owned, dtype=np.int32)
     nt = nthreads or l.orc_max_threads()
-    st = l.orc_backup_stage(C.byref(p), Jn.ctypes.data, Jo.ctypes.data, idx.ctypes.data, nt)
+    fn = l.orc_backup_stage_avx2 if impl == "avx2" else l.orc_backup_stage
+    st = fn(C.byref(p), Jn.ctypes.data, Jo.ctypes.data, idx.ctypes.data, nt)
     if st not in (0,):
         raise RuntimeError("orc_backup_stage status %d" % st)
     return Jo, idx

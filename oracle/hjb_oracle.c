@@ -277,6 +277,145 @@ static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float
 DEFINE_BACKUP(float, backup_f32, fmaf)
 DEFINE_BACKUP(double, backup_f64, fma)
 
+/* AVX2 + FMA3 form of backup_f32 (the row-vectorised CPU baseline): eight consecutive
+ * axis-0 states of one grid row per iteration, one lane each.  Lane by lane it performs exactly the operations of the
+ * scalar twin above in the same order (IEEE adds / multiplies, vfmadd for the lerps, the same binary search, strict
+ * '<'), so its results are bit-identical - tests/test_oracle_golden.py holds it to that.  float32 arithmetic only
+ * (float32 / float16 storage), no state model, J < 2^31 elements; anything else returns HJB_E_UNSUPPORTED. */
+static int backup_f32_avx2(const hjb_problem *p, const float *Jn, float *Jout, int32_t *idx_out, int nthreads) {
+    const int D = p->D, C = p->C;
+    if (p->model) return HJB_E_UNSUPPORTED;
+    float *knots[HJB_MAX_D], *rdx[HJB_MAX_D];
+    term_t nt[HJB_MAX_D][HJB_MAX_TERMS], ct[HJB_MAX_TERMS];
+    int32_t jstride[HJB_MAX_D];
+    int sb = p->slab_begin, se = p->slab_end, hlo = p->halo_lo, hhi = p->halo_hi;
+    if (sb == 0 && se == 0) { se = p->n[D - 1]; hlo = hhi = 0; }
+    const int plane0 = sb - hlo;
+    const int nplanes = (se + hhi) - plane0;
+    int64_t s = 1, inner = 1;
+    for (int a = 0; a < D; ++a) { jstride[a] = (int32_t)s; s *= (a == D - 1) ? nplanes : p->n[a]; }
+    if (s >= ((int64_t)1 << 31)) return HJB_E_UNSUPPORTED;
+    for (int a = 0; a + 1 < D; ++a) inner *= p->n[a];
+    for (int a = 0; a < D; ++a) {
+        int n = p->n[a];
+        knots[a] = (float *)malloc(sizeof(float) * n);
+        rdx[a] = (float *)malloc(sizeof(float) * n);
+        for (int i = 0; i < n; ++i) knots[a][i] = (float)p->knots[a][i];
+        for (int i = 0; i + 1 < n; ++i) rdx[a][i] = (float)1 / (knots[a][i + 1] - knots[a][i]);
+        rdx[a][n - 1] = 0;
+        for (int k = 0; k < p->n_next_terms[a]; ++k) build_term(p, &p->next_terms[a][k], &nt[a][k]);
+    }
+    for (int k = 0; k < p->n_cost_terms; ++k) build_term(p, &p->cost_terms[k], &ct[k]);
+    const int n0 = D > 1 ? p->n[0] : (se - sb);            /* D == 1: the only axis is the sharded one */
+    const int64_t n_owned = inner * (se - sb), rows = n_owned / n0;
+    int64_t nU = 1;
+    for (int c = 0; c < C; ++c) nU *= p->m[c];
+    int32_t corner[1 << HJB_MAX_D];
+    for (int c = 0; c < (1 << D); ++c) {
+        int32_t off = 0;
+        for (int a = 0; a < D; ++a)
+            if (c & (1 << a)) off += jstride[a];
+        corner[c] = off;
+    }
+    int err = 0;
+    (void)nthreads;
+    #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t row = 0; row < rows; ++row) {
+        int gi[HJB_MAX_G];
+        {
+            int64_t r = row;
+            gi[0] = 0;
+            for (int a = 1; a < D; ++a) {
+                int na = (a == D - 1) ? (se - sb) : p->n[a];
+                gi[a] = (int)(r % na);
+                r /= na;
+            }
+            if (D > 1) gi[D - 1] += sb;
+        }
+        const __m256i iota = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+        for (int i0 = 0; i0 < n0; i0 += 8) {
+            const int nl = n0 - i0 < 8 ? n0 - i0 : 8;       /* lanes past the row's end repeat its last state */
+            __m256i li = _mm256_min_epi32(_mm256_add_epi32(_mm256_set1_epi32(i0), iota), _mm256_set1_epi32(n0 - 1));
+            if (D == 1) li = _mm256_add_epi32(li, _mm256_set1_epi32(sb));
+            __m256 best = _mm256_setzero_ps();
+            __m256i lab = _mm256_setzero_si256();
+            int first = 1;
+            for (int c = 0; c < C; ++c) gi[D + c] = 0;
+            for (int64_t u = 0; u < nU; ++u) {
+                __m256 v[1 << HJB_MAX_D], tw[HJB_MAX_D];
+                __m256i base = _mm256_setzero_si256();
+                for (int a = 0; a < D; ++a) {
+                    __m256 q = _mm256_setzero_ps();
+                    for (int k = 0; k < p->n_next_terms[a]; ++k) {
+                        int64_t off = 0;
+                        for (int d = 1; d < D + C; ++d) off += nt[a][k].stride[d] * gi[d];
+                        const float *dp = (const float *)nt[a][k].data + off;
+                        const int s0 = (int)nt[a][k].stride[0];
+                        __m256 x = s0 == 0 ? _mm256_set1_ps(dp[0])
+                                           : _mm256_i32gather_ps(dp, _mm256_mullo_epi32(li, _mm256_set1_epi32(s0)), 4);
+                        q = (k == 0) ? x : _mm256_add_ps(q, x);
+                    }
+                    const float *kk = knots[a];
+                    __m256i lo = _mm256_setzero_si256(), hi = _mm256_set1_epi32(p->n[a] - 1);
+                    for (;;) {                               /* upper_bound(q) - 1, clamped to [0, n-2] */
+                        __m256i act = _mm256_cmpgt_epi32(_mm256_sub_epi32(hi, lo), _mm256_set1_epi32(1));
+                        if (!_mm256_movemask_epi8(act)) break;
+                        __m256i mid = _mm256_srai_epi32(_mm256_add_epi32(lo, hi), 1);
+                        __m256i le = _mm256_castps_si256(_mm256_cmp_ps(_mm256_i32gather_ps(kk, mid, 4), q, _CMP_LE_OQ));
+                        lo = _mm256_blendv_epi8(lo, mid, _mm256_and_si256(act, le));
+                        hi = _mm256_blendv_epi8(hi, mid, _mm256_andnot_si256(le, act));
+                    }
+                    tw[a] = _mm256_mul_ps(_mm256_sub_ps(q, _mm256_i32gather_ps(kk, lo, 4)), _mm256_i32gather_ps(rdx[a], lo, 4));
+                    __m256i cell = lo;
+                    if (a == D - 1) {
+                        cell = _mm256_sub_epi32(cell, _mm256_set1_epi32(plane0));
+                        __m256i bad = _mm256_or_si256(_mm256_cmpgt_epi32(_mm256_setzero_si256(), cell),
+                                                      _mm256_cmpgt_epi32(_mm256_add_epi32(cell, _mm256_set1_epi32(2)), _mm256_set1_epi32(nplanes)));
+                        if (_mm256_movemask_epi8(bad)) {
+                            err = 1;
+                            cell = _mm256_max_epi32(_mm256_min_epi32(cell, _mm256_set1_epi32(nplanes - 2)), _mm256_setzero_si256());
+                        }
+                    }
+                    base = _mm256_add_epi32(base, _mm256_mullo_epi32(cell, _mm256_set1_epi32(jstride[a])));
+                }
+                for (int c = 0; c < (1 << D); ++c) v[c] = _mm256_i32gather_ps(Jn + corner[c], base, 4);
+                for (int a = 0; a < D; ++a) {
+                    int half = 1 << (D - 1 - a);
+                    for (int j = 0; j < half; ++j) v[j] = _mm256_fmadd_ps(tw[a], _mm256_sub_ps(v[2 * j + 1], v[2 * j]), v[2 * j]);
+                }
+                __m256 g = _mm256_setzero_ps();
+                for (int k = 0; k < p->n_cost_terms; ++k) {
+                    int64_t off = 0;
+                    for (int d = 1; d < D + C; ++d) off += ct[k].stride[d] * gi[d];
+                    const float *dp = (const float *)ct[k].data + off;
+                    const int s0 = (int)ct[k].stride[0];
+                    __m256 x = s0 == 0 ? _mm256_set1_ps(dp[0])
+                                       : _mm256_i32gather_ps(dp, _mm256_mullo_epi32(li, _mm256_set1_epi32(s0)), 4);
+                    g = (k == 0) ? x : _mm256_add_ps(g, x);
+                }
+                const __m256 tot = _mm256_add_ps(g, v[0]);
+                int64_t label = 0, mul = 1;
+                for (int c = 0; c < C; ++c) { label += mul * gi[D + c]; mul *= p->m[c]; }
+                const __m256 take = first ? _mm256_castsi256_ps(_mm256_set1_epi32(-1)) : _mm256_cmp_ps(tot, best, _CMP_LT_OQ);
+                first = 0;
+                best = _mm256_blendv_ps(best, tot, take);
+                lab = _mm256_blendv_epi8(lab, _mm256_set1_epi32((int32_t)(label + p->index_base)), _mm256_castps_si256(take));
+                for (int c = C - 1; c >= 0; --c) {
+                    if (++gi[D + c] < p->m[c]) break;
+                    gi[D + c] = 0;
+                }
+            }
+            const int64_t ls = row * n0 + i0;                /* first owned state of this vector */
+            const int64_t in_plane = ls % inner, pl = ls / inner;
+            const __m256i keep = _mm256_cmpgt_epi32(_mm256_set1_epi32(nl), iota);
+            _mm256_maskstore_ps(Jout + in_plane + inner * (pl + hlo), keep, best);
+            if (idx_out) _mm256_maskstore_epi32(idx_out + ls, keep, lab);
+        }
+    }
+    for (int a = 0; a < D; ++a) { free(knots[a]); free(rdx[a]); }
+    return err ? HJB_E_HALO : HJB_OK;
+}
+
 /* one backup.  J buffers are in the haloed slab layout of hjb_problem (whole
  * grid when the slab fields are zero); idx_out covers owned states only. */
 /* IEEE binary16 <-> float (F16C): widening is exact, narrowing rounds to nearest even - the same
@@ -307,6 +446,24 @@ int orc_backup_stage(const hjb_problem *p, const void *J_next, void *J_out, int3
     }
     if (p->dtype == HJB_F32) return backup_f32(p, (const float *)J_next, (float *)J_out, idx_out, nthreads, NULL, 0, NULL);
     return backup_f64(p, (const double *)J_next, (double *)J_out, idx_out, nthreads, NULL, 0, NULL);
+}
+
+/* the same backup by the AVX2 row-vectorised form (float32 arithmetic only) */
+int orc_backup_stage_avx2(const hjb_problem *p, const void *J_next, void *J_out, int32_t *idx_out, int nthreads) {
+    int st = validate(p);
+    if (st) return st;
+    if (p->dtype == HJB_F16S) {   /* float32 arithmetic on widened J, result narrowed on store */
+        int64_t ne = j_elems_of(p);
+        float *a = (float *)malloc(sizeof(float) * (ne > 0 ? ne : 1)), *b = (float *)malloc(sizeof(float) * (ne > 0 ? ne : 1));
+        if (!a || !b) { free(a); free(b); return HJB_E_NOMEM; }
+        for (int64_t i = 0; i < ne; ++i) { a[i] = h2f(((const uint16_t *)J_next)[i]); b[i] = h2f(((const uint16_t *)J_out)[i]); }
+        st = backup_f32_avx2(p, a, b, idx_out, nthreads);
+        for (int64_t i = 0; i < ne; ++i) ((uint16_t *)J_out)[i] = f2h(b[i]);
+        free(a); free(b);
+        return st;
+    }
+    if (p->dtype == HJB_F32) return backup_f32_avx2(p, (const float *)J_next, (float *)J_out, idx_out, nthreads);
+    return HJB_E_UNSUPPORTED;
 }
 
 /* Backup of a LIST of states of the whole grid (no slab) with J_next given in separable form

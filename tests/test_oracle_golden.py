@@ -135,6 +135,41 @@ def test_slab_oracle_matches_whole_grid(orc):
     assert np.array_equal(io, iw.reshape(72, 12, order="F")[:, b:e].reshape(-1, order="F"))
 
 
+@pytest.mark.parametrize("case", ["random3d", "random4d_f16", "kirk", "rows_of_5", "one_axis", "slab"])
+def test_avx2_twin_equals_scalar_twin(orc, golden, case):
+    """The row-vectorised C twin (bench.py's faster CPU baseline) performs the scalar twin's
+    operations lane by lane: cost-to-go and argmin bit for bit, with ties, extrapolation, ragged rows and slabs."""
+    _abi, c_oracle, hjb_oracle = orc
+    slab = None
+    if case == "random3d":
+        spec = random_problem(5, (19, 8, 12), (4, 3), dtype=np.float32, spread=0.3)
+    elif case == "random4d_f16":
+        from problems import colsweep_problem
+        spec = colsweep_problem(8, (21, 6, 7, 10), j_storage=np.float16)
+    elif case == "kirk":
+        spec = kirk_spec(golden, dtype=np.float32)
+    elif case == "rows_of_5":
+        spec = random_problem(6, (5, 4, 3), (7,), dtype=np.float32, spread=0.5, nonuniform=True)
+    elif case == "one_axis":
+        spec = random_problem(7, (41,), (9,), dtype=np.float32, spread=0.4)
+    else:
+        spec = random_problem(99, (9, 8, 12), (4, 3), dtype=np.float32, spread=0.08)
+        slab = (4, 8, 2, 2)
+    term = random_terminal(spec, 3)
+    if case == "kirk":
+        term = np.zeros(spec.nS, dtype=np.float32)          # every first-stage total ties between some controls
+    if slab is not None:
+        inner = spec.nS // spec.n[-1]
+        term = np.asfortranarray(term.reshape(inner, -1, order="F")[:, slab[0] - slab[2]:slab[1] + slab[3]]).reshape(-1, order="F")
+    Js, i_s = c_oracle.backup_stage(_abi, spec, term, slab=slab)
+    Jv, i_v = c_oracle.backup_stage(_abi, spec, term, slab=slab, impl="avx2")
+    assert np.array_equal(Js.view(np.uint8), Jv.view(np.uint8)) and np.array_equal(i_s, i_v)
+    if case == "random3d":                                   # float64 arithmetic: the vector form says so, never guesses
+        spec64 = random_problem(5, (19, 8, 12), (4, 3), dtype=np.float64, spread=0.3)
+        with pytest.raises(RuntimeError):
+            c_oracle.backup_stage(_abi, spec64, random_terminal(spec64, 3), impl="avx2")
+
+
 def test_lookup_oracle_against_scipy(orc):
     """The lookup checker itself is checked against an independent implementation
     (scipy RegularGridInterpolator, linear + extrapolation; nearest away from midpoints)."""
