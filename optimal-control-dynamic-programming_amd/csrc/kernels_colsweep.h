@@ -123,6 +123,29 @@ __device__ __forceinline__ uint32_t gather_async(uint32_t off, gptr<char> base) 
     return r;
 }
 template <int N> __device__ __forceinline__ void wait_gathers() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N)); }
+// The same with a count known only at run time (a multiple of K, at most 9 K): `s_waitcnt` takes an immediate, and a
+// switch over ten of them compiles to a chain of some twenty scalar instructions - twice per step.  Instead: a computed
+// jump into a table of (s_waitcnt, s_branch) pairs, 8 bytes each; s_getpc_b64 yields the address of the s_add_u32.
+template <int K> __device__ __forceinline__ void wait_gathers_n(int younger) {
+    static_assert(K == 2 || K == 4, "gathers per window knot");
+    const int off = 12 + 8 * (younger / K);          // past s_add_u32, s_addc_u32, s_setpc_b64; then 8 bytes per entry
+    if (K == 2)
+        asm volatile("s_getpc_b64 vcc\n\ts_add_u32 vcc_lo, vcc_lo, %0\n\ts_addc_u32 vcc_hi, vcc_hi, 0\n\ts_setpc_b64 vcc\n\t"
+                     "s_waitcnt vmcnt(0)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(2)\n\ts_branch .Lwg%=\n\t"
+                     "s_waitcnt vmcnt(4)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(6)\n\ts_branch .Lwg%=\n\t"
+                     "s_waitcnt vmcnt(8)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(10)\n\ts_branch .Lwg%=\n\t"
+                     "s_waitcnt vmcnt(12)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(14)\n\ts_branch .Lwg%=\n\t"
+                     "s_waitcnt vmcnt(16)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(18)\n.Lwg%=:"
+                     : : "s"(off) : "vcc", "scc", "memory");
+    else
+        asm volatile("s_getpc_b64 vcc\n\ts_add_u32 vcc_lo, vcc_lo, %0\n\ts_addc_u32 vcc_hi, vcc_hi, 0\n\ts_setpc_b64 vcc\n\t"
+                     "s_waitcnt vmcnt(0)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(4)\n\ts_branch .Lwg%=\n\t"
+                     "s_waitcnt vmcnt(8)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(12)\n\ts_branch .Lwg%=\n\t"
+                     "s_waitcnt vmcnt(16)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(20)\n\ts_branch .Lwg%=\n\t"
+                     "s_waitcnt vmcnt(24)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(28)\n\ts_branch .Lwg%=\n\t"
+                     "s_waitcnt vmcnt(32)\n\ts_branch .Lwg%=\n\ts_waitcnt vmcnt(36)\n.Lwg%=:"
+                     : : "s"(off) : "vcc", "scc", "memory");
+}
 __device__ __forceinline__ void tie6(uint32_t (&r)[2][kCsNW]) {
     static_assert(kCsNW == 3, "six registers per group and neighbour");
     asm volatile("" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]));
@@ -409,18 +432,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     };
     // wait until at most `younger` gathers (a multiple of LPK) are outstanding, then release groups [g0, g1) to the arithmetic
     auto await_groups = [&](int g0, int g1, int younger) __attribute__((always_inline)) {
-        switch (younger / LPK) {
-            case 0: wait_gathers<0>(); break;
-            case 1: wait_gathers<1 * LPK>(); break;
-            case 2: wait_gathers<2 * LPK>(); break;
-            case 3: wait_gathers<3 * LPK>(); break;
-            case 4: wait_gathers<4 * LPK>(); break;
-            case 5: wait_gathers<5 * LPK>(); break;
-            case 6: wait_gathers<6 * LPK>(); break;
-            case 7: wait_gathers<7 * LPK>(); break;
-            case 8: wait_gathers<8 * LPK>(); break;
-            default: wait_gathers<9 * LPK>(); break;
-        }
+        wait_gathers_n<LPK>(younger);
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
             tie6(rlo[g]);
