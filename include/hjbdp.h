@@ -274,7 +274,8 @@ int32_t hjb_get_info_flat(hjb_handle h, int64_t *out8);
  * the interior planes while the copies are in flight and the two boundary strips after them; the early-stop monitor's
  * sums are added over the slabs.  Choose WHICH axis is last by relabelling the state axes (the axis should move less
  * than a slab per stage: pos-att shards x, v or theta, not w).  hjb_solve_opts: terminal / J_final / idx_final are
- * whole-grid host arrays; J_stages, idx_stages and probe are not supported.  The same device may be listed more than
+ * whole-grid host arrays, as are J_stages / idx_stages (copied out slab by slab behind each stage); probe is not
+ * supported.  The same device may be listed more than
  * once (several slabs on one GPU: testing).  One process per GPU with torch.distributed/RCCL is the other supported
  * form (hjbdp/sharded.py, bench.py --gpus N). */
 typedef struct hjb_multi_s *hjb_multi;

@@ -2523,8 +2523,8 @@ int32_t hjb_multi_set_option(hjb_multi m, const char *key, int64_t value) {
 int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
     if (!m || !o) return mfail(m, HJB_E_INVALID, "null argument");
     if (o->n_stages < 1) return mfail(m, HJB_E_INVALID, "n_stages=%d", o->n_stages);
-    if (o->J_stages || o->idx_stages || o->probe)
-        return mfail(m, HJB_E_UNSUPPORTED, "hjb_solve_multi keeps no per-stage planes and no probe block (use one device, or drive the slabs yourself)");
+    if (o->probe)
+        return mfail(m, HJB_E_UNSUPPORTED, "hjb_solve_multi takes no probe block (use one device, or drive the slabs yourself)");
     const int n = (int)m->slabs.size();
     const int64_t inner = m->inner;
     const size_t esz = m->esz, plane_b = (size_t)inner * esz;
@@ -2600,6 +2600,15 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
             }
             if (st) return mfail(m, st, "stage launch on slab %d: %s", i, m->err.c_str());
             MULTI_TRY(hipEventRecord(S.done[par], S.sc));
+            // per-stage planes (Dynamic_Solver.m:100,105): plane k_s - 1 of the host arrays, this slab's states; the copies
+            // run behind the stage on its compute stream (the output buffer is rewritten two stages on, idx one stage on)
+            const size_t own = (size_t)(S.end - S.begin);
+            const size_t at = (size_t)(k_s - 1) * (size_t)inner * (size_t)m->nl + (size_t)inner * (size_t)S.begin;
+            if (o->J_stages)
+                MULTI_TRY(hipMemcpyAsync((char *)o->J_stages + at * esz, (const char *)S.whole->dJ[cur ^ 1] + plane_b * S.hlo, plane_b * own,
+                                         hipMemcpyDeviceToHost, S.sc));
+            if (o->idx_stages)
+                MULTI_TRY(hipMemcpyAsync(o->idx_stages + at, S.whole->d_idx, (size_t)inner * own * 4, hipMemcpyDeviceToHost, S.sc));
         }
         cur ^= 1;
         // ---- the early-stop monitor (Solver_pos_att.m:273-285): per-slab sums, added on the host ----------------------

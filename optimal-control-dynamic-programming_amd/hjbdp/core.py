@@ -301,7 +301,7 @@ class MultiBackup:
     def set_option(self, key, value):
         self._check(self.lib.hjb_multi_set_option(self._m, key.encode(), int(value)))
 
-    def solve(self, n_stages, terminal=None, monitor_period=0, monitor_tol=0.0, progress=None):
+    def solve(self, n_stages, terminal=None, keep_J=False, keep_idx=False, monitor_period=0, monitor_tol=0.0, progress=None):
         nS, dt = self.spec.nS, self.spec.j_dtype
         o = _abi.hjb_solve_opts()
         o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
@@ -315,13 +315,20 @@ class MultiBackup:
         J = np.empty(nS, dtype=dt)
         idx = np.empty(nS, dtype=np.int32)
         o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
+        Js = Is = None
+        if keep_J:
+            Js = np.zeros((nS, n_stages), dtype=dt, order="F")
+            o.J_stages = Js.ctypes.data
+        if keep_idx:
+            Is = np.zeros((nS, n_stages), dtype=np.int32, order="F")
+            o.idx_stages = Is.ctypes.data
         if progress is not None:
             cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
             keep.append(cb)
             o.progress = cb
         res = _abi.hjb_result()
         self._check(self.lib.hjb_solve_multi(self._m, C.byref(o), C.byref(res)))
-        return {"J": J, "idx": idx, "stages_done": res.stages_done, "stopped_early": bool(res.stopped_early),
+        return {"J": J, "idx": idx, "J_stages": Js, "idx_stages": Is, "stages_done": res.stages_done, "stopped_early": bool(res.stopped_early),
                 "sweep_ms": res.sweep_ms, "last_e": res.last_e, "last_e2": res.last_e2}
 
 

@@ -169,10 +169,10 @@ def test_solve_multi_matches_single_device(env, case):
     else:
         spec, devs, stages = colsweep_problem(7, (33, 6, 8, 15), gax=2, j_storage=np.float16), [0, 0, 0, 0], 3
     term = random_terminal(spec, 4)
-    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, **kw)
+    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, keep_J=True, keep_idx=True, **kw)
     with hjbdp.MultiBackup(spec, devs) as mb:
         infos = [mb.slab_info(i) for i in range(len(devs))]
-        out = mb.solve(stages, terminal=term, **kw)
+        out = mb.solve(stages, terminal=term, keep_J=True, keep_idx=True, **kw)
         again = mb.solve(stages, terminal=term, **kw)            # a second sweep on the same object
     assert infos[0]["begin"] == 0 and infos[-1]["end"] == spec.n[-1]
     assert all(a["end"] == b["begin"] for a, b in zip(infos, infos[1:]))
@@ -180,6 +180,7 @@ def test_solve_multi_matches_single_device(env, case):
         assert any(i["split"] for i in infos), infos          # the overlapped form was exercised
     assert out["stages_done"] == ref["stages_done"] and out["stopped_early"] == ref["stopped_early"]
     assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+    assert np.array_equal(out["J_stages"], ref["J_stages"]) and np.array_equal(out["idx_stages"], ref["idx_stages"])   # every stage's planes
     assert np.array_equal(again["J"], ref["J"]) and np.array_equal(again["idx"], ref["idx"])
     if kw:
         assert out["stopped_early"] and out["stages_done"] == 3
