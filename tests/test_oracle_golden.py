@@ -170,6 +170,40 @@ def test_avx2_twin_equals_scalar_twin(orc, golden, case):
             c_oracle.backup_stage(_abi, spec64, random_terminal(spec64, 3), impl="avx2")
 
 
+@pytest.mark.parametrize("n,m,nonuniform", [((9, 7, 6), (5,), True), ((6, 5, 4, 5), (3, 2), True), ((11, 8), (7,), False)])
+def test_backup_oracle_against_scipy_interpolant(orc, n, m, nonuniform):
+    """The backup itself against an independent implementation of griddedInterpolant's 'linear' semantics on what the
+    reference's golden vector does not cover (non-uniform knots, D = 3 and 4, two control dims): scipy's
+    RegularGridInterpolator (multilinear, fill_value=None = linear extrapolation) evaluated at the oracle's own next
+    states, plus numpy's first-minimum.  float64: 1e-11 relative on J; argmin equal wherever the minimum is not a
+    near-tie."""
+    from scipy.interpolate import RegularGridInterpolator
+    _abi, c_oracle, hjb_oracle = orc
+    spec = random_problem(17 + len(n), n, m, dtype=np.float64, nonuniform=nonuniform, spread=0.45)
+    term = random_terminal(spec, 9)
+    Jc, ic = c_oracle.backup_stage(_abi, spec, term)
+    prob = hjb_oracle.Problem(spec.knots, spec.m, [[hjb_oracle.Term(t.dims, t.data) for t in ts] for ts in spec.next_terms],
+                              [hjb_oracle.Term(t.dims, t.data) for t in spec.cost_terms], dtype=np.float64)
+    full = tuple(n) + tuple(m)
+    q = np.stack([np.broadcast_to(prob._sum(prob.next_terms[a]), full).reshape(-1) for a in range(len(n))], axis=1)
+    F = RegularGridInterpolator([np.asarray(k, dtype=np.float64) for k in spec.knots], np.asarray(term).reshape(n, order="F"),
+                                method="linear", bounds_error=False, fill_value=None)
+    tot = (np.broadcast_to(prob._sum(prob.cost_terms), full).reshape(-1) + F(q)).reshape(full)
+    tot = tot.reshape(tuple(n) + (-1,))                     # C-order flatten of the control dims: first dim slowest = cascade order
+    k = np.argmin(tot, axis=-1)
+    Jr = np.take_along_axis(tot, k[..., None], axis=-1)[..., 0].reshape(-1, order="F")
+    assert np.max(np.abs(Jc - Jr)) <= 1e-11 * max(1.0, np.max(np.abs(Jr)))
+    srt = np.sort(tot, axis=-1)
+    clear = ((srt[..., 1] - srt[..., 0]) > 1e-9 * (1 + np.abs(srt[..., 0]))).reshape(-1, order="F")
+    sub = np.unravel_index(k.reshape(-1, order="F"), m)     # (i1, ..., iC); the label is column-major, first dim fastest
+    lab = np.zeros(k.size, dtype=np.int64)
+    mul = 1
+    for c in range(len(m)):
+        lab += mul * sub[c]
+        mul *= m[c]
+    assert np.array_equal(ic[clear] - spec.index_base, lab[clear]) and clear.mean() > 0.9
+
+
 def test_lookup_oracle_against_scipy(orc):
     """The lookup checker itself is checked against an independent implementation
     (scipy RegularGridInterpolator, linear + extrapolation; nearest away from midpoints)."""
