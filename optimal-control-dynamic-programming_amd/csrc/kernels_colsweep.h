@@ -50,7 +50,7 @@ constexpr int kCsMMax = 6;      // member slots per group: 3 per window pair
 constexpr int kCsNW = 3;        // window knots per group
 constexpr int kCsUMax = 16;     // controls
 constexpr int kCsMaxCu = kLeanMaxCu;
-constexpr int kCsFlush = 8;     // results are parked in LDS and written out every kCsFlush steps
+constexpr int kCsFlush = 20;    // results are parked in LDS and written out every kCsFlush steps
 constexpr int kCsDppLanes = 60; // states per wave in the one-load form (+ a halo lane + a spare lane pair + 1)
 // The plan of one (i2, i3), 32-bit words:
 //   [0] halo violation flag | groups << 8   [1 + g] byte offset of group g's first corner row
@@ -256,7 +256,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     typedef float f2 __attribute__((ext_vector_type(2)));
     __shared__ f4 s_slots[4][kCsSlots * 2];
     __shared__ T s_best[4][kCsFlush][64];
-    __shared__ int32_t s_idx[4][kCsFlush][64];
+    __shared__ uint8_t s_idx[4][kCsFlush][64];               // control numbers (< kCsUMax) as bytes: more steps per flush
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int n0 = P->n[0], n1 = P->n[1], n2 = P->n[2], n3 = P->n[3];
@@ -529,14 +529,14 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         // ---- results: parked in LDS, written out every kCsFlush steps ------------------------------------
         const int slot = i1 % kCsFlush;
         s_best[wave][slot][lane] = best;
-        s_idx[wave][slot][lane] = best_u + index_base;
+        s_idx[wave][slot][lane] = (uint8_t)best_u;
         if (slot == kCsFlush - 1 || i1 == n1 - 1) {
             __builtin_amdgcn_wave_barrier();
             if (valid) {
                 const int first = i1 - slot;
                 for (int j = 0; j <= slot; ++j) {
                     stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)(first + j)), s_best[wave][j][lane]);
-                    if (idx_out) idx_out[idx_col + (uint32_t)n0 * (uint32_t)(first + j)] = s_idx[wave][j][lane];
+                    if (idx_out) idx_out[idx_col + (uint32_t)n0 * (uint32_t)(first + j)] = (int32_t)s_idx[wave][j][lane] + index_base;
                 }
             }
             // let the stores finish here (and with them the gathers in flight): the counted waits above rely on no
