@@ -173,7 +173,6 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
     asm volatile("" : "+s"(ug));
     const f2 t1p = {t1, t1};
     // knot 1 of the window serves both pairs; knot 0 only pair 0's slots, knot 2 only pair 1's
-    const bool pair0 = (ug & ((1 << (MM / 2)) - 1)) != 0, pair1 = (ug & (((1 << (MM / 2)) - 1) << (MM / 2))) != 0;
     f2 Bv[NW];
     auto roll = [&](int w) {
         const f2 an = row0(w);
@@ -187,16 +186,6 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
     T Dg[NW];
     roll(1);
     if (GAX == 2) Dg[1] = (T)(Bv[1].y - Bv[1].x);
-    if (pair0) {
-        roll(0);
-        if (GAX == 3) Ew[0] = Bv[1] - Bv[0];
-        else Dg[0] = (T)(Bv[0].y - Bv[0].x);
-    }
-    if (pair1) {
-        roll(2);
-        if (GAX == 3) Ew[1] = Bv[2] - Bv[1];
-        else Dg[2] = (T)(Bv[2].y - Bv[2].x);
-    }
     auto member = [&](int s) {
         const int off = s / (MM / 2);                // slots 0-2: window knots (0, 1); slots 3-5: (1, 2)
         const f4 ms = slots[(g * MM + s) * 2];       // broadcast read of the slot's plan data
@@ -230,11 +219,15 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
         if (ug & (0x10000 << s)) take_tie(best, best_u, tot, u);
         take_less(best, best_u, tot, u);
     };
-    // the slots of a pair are filled from its first one (the plan builder's order): an empty slot ends the pair
+    // the slots of a pair are filled from its first one (the plan builder's order): an empty first slot means the pair -
+    // and its outer window knot - is not in use, an empty slot ends the pair
     static_assert(MM == 6, "three slots per window pair");
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         if (ug & (1 << (3 * p))) {
+            roll(2 * p);
+            if (GAX == 3) Ew[p] = Bv[p + 1] - Bv[p];
+            else Dg[2 * p] = (T)(Bv[2 * p].y - Bv[2 * p].x);
             member(3 * p);
             if (ug & (2 << (3 * p))) {
                 member(3 * p + 1);
