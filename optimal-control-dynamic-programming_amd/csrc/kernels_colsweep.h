@@ -411,8 +411,8 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                 asm volatile("" : "+s"(ug));                 // tested here, per step (see cs_group)
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    if (w == 0 && !(ug & pairmask)) continue;
-                    if (w == 2 && !(ug & (pairmask << (MM / 2)))) continue;
+                    if (w == 0 && !(ug & 1)) continue;                          // a pair is in use iff its first slot is
+                    if (w == 2 && !(ug & (1 << (MM / 2)))) continue;
                     const uint32_t o = vb[w] + rog[g];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
