@@ -394,19 +394,20 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     // uses is neither gathered nor lerped.  How many gathers each half issues is therefore a property of the column.
     const int pairmask = (1 << (MM / 2)) - 1;
     int nH0 = 0, nH1 = 0;
+    // (A group the column does not have - fewer distinct cells at the grid's edge - has no slot in use and repeats group
+    // 0's rows: its knot 1 is gathered all the same, which costs two L1 hits and saves a test per group and half.)
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-        if (g < ng) {
-            const int n = LPK * (1 + ((used[g] & pairmask) != 0) + ((used[g] & (pairmask << (MM / 2))) != 0));
-            if (g < NGH) nH0 += n; else nH1 += n;
-        }
+    for (int g = 0; g < NG; ++g) {
+        const int n = LPK * (1 + ((used[g] & pairmask) != 0) + ((used[g] & (pairmask << (MM / 2))) != 0));
+        if (g < NGH) nH0 += n; else nH1 += n;
+    }
     auto load_groups = [&](int g0, int g1, uint32_t vrow) __attribute__((always_inline)) {
         uint32_t vb[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) vb[w] = voff0 + (vrow + (uint32_t)w * w_bytes);
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
-            if (g < ngs) {
+            {
                 int ug = used[g];
                 asm volatile("" : "+s"(ug));                 // tested here, per step (see cs_group)
 #pragma unroll
@@ -455,6 +456,15 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
             }
         }
     };
+    // the per-step cost term of the usual shape: its descriptor is read once, not once per step
+    const bool one_su = step_uniform && npre - npre_col == 1;
+    cptr<T> su_ptr = as_const<T>(P->cost[one_su ? npre_col : 0].data);
+    int su_s1 = 0;
+    if (one_su) {
+        const DTerm &tm = P->cost[npre_col];
+        su_ptr += tm.stride[2] * i2 + tm.stride[3] * si[3];
+        su_s1 = tm.stride[1];
+    }
     int prev_c1 = -2;
     int c1n = tab1[0].cell;
     T t1n = tab1[0].t;
@@ -496,7 +506,10 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         load_groups(NGH, NG, (uint32_t)(c1 + 1) * s1_bytes);              // H1 of this step
         // ---- this state's cost without the control terms -----------------------------------------------
         gstep = gcol;
-        if (npre > npre_col) {
+        if (one_su) {                            // the usual shape: ONE per-step term, the same for every state of the wave
+            const T x = su_ptr[su_s1 * i1];
+            gstep = npre_col == 0 ? x : (T)(gcol + x);
+        } else if (npre > npre_col) {
             si[1] = i1;
             if (step_uniform) {
                 for (int k = npre_col; k < npre; ++k) {
