@@ -466,6 +466,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         su_s1 = tm.stride[1];
     }
     int prev_c1 = -2;
+    cptr<TabEntry<T>> tab1n = tab1;                          // entry of the next step
     int c1n = tab1[0].cell;
     T t1n = tab1[0].t;
     // Everything hipcc loaded for the set-up has landed before the loop starts: a value still "pending" at the loop
@@ -473,6 +474,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" : "+v"(gcol), "+v"(t0), "+v"(voff0));
     load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // prologue: H0 of step 0
+    int slot = 0;                                            // LDS slot of this step's result (= i1 % kCsFlush)
     for (int i1 = 0; i1 < n1; ++i1) {
         // The four waves of the workgroup (neighbours along the group axis: half their corner rows are the same) take every
         // step together, so that what one of them misses in L1 the others find there: 2.31 -> 2.26 ms per stage on C4.
@@ -483,9 +485,9 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         ngs = ng;
         asm volatile("" : "+s"(ngs));        // group-count tests stay scalar compares of this step (see the slot bits)
         {   // next step's axis-1 entry: a scalar load in flight during this step
-            const int nx = (i1 + 1 < n1 ? i1 + 1 : i1) * a1_s;
-            c1n = tab1[nx].cell;
-            t1n = tab1[nx].t;
+            if (i1 + 1 < n1) tab1n += a1_s;
+            c1n = tab1n[0].cell;
+            t1n = tab1n[0].t;
         }
         if (c1 != prev_c1 + 1) {         // (re-)prime: A <- the row at knot c1 (column start; irregular axis-1 cells)
             const uint32_t vrow = (uint32_t)c1 * s1_bytes;
@@ -533,7 +535,6 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         await_groups(NGH, NG, nH0);                                       // H1 landed; the next H0 in flight
         compute_groups(NGH, NG);
         // ---- results: parked in LDS, written out every kCsFlush steps ------------------------------------
-        const int slot = i1 % kCsFlush;
         s_best[wave][slot][lane] = best;
         s_idx[wave][slot][lane] = (uint8_t)best_u;
         if (slot == kCsFlush - 1 || i1 == n1 - 1) {
@@ -549,6 +550,9 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
             // store being pending, loads and stores complete out of order with each other
             __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
             __builtin_amdgcn_wave_barrier();
+            slot = 0;
+        } else {
+            ++slot;
         }
     }
 }
