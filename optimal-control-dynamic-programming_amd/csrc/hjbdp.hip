@@ -2362,7 +2362,9 @@ struct hjb_multi_s {
         int64_t part_row0[3] = {0, 0, 0};    // first plane of the part's view inside the slab's J buffer
         int64_t part_own0[3] = {0, 0, 0};    // first owned plane of the part, relative to `begin`
         hipStream_t sc = nullptr, sx = nullptr;
+        hipStream_t ss[2] = {nullptr, nullptr};              // the two boundary strips run beside the interior
         hipEvent_t done[2] = {nullptr, nullptr}, halo[2] = {nullptr, nullptr};
+        hipEvent_t fork = nullptr, sdone[2] = {nullptr, nullptr};
     };
     std::vector<Slab> slabs;
     int need_lo = 0, need_hi = 0, nl = 0, dtype = HJB_F32;
@@ -2392,7 +2394,10 @@ int32_t hjb_destroy_multi(hjb_multi m) {
         for (int i = 0; i < 2; ++i) {
             if (S.done[i]) (void)hipEventDestroy(S.done[i]);
             if (S.halo[i]) (void)hipEventDestroy(S.halo[i]);
+            if (S.sdone[i]) (void)hipEventDestroy(S.sdone[i]);
+            if (S.ss[i]) (void)hipStreamDestroy(S.ss[i]);
         }
+        if (S.fork) (void)hipEventDestroy(S.fork);
         if (S.sc) (void)hipStreamDestroy(S.sc);
         if (S.sx) (void)hipStreamDestroy(S.sx);
         for (int i = 0; i < 3; ++i) if (S.part[i]) (void)hjb_destroy((hjb_handle)S.part[i]);
@@ -2478,7 +2483,9 @@ int32_t hjb_create_multi(const hjb_problem *p, int32_t n_dev, const int32_t *dev
         if (st) break;
         bool ok = hipStreamCreateWithFlags(&S.sc, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&S.sx, hipStreamNonBlocking) == hipSuccess;
         for (int k = 0; k < 2 && ok; ++k)
-            ok = hipEventCreateWithFlags(&S.done[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&S.halo[k], hipEventDisableTiming) == hipSuccess;
+            ok = hipEventCreateWithFlags(&S.done[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&S.halo[k], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&S.sdone[k], hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&S.ss[k], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&S.fork, hipEventDisableTiming) == hipSuccess;
         if (!ok) { st = mfail(nullptr, HJB_E_DEVICE, "stream / event creation failed on device %d", S.device); break; }
         for (int j = 0; j < n_dev; ++j)          // direct peer copies where the platform allows them (errors: staged copies still work)
             if (devices[j] != S.device) { int can = 0; if (hipDeviceCanAccessPeer(&can, S.device, devices[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[j], 0); }
@@ -2543,12 +2550,12 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
         else MULTI_TRY(hipMemset(J0, 0, plane_b * (size_t)(S.end - S.begin + S.hlo + S.hhi)));
         MULTI_TRY(hipDeviceSynchronize());
     }
-    auto stage_part = [&](hjb_multi_s::Slab &S, int k, int cur) -> int {
+    auto stage_part = [&](hjb_multi_s::Slab &S, int k, int cur, hipStream_t stream) -> int {
         Handle *h = k < 0 ? S.whole : S.part[k];
         const int64_t row0 = k < 0 ? 0 : S.part_row0[k], own0 = k < 0 ? 0 : S.part_own0[k];
         const char *in = (const char *)S.whole->dJ[cur] + plane_b * row0;
         char *outp = (char *)S.whole->dJ[cur ^ 1] + plane_b * row0;
-        const int st = launch_stage(h, in, outp, S.whole->d_idx + inner * own0, S.sc);
+        const int st = launch_stage(h, in, outp, S.whole->d_idx + inner * own0, stream);
         if (st) m->err = h->err;
         return st;
     };
@@ -2590,13 +2597,25 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
             }
             int st = HJB_OK;
             if (S.part[0]) {
-                st = stage_part(S, 0, cur);
-                if (!st && (S.hlo || S.hhi)) MULTI_TRY(hipStreamWaitEvent(S.sc, S.halo[par], 0));
-                if (!st && S.part[1]) st = stage_part(S, 1, cur);
-                if (!st && S.part[2]) st = stage_part(S, 2, cur);
+                // the strips on streams of their own, beside the interior: each launch of the column-sweep kernel lasts at
+                // least one column (~0.2 ms), in line behind the interior two strips would cost more than the copies hide.
+                // A strip stream waits for what the compute stream has waited for so far (event `fork`), and for the halos.
+                MULTI_TRY(hipEventRecord(S.fork, S.sc));          // fork point: everything this stage depends on, before the interior
+                for (int k = 1; k <= 2 && !st; ++k)
+                    if (S.part[k]) MULTI_TRY(hipStreamWaitEvent(S.ss[k - 1], S.fork, 0));
+                st = stage_part(S, 0, cur, S.sc);
+                for (int k = 1; k <= 2 && !st; ++k)
+                    if (S.part[k]) {
+                        if (S.hlo || S.hhi) MULTI_TRY(hipStreamWaitEvent(S.ss[k - 1], S.halo[par], 0));
+                        st = stage_part(S, k, cur, S.ss[k - 1]);
+                        if (!st) {
+                            MULTI_TRY(hipEventRecord(S.sdone[k - 1], S.ss[k - 1]));
+                            MULTI_TRY(hipStreamWaitEvent(S.sc, S.sdone[k - 1], 0));
+                        }
+                    }
             } else {
                 if (S.hlo || S.hhi) MULTI_TRY(hipStreamWaitEvent(S.sc, S.halo[par], 0));
-                st = stage_part(S, -1, cur);
+                st = stage_part(S, -1, cur, S.sc);
             }
             if (st) return mfail(m, st, "stage launch on slab %d: %s", i, m->err.c_str());
             MULTI_TRY(hipEventRecord(S.done[par], S.sc));
@@ -2637,6 +2656,8 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
         MULTI_TRY(hipSetDevice(S.device));
         MULTI_TRY(hipStreamSynchronize(S.sc));
         MULTI_TRY(hipStreamSynchronize(S.sx));
+        MULTI_TRY(hipStreamSynchronize(S.ss[0]));
+        MULTI_TRY(hipStreamSynchronize(S.ss[1]));
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (auto &S : m->slabs) {

@@ -130,6 +130,7 @@ class ShardedSweep:
                 if hi_w:
                     sub(e - hi_w, e, min(need_lo, (e - hi_w) - b), self.halo_hi)
                 self._comm_stream = torch.cuda.Stream(device=self.device)
+                self._strip_streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self.stage_fn = stage_fn
         # what my neighbours need from me
         self.up_needs = min(need_lo, self.end) if self.rank < world - 1 else 0     # my top planes -> rank+1's lower halo
@@ -227,11 +228,20 @@ class ShardedSweep:
             self._comm_stream.wait_stream(main)            # the previous stage's output is the data to send
             with t.cuda.stream(self._comm_stream):
                 works = self.exchange_halos(wait=False)
+            # the boundary strips run on streams of their own, beside the interior: a strip is a few hundred waves, but
+            # every launch of the column-sweep kernel lasts at least one column (~0.2 ms) - in line behind the interior
+            # two strips would cost more than the exchange they hide
+            strips = list(zip(range(1, len(self._parts)), self._strip_streams))
+            for _, s in strips:
+                s.wait_stream(main)                        # J_in complete (recorded BEFORE the interior is enqueued)
             self._hip_part(0, J_in, J_out, self.idx)       # interior: independent of the halos
-            for w in works:
-                w.wait()                                   # the compute stream waits for the transfers
-            for i in range(1, len(self._parts)):
-                self._hip_part(i, J_in, J_out, self.idx)
+            for i, s in strips:
+                with t.cuda.stream(s):
+                    for w in works:
+                        w.wait()                           # this stream waits for the transfers
+                    self._hip_part(i, J_in, J_out, self.idx)
+            for _, s in strips:
+                main.wait_stream(s)
         self.cur = 1 - self.cur
 
     def monitor_sums(self):
