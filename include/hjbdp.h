@@ -198,8 +198,12 @@ int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
  * of every reference solver; csrc/kernels_prep_mfma.h), 0: with the vector kernels.  Bit-identical tables either way;
  * get: "prep_mfma", "prep_mfma_tables", "prep_tables", "prep_ns" (device time of the last rebuild), "table_hash".
  * read a knob back, plus what the column-sweep kernel (variant 7) settled on: "cs_dpp" (1: one load per corner row, the
- * upper axis-0 neighbour taken from the next lane), "cs_groups", "cs_group_axis".  "cs_dpp" and "cs_xcd_mod" (residue
- * modulus of the column -> XCD assignment: 0/1 contiguous ranges, -1 the group spacing) are also settable (testing, tuning). */
+ * upper axis-0 neighbour taken from the next lane), "cs_groups", "cs_group_axis", "cs_rows" (corner rows per step of the
+ * mid-grid column), "cs_coop" (1: the cooperative form is in effect), "cs_coop_why" (why it does not apply: 0 applies,
+ * 1 groups, 2 axis 1 sees the window axis, 3 n0 / storage, 4 cells, 5 window knots, 6 axis-0 knots).  Settable (testing,
+ * tuning): "cs_dpp", "cs_coop" (1: eight neighbouring columns share their corner rows through LDS, kernels_colcoop.h;
+ * off by default - slower on C4), "cs_xcd_mod" (residue modulus of the column -> XCD assignment: 0/1 contiguous ranges,
+ * -1 the group spacing), "cs_xcd_axis" (0: the XCDs split the group axis [default], 1: the window axis). */
 int32_t hjb_get_option(hjb_handle h, const char *key, int64_t *value);
 
 /* ONE backup, host buffers (exactly the MATLAB statement above):
