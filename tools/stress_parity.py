@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hjbdp
 from hjbdp import _abi
 from oracle import c_oracle
-from problems import nested_problem, random_problem, random_terminal
+from problems import colsweep_problem, nested_problem, random_problem, random_terminal
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -29,7 +29,7 @@ while time.time() < t_end:
     nonuniform = bool(rng.random() < 0.4)
     spread = float(rng.choice([0.02, 0.1, 0.3, 0.8]))
     seed = int(rng.integers(1 << 30))
-    kind = rng.choice(["nested", "nested_mixed", "random", "rowwise", "local2d"]) if C <= D else "random"
+    kind = rng.choice(["nested", "nested_mixed", "random", "rowwise", "local2d", "colsweep", "colsweep"]) if C <= D else "random"
     try:
         if kind == "local2d":         # every query within one cell of its state: hjb_solve's several-stages-per-launch path
             from hjbdp import Term
@@ -43,6 +43,20 @@ while time.time() < t_end:
                    [Term((1,), kv), Term((0,), 0.4 * hv * np.cos(5 * kx)), Term((2,), 0.55 * hv * U / 0.26)]]
             cost = [Term((0,), 6 * kx ** 2), Term((1,), 3 * kv ** 2), Term((2,), 0.1 * U ** 2), Term((0, 1), 0.05 * rng.random(n))]
             spec = hjbdp.ProblemSpec([kx, kv], m, nxt, cost, dtype=dtype, index_base=1)
+        elif kind == "colsweep":      # the pos-att shape: variant 7 in its forms (one load per row / two, cooperative)
+            D, C = 4, 1
+            n = (int(rng.choice([int(rng.integers(3, 150)), 64, 120, 128, 60, 61, 121])), int(rng.integers(2, 14)),
+                 int(rng.integers(3, 13)), int(rng.integers(3, 13)))
+            if np.prod(n) > 4e5:
+                n = (n[0], min(n[1], 6), min(n[2], 7), min(n[3], 7))
+            nU = int(rng.integers(1, 17))
+            m = (nU,)
+            dtype = np.float32
+            gax = int(rng.choice([2, 3]))
+            spec = colsweep_problem(seed, n, nU=nU, nonuniform=nonuniform, gax=gax, big=float(rng.choice([0.4, 1.3, 2.7, 3.8])),
+                                    small=float(rng.choice([0.2, 0.6, 0.95])), cost=str(rng.choice(["fast", "step01", "multi", "ctrl_only"])),
+                                    a1_amp=float(rng.choice([0.3, 0.6, 1.8])), levels=int(rng.integers(1, 7)),
+                                    a1_axis=(None if rng.random() < 0.5 else int(rng.choice([2, 3]))))
         elif kind == "rowwise":       # no axis but axis 0 depends on state dim 0: variant 6 (lean form when it applies)
             if D < 2:
                 continue
@@ -70,13 +84,19 @@ while time.time() < t_end:
         continue      # random dynamics with strong extrapolation can blow J up to inf/NaN: outside the contract
                       # (SURVEY 8a note 3: "NaNs ... none arise"; min/argmin of NaNs is not defined alike everywhere)
     n_prob += 1
-    for v in (None, 0, 1, 2, 3, 4, 5, 6):
+    for v in (None, 0, 1, 2, 3, 4, 5, 6, 7, "7 two loads", "7 coop"):
         try:
-            bk = hjbdp.Backup(spec, variant=v)
+            bk = hjbdp.Backup(spec, variant=7 if isinstance(v, str) else v)
         except hjbdp.HjbError as e:
             assert e.status == _abi.HJB_E_UNSUPPORTED, (v, str(e))
             continue
         with bk:
+            if v == "7 two loads":
+                bk.set_option("cs_dpp", 0)
+            if v == "7 coop":
+                bk.set_option("cs_coop", 1)
+                if not bk.get_option("cs_coop"):
+                    continue
             kv = bk.info()["kernel_variant"]
             out = bk.solve(stages, terminal=term)
         ok = np.array_equal(out["J"], ref["J"], equal_nan=True) and np.array_equal(out["idx"], ref["idx"])   # (f16 J may overflow to inf/NaN over many stages - on both sides alike)
