@@ -105,6 +105,7 @@ struct Handle {
     int cs_dpp = 1;               // option "cs_dpp": allow the DPP form of variant 7 when the axis-0 cells permit it
     int cs_rows_mid = 0;          // corner rows per step the mid-grid column needs (get_option "cs_rows")
     int cs_xcd_axis = 0;          // option "cs_xcd_axis": 0 = the XCDs split the group axis, 1 = the window axis
+    int cs_split = 0;             // option "cs_split": parts a column is swept in (0 = automatic, see colsweep_split)
     int cs_coop = 0;              // option "cs_coop": allow the cooperative form (kernels_colcoop.h) where it applies
     int cs_coop_why = 0;          // why it does not: 1 groups, 2 axis 1 sees the window axis, 3 n0 / storage, 4 cells, 5 window knots, 6 axis-0 knots
     int cs_coop_epl = 0;          // ... it applies: elements per staging load (0 = does not apply)
@@ -1024,6 +1025,24 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
     return HJB_OK;
 }
 
+// Variant 7: in how many parts (waves) a column is swept (DColSweep::split).  Automatic: double it while the launch has
+// fewer waves than ~1.2 x the chip's 5120 wave slots and every part keeps >= 12 steps (a part starts by priming: one
+// step's worth of extra gathers) - a boundary strip of a multi-GPU slab (240 columns on C4) then lasts 15 steps, not 120.
+void colsweep_split(Handle *h) {
+    const DParams &P = h->hp;
+    DColSweep &CSh = h->hcs;
+    const int lanes = CSh.dpp ? kCsDppLanes : 64;
+    const int64_t chunks = (P.n[0] + lanes - 1) / lanes;
+    const int64_t waves = chunks * (int64_t)P.n[2] * (int64_t)P.n[3];
+    const int n1 = P.n[1];
+    int S = h->cs_split;
+    if (S <= 0) {
+        S = 1;
+        while (S < 8 && waves * S * 2 <= 6144 && n1 / (S * 2) >= 12) S *= 2;
+    }
+    CSh.split = std::max(1, std::min(S, std::max(1, n1)));
+}
+
 template <typename T>
 int ensure_colsweep_t(Handle *h) {
     if (h->cs_state >= 0) return HJB_OK;
@@ -1093,6 +1112,7 @@ int ensure_colsweep_t(Handle *h) {
         if (st) return st;
         CSh.dpp = (dok && h->cs_dpp) ? 1 : 0;
     }
+    colsweep_split(h);
     st = dev_alloc(h, sizeof(DColSweep), &d);
     if (st) return st;
     h->dcs = (DColSweep *)d;
@@ -1209,7 +1229,7 @@ void choose_launch(Handle *h) {
         const int64_t nwax = P.n[5 - h->hcs.gax];
         int64_t most = 0;
         const int64_t nfull = h->hcs.xcd_win ? P.n[h->hcs.gax] : nwax;      // the axis every XCD walks in full
-        for (int x = 0; x < 8; ++x) most = std::max<int64_t>(most, (int64_t)h->hcs.xcd_cnt[x] * chunks * nfull);
+        for (int x = 0; x < 8; ++x) most = std::max<int64_t>(most, (int64_t)h->hcs.xcd_cnt[x] * chunks * nfull * h->hcs.split);
         h->grid = (int)(8 * ((most + 3) / 4));
         h->cc_grid = 0;
         if (h->hcs.coop && !h->hcs.xcd_win) {       // cooperative form: one workgroup of kCcW waves per (group-axis index, 64-state chunk, kCcW columns)
@@ -1758,6 +1778,17 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             const int cst = colsweep_dpp_ok<float>(h, &dok);
             if (cst) return cst;
             h->hcs.dpp = (dok && h->cs_dpp) ? 1 : 0;
+            colsweep_split(h);
+            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            choose_launch(h);
+        }
+        return HJB_OK;
+    }
+    if (!strcmp(key, "cs_split")) {                                  // variant 7: parts a column is swept in (0 = automatic)
+        if (value < 0 || value > 64) return fail(h, HJB_E_INVALID, "%s out of range", key);
+        h->cs_split = (int)value;
+        if (h->cs_state == 1) {
+            colsweep_split(h);
             HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
             choose_launch(h);
         }
@@ -1831,6 +1862,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "lds_pad")) *value = (int64_t)h->lds_pad;
     else if (!strcmp(key, "cs_xcd_mod")) *value = h->cs_xcd_mod;
     else if (!strcmp(key, "cs_xcd_axis")) *value = h->cs_xcd_axis;
+    else if (!strcmp(key, "cs_split")) *value = h->variant == 7 ? h->hcs.split : 0;       // the value in effect
     else if (!strcmp(key, "cs_coop_why")) *value = h->cs_coop_why;
     else if (!strcmp(key, "cs_rows")) *value = h->variant == 7 ? h->cs_rows_mid : 0;
     else if (!strcmp(key, "prep_mfma")) *value = h->prep_mfma;

@@ -82,6 +82,9 @@ struct DColSweep {
     int32_t xcd_cnt[8];
     int32_t xcd_stride;
     int32_t xcd_win;        // the XCDs split the WINDOW axis instead (xcd_ig then lists window-axis indices)
+    int32_t split;          // a column is swept by `split` waves, each a contiguous part of i1 (priming where it starts): few
+                            // columns (a boundary strip of a multi-GPU slab, a small grid) still fill the chip, and a launch
+                            // lasts n1 / split steps instead of n1
     int32_t coop;           // cooperative form (kernels_colcoop.h): 0 = off, else elements per staging load (1, 4, 8)
     const int32_t *wg;      // its per-workgroup words, [(ig * chunks + chunk) * blocks + block][kCcWgWords]
 };
@@ -255,12 +258,16 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     const int n0 = P->n[0], n1 = P->n[1], n2 = P->n[2], n3 = P->n[3];
     const int chunks = (n0 + LANES - 1) / LANES;
     // ---- which column (see DColSweep::xcd_ig) --------------------------------------------------------------
-    int i2, i3, chunk;
+    int i2, i3, chunk, part;
     {
-        const unsigned xcd = blockIdx.x & 7u, item = (blockIdx.x >> 3) * 4u + (unsigned)wave;
+        const unsigned xcd = blockIdx.x & 7u;
+        unsigned item = (blockIdx.x >> 3) * 4u + (unsigned)wave;
         const unsigned cnt = (unsigned)CS->xcd_cnt[xcd];
         const unsigned nfull = (unsigned)((GAX == 3) != (CS->xcd_win != 0) ? n2 : n3);   // the axis every XCD walks in full
-        if (item >= cnt * (unsigned)chunks * nfull) return;                   // uniform over the wave
+        const unsigned per_part = cnt * (unsigned)chunks * nfull;
+        if (item >= per_part * (unsigned)CS->split) return;                   // uniform over the wave
+        part = (int)(item / per_part);                                        // which part of the column (outermost)
+        item -= (unsigned)part * per_part;
         int ig, iw;
         if (CS->xcd_win) {               // the XCD owns window-axis indices: the group axis is walked in full, fastest
             const unsigned ngx = (unsigned)(GAX == 3 ? n3 : n2);
@@ -466,16 +473,17 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         su_s1 = tm.stride[1];
     }
     int prev_c1 = -2;
-    cptr<TabEntry<T>> tab1n = tab1;                          // entry of the next step
-    int c1n = tab1[0].cell;
-    T t1n = tab1[0].t;
+    const int i1b = (int)((int64_t)n1 * part / CS->split), i1e = (int)((int64_t)n1 * (part + 1) / CS->split);   // this wave's steps
+    cptr<TabEntry<T>> tab1n = tab1 + i1b * a1_s;             // entry of the next step
+    int c1n = tab1n[0].cell;
+    T t1n = tab1n[0].t;
     // Everything hipcc loaded for the set-up has landed before the loop starts: a value still "pending" at the loop
     // header would make its first use INSIDE the loop a `vmcnt(0)` on every step - a drain of the gathers in flight.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" : "+v"(gcol), "+v"(t0), "+v"(voff0));
     load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // prologue: H0 of step 0
     int slot = 0;                                            // LDS slot of this step's result (= i1 % kCsFlush)
-    for (int i1 = 0; i1 < n1; ++i1) {
+    for (int i1 = i1b; i1 < i1e; ++i1) {
         // The four waves of the workgroup (neighbours along the group axis: half their corner rows are the same) take every
         // step together, so that what one of them misses in L1 the others find there: 2.31 -> 2.26 ms per stage on C4.
         // (A wave that has left - no column - does not count for the barrier.)
@@ -485,7 +493,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         ngs = ng;
         asm volatile("" : "+s"(ngs));        // group-count tests stay scalar compares of this step (see the slot bits)
         {   // next step's axis-1 entry: a scalar load in flight during this step
-            if (i1 + 1 < n1) tab1n += a1_s;
+            if (i1 + 1 < i1e) tab1n += a1_s;
             c1n = tab1n[0].cell;
             t1n = tab1n[0].t;
         }
@@ -537,7 +545,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         // ---- results: parked in LDS, written out every kCsFlush steps ------------------------------------
         s_best[wave][slot][lane] = best;
         s_idx[wave][slot][lane] = (uint8_t)best_u;
-        if (slot == kCsFlush - 1 || i1 == n1 - 1) {
+        if (slot == kCsFlush - 1 || i1 == i1e - 1) {
             __builtin_amdgcn_wave_barrier();
             if (valid) {
                 const int first = i1 - slot;

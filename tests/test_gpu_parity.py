@@ -249,6 +249,15 @@ def test_colsweep_variant_bit_exact(env, n, nU, nonuniform, gax, cost, a1_amp, l
             o2 = bk.solve(3, terminal=term)
             assert np.array_equal(o2["J"], ref["J"]) and np.array_equal(o2["idx"], ref["idx"]), mod
         bk.set_option("cs_xcd_mod", 0)
+        auto_split = bk.get_option("cs_split")
+        assert auto_split >= 1
+        for parts in (1, 3, 8):                              # a column swept in several parts, each priming where it starts
+            bk.set_option("cs_split", parts)
+            assert bk.get_option("cs_split") == min(parts, n[1])
+            o5 = bk.solve(3, terminal=term)
+            assert np.array_equal(o5["J"], ref["J"]) and np.array_equal(o5["idx"], ref["idx"]), parts
+        bk.set_option("cs_split", 0)
+        assert bk.get_option("cs_split") == auto_split
         bk.set_option("cs_xcd_axis", 1)                      # the XCDs split the window axis instead of the group axis
         o4 = bk.solve(3, terminal=term)
         assert np.array_equal(o4["J"], ref["J"]) and np.array_equal(o4["idx"], ref["idx"])

@@ -41,11 +41,13 @@ for v in variants:
                 bk.set_option("cs_dpp", int(os.environ["CS_DPP"]))
             if os.environ.get("CS_XCD_AXIS"):
                 bk.set_option("cs_xcd_axis", int(os.environ["CS_XCD_AXIS"]))
+            if os.environ.get("CS_SPLIT"):
+                bk.set_option("cs_split", int(os.environ["CS_SPLIT"]))
             if os.environ.get("CS_COOP"):
                 bk.set_option("cs_coop", int(os.environ["CS_COOP"]))
             info = bk.info()
             if info["kernel_variant"] == 7:
-                print("variant 7: group axis %d, %d groups, dpp %d, coop %d, rows %d" % (bk.get_option("cs_group_axis"), bk.get_option("cs_groups"), bk.get_option("cs_dpp"), bk.get_option("cs_coop"), bk.get_option("cs_rows")))
+                print("variant 7: group axis %d, %d groups, dpp %d, coop %d, rows %d, split %d" % (bk.get_option("cs_group_axis"), bk.get_option("cs_groups"), bk.get_option("cs_dpp"), bk.get_option("cs_coop"), bk.get_option("cs_rows"), bk.get_option("cs_split")))
             bk.solve(2)
             out = bk.solve(stages)
     except hjbdp.HjbError as e:
