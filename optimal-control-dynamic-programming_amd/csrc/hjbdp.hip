@@ -1025,9 +1025,11 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
     return HJB_OK;
 }
 
-// Variant 7: in how many parts (waves) a column is swept (DColSweep::split).  Automatic: double it while the launch has
-// fewer waves than ~1.2 x the chip's 5120 wave slots and every part keeps >= 12 steps (a part starts by priming: one
-// step's worth of extra gathers) - a boundary strip of a multi-GPU slab (240 columns on C4) then lasts 15 steps, not 120.
+// Variant 7: in how many parts (waves) a column is swept (DColSweep::split).  Automatic: doubled while the launch stays
+// within three times the chip's 5120 wave slots (5 waves per SIMD) and every part keeps >= 12 steps (a part starts by
+// priming: about a step and a half of extra gathers).  Measured on one middle rank of an 8-GPU run of C4 (15 planes =
+// 3600 columns, profiles/r02_rank_slab_timing.log): 1 / 2 / 4 / 8 parts -> 0.270 / 0.249 / 0.233 / 0.235 ms per stage;
+// a boundary strip (240 columns) lasts 15 steps instead of 120; the whole grid (28800 columns) keeps one part.
 void colsweep_split(Handle *h) {
     const DParams &P = h->hp;
     DColSweep &CSh = h->hcs;
@@ -1038,7 +1040,7 @@ void colsweep_split(Handle *h) {
     int S = h->cs_split;
     if (S <= 0) {
         S = 1;
-        while (S < 8 && waves * S * 2 <= 6144 && n1 / (S * 2) >= 12) S *= 2;
+        while (S < 8 && waves * S * 2 <= 3 * 5120 && n1 / (S * 2) >= 12) S *= 2;
     }
     CSh.split = std::max(1, std::min(S, std::max(1, n1)));
 }

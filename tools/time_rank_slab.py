@@ -25,6 +25,10 @@ whole = hjbdp.Backup(spec, slab=(b, e, hl, hh))
 parts = [(hjbdp.Backup(spec, slab=(b + hl, e - hh, hl, hh)), hl, hl, own - hl - hh, hl, hh),     # interior: rows from hl (its own halo = owned planes)
          (hjbdp.Backup(spec, slab=(b, b + hl, hl, min(hh, own - hl))), 0, 0, hl, hl, min(hh, own - hl)),
          (hjbdp.Backup(spec, slab=(e - hh, e, min(hl, own - hh), hh)), own + hl - min(hl, own - hh) - hh, own - hh, hh, min(hl, own - hh), hh)]
+if os.environ.get("CS_SPLIT"):                        # CS_SPLIT=s forces the parts per column of every handle
+    for h in [whole] + [p[0] for p in parts]:
+        h.set_option("cs_split", int(os.environ["CS_SPLIT"]))
+print("parts per column: whole %d, interior %d, strips %d / %d" % tuple(h.get_option("cs_split") for h in [whole] + [p[0] for p in parts]))
 main = torch.cuda.current_stream(dev)
 side = [torch.cuda.Stream(device=dev) for _ in range(2)]
 
@@ -47,6 +51,6 @@ for name, fn in (("fused", fused), ("interior + strips in line", inline), ("stri
     for _ in range(3): fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(30): fn()
+    for _ in range(300): fn()
     torch.cuda.synchronize()
-    print("N=%d (%d owned planes, halo %d/%d): %-28s %.3f ms per stage" % (N, own, hl, hh, name, (time.perf_counter() - t0) / 30 * 1e3))
+    print("N=%d (%d owned planes, halo %d/%d): %-28s %.3f ms per stage" % (N, own, hl, hh, name, (time.perf_counter() - t0) / 300 * 1e3))
