@@ -203,7 +203,9 @@ int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
  * 1 groups, 2 axis 1 sees the window axis, 3 n0 / storage, 4 cells, 5 window knots, 6 axis-0 knots).  Settable (testing,
  * tuning): "cs_dpp", "cs_coop" (1: eight neighbouring columns share their corner rows through LDS, kernels_colcoop.h;
  * off by default - slower on C4), "cs_xcd_mod" (residue modulus of the column -> XCD assignment: 0/1 contiguous ranges,
- * -1 the group spacing), "cs_xcd_axis" (0: the XCDs split the group axis [default], 1: the window axis). */
+ * -1 the group spacing), "cs_xcd_axis" (0: the XCDs split the group axis [default], 1: the window axis), "cs_split" (parts
+ * a column is swept in - each by a wave of its own, priming where it starts; 0 = automatic: more parts for launches with
+ * few columns, e.g. the boundary strips of a multi-GPU slab; reads back the value in effect). */
 int32_t hjb_get_option(hjb_handle h, const char *key, int64_t *value);
 
 /* ONE backup, host buffers (exactly the MATLAB statement above):
