@@ -52,5 +52,6 @@ for name, fn in (("fused", fused), ("interior + strips in line", inline), ("stri
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(300): fn()
+    t_cpu = (time.perf_counter() - t0) / 300 * 1e3           # host time to enqueue one stage (the GPU may lag behind)
     torch.cuda.synchronize()
-    print("N=%d (%d owned planes, halo %d/%d): %-28s %.3f ms per stage" % (N, own, hl, hh, name, (time.perf_counter() - t0) / 300 * 1e3))
+    print("N=%d (%d owned planes, halo %d/%d): %-28s %.3f ms per stage (host enqueue %.3f)" % (N, own, hl, hh, name, (time.perf_counter() - t0) / 300 * 1e3, t_cpu))
