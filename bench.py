@@ -304,8 +304,9 @@ def main():
         "dtype": "f32" if spec.j_dtype.itemsize == 4 else "f32 (J stored as f16)", "data": "synthetic",
         "config": {"workload": head["name"], "states": spec.nS, "states_per_gpu": head["states_rank"], "controls": spec.nU,
                    "stages": args.steps,
-                   "sharding": ("last state axis (v): %d of %d planes per GPU, halo %d/%d planes exchanged per stage over RCCL%s"
+                   "sharding": ("last state axis (v): %d of %d planes per GPU, halo %d/%d planes (rank 0) exchanged per stage over %s%s"
                                 % (head["states_rank"] // (spec.nS // spec.n[-1]), spec.n[-1], head["halo"][0], head["halo"][1],
+                                   "RCCL" if args.backend == "nccl" else args.backend + " (test transport)",
                                    "" if args.no_overlap else ", overlapped with the interior planes")) if world > 1 else "none",
                    "kernel_variant": info["kernel_variant"]},
         "roofline": {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
