@@ -2317,6 +2317,140 @@ int32_t hjb_problem_set_model(hjb_builder b, int32_t model, double model_h, cons
     return HJB_OK;
 }
 
+// Relabel the state axes of a problem under construction: new axis i = old axis order[i].  Pure bookkeeping - which
+// axis is "last" decides which stage kernel applies, the order of the 1-D lerps and the axis a multi-GPU run shards -
+// but the term arrays are stored over their dims in ascending order, so a term over several state dims is transposed.
+// The caller permutes its own arrays the same way: MATLAB `permute(J, order + 1)` in, `ipermute` out.
+int32_t hjb_problem_permute_axes(hjb_builder b, const int32_t *order) {
+    if (!b || !order) return bfail(b, HJB_E_INVALID, "null argument");
+    hjb_problem &p = b->p;
+    const int D = p.D, C = p.C;
+    if (p.model != HJB_MODEL_NONE) return bfail(b, HJB_E_UNSUPPORTED, "a problem with a state model has a fixed axis labelling");
+    if (p.slab_begin || p.slab_end || p.halo_lo || p.halo_hi) return bfail(b, HJB_E_INVALID, "permute the axes before setting a slab");
+    int new_of_old[HJB_MAX_G], seen = 0;
+    for (int i = 0; i < D; ++i) {
+        if (order[i] < 0 || order[i] >= D || (seen >> order[i]) & 1) return bfail(b, HJB_E_INVALID, "order is not a permutation of 0..%d", D - 1);
+        seen |= 1 << order[i];
+        new_of_old[order[i]] = i;
+    }
+    for (int c = 0; c < C; ++c) new_of_old[D + c] = D + c;
+    int gn[HJB_MAX_G];                                           // old grid sizes of all dims
+    for (int a = 0; a < D; ++a) gn[a] = p.n[a];
+    for (int c = 0; c < C; ++c) gn[D + c] = p.m[c];
+    const size_t esz = p.dtype == HJB_F64 ? 8 : 4;
+    auto remap = [&](hjb_term &t) {
+        int od[HJB_MAX_G], k = 0;                                // the term's dims, ascending (old labels) = its storage order
+        for (int d = 0; d < D + C; ++d) if ((t.mask >> d) & 1u) od[k++] = d;
+        uint32_t nm = 0;
+        for (int i = 0; i < k; ++i) nm |= 1u << new_of_old[od[i]];
+        // storage position of old dim od[i] in the new array = rank of its new label
+        int pos[HJB_MAX_G];
+        for (int i = 0; i < k; ++i) {
+            pos[i] = 0;
+            for (int j = 0; j < k; ++j) pos[i] += new_of_old[od[j]] < new_of_old[od[i]];
+        }
+        bool same = true;
+        for (int i = 0; i < k; ++i) same = same && pos[i] == i;
+        t.mask = nm;
+        if (same) return;
+        std::vector<unsigned char> &blob = b->blobs[t.reserved - 1];
+        std::vector<unsigned char> out(blob.size());
+        int64_t nstride[HJB_MAX_G], sz[HJB_MAX_G];               // stride (elements) of old dim i in the new array
+        for (int i = 0; i < k; ++i) sz[i] = gn[od[i]];
+        for (int i = 0; i < k; ++i) {
+            nstride[i] = 1;
+            for (int j = 0; j < k; ++j) if (pos[j] < pos[i]) nstride[i] *= sz[j];
+        }
+        int64_t idx[HJB_MAX_G] = {0}, total = 1;
+        for (int i = 0; i < k; ++i) total *= sz[i];
+        for (int64_t e = 0; e < total; ++e) {                    // e walks the old array in storage order
+            int64_t o = 0;
+            for (int i = 0; i < k; ++i) o += idx[i] * nstride[i];
+            memcpy(&out[(size_t)o * esz], &blob[(size_t)e * esz], esz);
+            for (int i = 0; i < k; ++i) { if (++idx[i] < sz[i]) break; idx[i] = 0; }
+        }
+        blob.swap(out);
+    };
+    for (int a = 0; a < D; ++a)
+        for (int k = 0; k < p.n_next_terms[a]; ++k) remap(p.next_terms[a][k]);
+    for (int k = 0; k < p.n_cost_terms; ++k) remap(p.cost_terms[k]);
+    hjb_problem q = p;
+    std::vector<std::vector<double>> kn((size_t)D);
+    for (int i = 0; i < D; ++i) {
+        const int o = order[i];
+        q.n[i] = p.n[o];
+        q.n_next_terms[i] = p.n_next_terms[o];
+        for (int k = 0; k < HJB_MAX_TERMS; ++k) q.next_terms[i][k] = p.next_terms[o][k];
+        kn[(size_t)i] = b->knots[(size_t)o];
+    }
+    p = q;
+    b->knots.swap(kn);
+    return HJB_OK;
+}
+
+// A labelling of the state axes under which the column-sweep stage kernel applies (the pos-att shape: D = 4, one control
+// dim, two axes whose next value involves neither the control nor each other's state dim, two that involve their own
+// pair of dims and the control only), found from the terms' masks alone; of the two control-driven axes the one the
+// controls move less - the larger (next - own) range of its control-only terms over its mean knot spacing goes first -
+// comes last (its halo is the narrower one for a multi-GPU run).  order_out[i] = the present axis that becomes axis i;
+// *found = 0 and the identity when no labelling qualifies (or the present one already does).
+int32_t hjb_problem_suggest_order(hjb_builder b, int32_t *order_out, int32_t *found) {
+    if (!b || !order_out || !found) return bfail(b, HJB_E_INVALID, "null argument");
+    const hjb_problem &p = b->p;
+    const int D = p.D;
+    for (int i = 0; i < D; ++i) order_out[i] = i;
+    *found = 0;
+    if (D != 4 || p.C != 1 || p.model != HJB_MODEL_NONE) return HJB_OK;
+    uint32_t dom[4];
+    for (int a = 0; a < 4; ++a) {
+        dom[a] = 0;
+        for (int k = 0; k < p.n_next_terms[a]; ++k) dom[a] |= p.next_terms[a][k].mask;
+    }
+    const uint32_t cbit = 1u << 4;
+    auto spread = [&](int a) -> double {                         // range of the axis' control-only terms, in mean knot spacings
+        double lo = 0, hi = 0;
+        for (int k = 0; k < p.n_next_terms[a]; ++k) {
+            const hjb_term &t = p.next_terms[a][k];
+            if (t.mask != cbit) continue;
+            const std::vector<unsigned char> &bl = b->blobs[t.reserved - 1];
+            double tl = 0, th = 0;
+            for (int u = 0; u < p.m[0]; ++u) {
+                const double v = p.dtype == HJB_F64 ? ((const double *)bl.data())[u] : (double)((const float *)bl.data())[u];
+                tl = u == 0 ? v : std::min(tl, v);
+                th = u == 0 ? v : std::max(th, v);
+            }
+            lo += tl; hi += th;
+        }
+        const std::vector<double> &kn = b->knots[(size_t)a];
+        const double h = kn.size() > 1 ? (kn.back() - kn.front()) / (double)(kn.size() - 1) : 1.0;
+        return h > 0 ? (hi - lo) / h : 0.0;
+    };
+    int best[4] = {0, 1, 2, 3};
+    double best_score = 0;
+    int perm[4] = {0, 1, 2, 3};
+    do {
+        // new axis i = old axis perm[i]; an old dim d carries new label pos(d)
+        int pos[4];
+        for (int i = 0; i < 4; ++i) pos[perm[i]] = i;
+        auto relabel = [&](uint32_t m) { uint32_t r = m & cbit; for (int d = 0; d < 4; ++d) if ((m >> d) & 1u) r |= 1u << pos[d]; return r; };
+        const uint32_t d0 = relabel(dom[perm[0]]), d1 = relabel(dom[perm[1]]), d2 = relabel(dom[perm[2]]), d3 = relabel(dom[perm[3]]);
+        if ((d0 & (cbit | 2u)) || (d1 & (cbit | 1u)) || (d2 & 3u) || (d3 & 3u)) continue;
+        for (size_t a = 0; a < 4; ++a) if (b->knots[a].empty()) return bfail(b, HJB_E_INVALID, "set the knots before asking for an axis order");
+        // prefer: the less-moved control axis last; then the labelling closest to the present one
+        double score = spread(perm[2]) - spread(perm[3]);
+        int moved = 0;
+        for (int i = 0; i < 4; ++i) moved += perm[i] != i;
+        score -= 1e-6 * moved;
+        if (!*found || score > best_score) { best_score = score; for (int i = 0; i < 4; ++i) best[i] = perm[i]; *found = 1; }
+    } while (std::next_permutation(perm, perm + 4));
+    if (*found) {
+        bool ident = true;
+        for (int i = 0; i < 4; ++i) { order_out[i] = best[i]; ident = ident && best[i] == i; }
+        if (ident) *found = 0;
+    }
+    return HJB_OK;
+}
+
 static int builder_bind(hjb_builder b, hjb_problem *out) {      // the builder's problem with its pointers bound
     hjb_problem p = b->p;
     for (int a = 0; a < p.D; ++a) {

@@ -141,6 +141,8 @@ SYMBOLS = {
     "hjb_problem_add_cost_term": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]),
     "hjb_problem_set_slab": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hjb_problem_set_model": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_problem_permute_axes": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "hjb_problem_suggest_order": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hjb_create_from": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "hjb_problem_free": (C.c_int32, [C.c_void_p]),
     "hjb_problem_last_error": (C.c_char_p, [C.c_void_p]),

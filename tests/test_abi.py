@@ -95,6 +95,62 @@ def test_flat_builder_validates_without_a_gpu(lib):
     assert lib.hjb_problem_free(None) == _abi.HJB_OK
 
 
+def _builder_from_spec(lib, spec):
+    """A ProblemSpec through the flat builder calls (float32 / float64 arithmetic, no model)."""
+    from hjbdp import _abi
+    b = C.c_void_p()
+    n = (C.c_int32 * spec.D)(*spec.n)
+    m = (C.c_int32 * spec.C)(*spec.m)
+    dt = _abi.HJB_F64 if spec.dtype == np.float64 else _abi.HJB_F32
+    assert lib.hjb_problem_new(spec.D, spec.C, n, m, dt, spec.index_base, C.byref(b)) == _abi.HJB_OK
+    for a in range(spec.D):
+        k = np.ascontiguousarray(spec.knots[a], dtype=np.float64)
+        assert lib.hjb_problem_set_knots(b, a, k.ctypes.data_as(C.POINTER(C.c_double)), k.size) == _abi.HJB_OK
+    def flat(t):
+        mask = sum(1 << d for d in t.dims)
+        v = np.ascontiguousarray(np.asarray(t.data, dtype=spec.dtype).reshape(-1, order="F"))
+        return mask, v
+    for a in range(spec.D):
+        for t in spec.next_terms[a]:
+            mask, v = flat(t)
+            assert lib.hjb_problem_add_next_term(b, a, mask, v.ctypes.data, v.size) == _abi.HJB_OK
+    for t in spec.cost_terms:
+        mask, v = flat(t)
+        assert lib.hjb_problem_add_cost_term(b, mask, v.ctypes.data, v.size) == _abi.HJB_OK
+    return b
+
+
+def test_flat_builder_suggests_the_fast_axis_order_for_pos_att(lib):
+    """hjb_problem_suggest_order on the reference's own Solver_pos_att channel (axes x, v, theta, w as
+    Solver_pos_att.m:299-328 builds them): the labelling of the column-sweep kernel, (x, theta, w, v) = old axes
+    (0, 2, 3, 1) - what hjbdp.Solver_pos_att.FAST_AXIS_ORDER + the bench use; nothing to suggest for a problem that is
+    already labelled that way, for Kirk's 2-D problem, or when every axis moves with the control.  No GPU involved."""
+    import hjbdp
+    from hjbdp import _abi
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = "terms"
+    sx, sv, st, sw = pa.grids()
+    spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1,
+                                    pa.Qw1, pa.R1, pa.J2)
+    b = _builder_from_spec(lib, spec)
+    order = (C.c_int32 * 4)()
+    found = C.c_int32(-1)
+    assert lib.hjb_problem_suggest_order(b, order, C.byref(found)) == _abi.HJB_OK
+    assert found.value == 1 and tuple(order) == (0, 2, 3, 1)
+    assert lib.hjb_problem_permute_axes(b, order) == _abi.HJB_OK
+    assert lib.hjb_problem_suggest_order(b, order, C.byref(found)) == _abi.HJB_OK
+    assert found.value == 0 and tuple(order) == (0, 1, 2, 3)                  # already labelled that way
+    bad = (C.c_int32 * 4)(0, 1, 1, 3)
+    assert lib.hjb_problem_permute_axes(b, bad) == _abi.HJB_E_INVALID and b"permutation" in lib.hjb_problem_last_error(b)
+    assert lib.hjb_problem_set_slab(b, 2, 5, 1, 1) == _abi.HJB_OK
+    assert lib.hjb_problem_permute_axes(b, (C.c_int32 * 4)(0, 1, 2, 3)) == _abi.HJB_E_INVALID       # after a slab: refused
+    assert lib.hjb_problem_free(b) == _abi.HJB_OK
+    from problems import random_problem
+    b2 = _builder_from_spec(lib, random_problem(3, (5, 4, 3, 4), (3,), dtype=np.float32))   # every axis sees the control
+    assert lib.hjb_problem_suggest_order(b2, order, C.byref(found)) == _abi.HJB_OK and found.value == 0
+    assert lib.hjb_problem_free(b2) == _abi.HJB_OK
+
+
 def _prototypes(text):
     """name -> normalised parameter-type list of every hjb_* prototype in a header."""
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)

@@ -3,6 +3,9 @@ arrays only - what loadlibrary/calllib can marshal) and the pr
 test/Dynamic_Solver.m:212-219)."""
 import ctypes as C
 
+import sys
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -78,6 +81,40 @@ def test_kirk_fixture_through_the_flat_api_only(env, golden):
         out = bk.solve(n_st, keep_J=True)
     if np.array_equal(ds.s_r, s_r):
         assert np.array_equal(out["J_stages"], Js)
+
+
+def test_flat_permute_axes_equals_the_python_relabelling(env):
+    """hjb_problem_permute_axes (what a MATLAB host calls after hjb_problem_suggest_order): a problem with terms over
+    one, two and three state dims relabelled in C solves to the same bits as the Python relabelling of the same problem
+    - and to the original problem's result with J permuted back."""
+    hjbdp, _abi, c_oracle = env
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_abi import _builder_from_spec
+    from problems import random_problem, random_terminal
+    lib = hjbdp.load_library()
+    spec = random_problem(21, (6, 5, 7, 4), (3, 2), dtype=np.float32, spread=0.3)
+    order = (2, 0, 3, 1)
+    pspec, to_old = hjbdp.permute_state_axes(spec, order)
+    term = random_terminal(spec, 3)
+    pterm = np.transpose(term.reshape(spec.n, order="F"), order).reshape(-1, order="F")
+    ref = c_oracle.sweep(_abi, spec, 3, terminal=term)
+    b = _builder_from_spec(lib, spec)
+    assert lib.hjb_problem_permute_axes(b, (C.c_int32 * 4)(*order)) == _abi.HJB_OK
+    h = C.c_void_p()
+    assert lib.hjb_create_from(b, 0, C.byref(h)) == _abi.HJB_OK, lib.hjb_problem_last_error(b)
+    assert lib.hjb_problem_free(b) == _abi.HJB_OK
+    nS = spec.nS
+    Jf, If = np.zeros(nS, dtype=np.float32), np.zeros(nS, dtype=np.int32)
+    done, early, ms = C.c_int32(), C.c_int32(), C.c_double()
+    pt = np.ascontiguousarray(pterm, dtype=np.float32)
+    st = lib.hjb_solve_flat(h, 3, 0, 0.0, pt.ctypes.data, Jf.ctypes.data, If.ctypes.data, None, None, C.byref(done), C.byref(early), C.byref(ms))
+    assert st == _abi.HJB_OK, lib.hjb_last_error(h)
+    lib.hjb_destroy(h)
+    with hjbdp.Backup(pspec) as bk:
+        out = bk.solve(3, terminal=pterm)
+    assert np.array_equal(Jf, out["J"]) and np.array_equal(If, out["idx"])          # C relabelling == Python relabelling
+    # the order of the 1-D lerps follows the labelling: against the original problem's sweep equal to rounding only
+    assert np.allclose(to_old(Jf), ref["J"], rtol=2e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("precision", ["single", "double"])
