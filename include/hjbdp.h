@@ -264,10 +264,13 @@ int32_t hjb_problem_set_model(hjb_builder b, int32_t model, double model_h, cons
  * the caller permutes its own arrays the same way (MATLAB: permute(J, order + 1) in, ipermute out).  Before
  * hjb_problem_set_slab; not for problems with a state model. */
 int32_t hjb_problem_permute_axes(hjb_builder b, const int32_t *order);
-/* A labelling under which the column-sweep stage kernel applies (the pos-att shape, Solver_pos_att.m:299-328: the two
- * axes the thrusters do not drive first, of the other two the less-moved one last), from the terms' masks and the
- * control terms' ranges: order_out[D], *found = 1 when it differs from the present labelling (else the identity, 0).
- * 120^4 x 9: 1.8 ms per stage under it against 6.7 ms in the reference's own order (x, v, theta, w). */
+/* A labelling under which a faster stage kernel applies, from the terms' masks (and, for D = 4 with one control dim, the
+ * control terms' ranges): order_out[D], *found = 1 when it differs from the present labelling (else the identity, 0).
+ * D = 4, C = 1: the column-sweep kernel's shape (Solver_pos_att.m:299-328: the two axes the thrusters do not drive
+ * first, of the other two the less-moved one last; 120^4 x 9: 1.8 ms per stage against 6.7 ms in the reference's own
+ * order (x, v, theta, w)).  Otherwise: the axes no control drives first, then the driven ones in the order of the
+ * control dims (Solver_attitude.m's (w1, w2, w3, yaw, pitch, roll) -> (yaw, pitch, roll, w1, w2, w3): 4.4 ms against
+ * 28 ms on the reference grid). */
 int32_t hjb_problem_suggest_order(hjb_builder b, int32_t *order_out, int32_t *found);
 int32_t hjb_create_from(hjb_builder b, int32_t device, hjb_handle *out);
 int32_t hjb_problem_free(hjb_builder b);

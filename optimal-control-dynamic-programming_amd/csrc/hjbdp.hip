@@ -2388,7 +2388,8 @@ int32_t hjb_problem_permute_axes(hjb_builder b, const int32_t *order) {
     return HJB_OK;
 }
 
-// A labelling of the state axes under which the column-sweep stage kernel applies (the pos-att shape: D = 4, one control
+// A labelling of the state axes under which a faster stage kernel applies.  D = 4 with one control dim: the one under
+// which the column-sweep stage kernel applies (the pos-att shape: D = 4, one control
 // dim, two axes whose next value involves neither the control nor each other's state dim, two that involve their own
 // pair of dims and the control only), found from the terms' masks alone; of the two control-driven axes the one the
 // controls move less - the larger (next - own) range of its control-only terms over its mean knot spacing goes first -
@@ -2400,11 +2401,32 @@ int32_t hjb_problem_suggest_order(hjb_builder b, int32_t *order_out, int32_t *fo
     const int D = p.D;
     for (int i = 0; i < D; ++i) order_out[i] = i;
     *found = 0;
-    if (D != 4 || p.C != 1 || p.model != HJB_MODEL_NONE) return HJB_OK;
-    uint32_t dom[4];
-    for (int a = 0; a < 4; ++a) {
+    if (p.model != HJB_MODEL_NONE) return HJB_OK;
+    uint32_t dom[HJB_MAX_D];
+    for (int a = 0; a < D; ++a) {
         dom[a] = 0;
         for (int k = 0; k < p.n_next_terms[a]; ++k) dom[a] |= p.next_terms[a][k].mask;
+    }
+    if (D != 4 || p.C != 1) {
+        // The general rule of the fast kernels (control-nested, packed): axes the controls do not drive first (they are
+        // contracted once per state), then the driven axes in the order of the control loops, the axis of the innermost
+        // control dim last (Solver_attitude.m's (w1, w2, w3, yaw, pitch, roll) becomes (yaw, pitch, roll, w1, w2, w3):
+        // 4.4 instead of 28 ms on the reference grid).  A stable sort: axes of equal rank keep their order.
+        int key[HJB_MAX_D];
+        for (int a = 0; a < D; ++a) {
+            key[a] = 0;
+            for (int c = 0; c < p.C; ++c) if ((dom[a] >> (D + c)) & 1u) key[a] = 1 + c;
+        }
+        int ord[HJB_MAX_D];
+        for (int i = 0; i < D; ++i) ord[i] = i;
+        std::stable_sort(ord, ord + D, [&](int x, int y) { return key[x] < key[y]; });
+        bool ident = true;
+        for (int i = 0; i < D; ++i) ident = ident && ord[i] == i;
+        if (!ident) {
+            for (int i = 0; i < D; ++i) order_out[i] = ord[i];
+            *found = 1;
+        }
+        return HJB_OK;
     }
     const uint32_t cbit = 1u << 4;
     auto spread = [&](int a) -> double {                         // range of the axis' control-only terms, in mean knot spacings

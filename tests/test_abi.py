@@ -145,6 +145,15 @@ def test_flat_builder_suggests_the_fast_axis_order_for_pos_att(lib):
     assert lib.hjb_problem_set_slab(b, 2, 5, 1, 1) == _abi.HJB_OK
     assert lib.hjb_problem_permute_axes(b, (C.c_int32 * 4)(0, 1, 2, 3)) == _abi.HJB_E_INVALID       # after a slab: refused
     assert lib.hjb_problem_free(b) == _abi.HJB_OK
+    # Solver_attitude.run's 6-D problem in the reference's dim order (w1, w2, w3, yaw, pitch, roll): angles first, the
+    # rates in the order of their torques - what the mirror's AXIS_ORDER applies
+    sa = hjbdp.Solver_attitude()
+    sa.n_mesh_w, sa.n_mesh_q = 4, 5
+    b3 = _builder_from_spec(lib, sa.build_spec_full())
+    o6 = (C.c_int32 * 6)()
+    assert lib.hjb_problem_suggest_order(b3, o6, C.byref(found)) == _abi.HJB_OK
+    assert found.value == 1 and tuple(o6) == tuple(hjbdp.Solver_attitude.AXIS_ORDER) == (3, 4, 5, 0, 1, 2)
+    assert lib.hjb_problem_free(b3) == _abi.HJB_OK
     from problems import random_problem
     b2 = _builder_from_spec(lib, random_problem(3, (5, 4, 3, 4), (3,), dtype=np.float32))   # every axis sees the control
     assert lib.hjb_problem_suggest_order(b2, order, C.byref(found)) == _abi.HJB_OK and found.value == 0
