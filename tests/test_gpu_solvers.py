@@ -342,6 +342,44 @@ def test_c4_c5_full_size_colsweep_plane_vs_oracle(env, j_storage):
         assert np.array_equal(io, idx.reshape(n3, 120, order="F")[:, p]), p
 
 
+def test_c4_bench_order_as_eight_slabs_full_size(env):
+    """BASELINE configs[3] as bench.py runs it - pos-att 120^4 x 9, axes (x, theta, w, v), the last axis v sharded - in
+    its 8-GPU form on the one GPU of the box: hjb_solve_multi with eight slabs of 15 planes (halo of ONE plane each way,
+    interior + boundary strips on their own streams, columns swept in parts) equals the whole-grid sweep bit for bit
+    over two stages, and planes of the first stage equal the oracle's (both edges, a slab boundary, the interior)."""
+    hjbdp, _abi, c_oracle = env
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = "terms"
+    pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = 120
+    sx, sv, st, sw = pa.grids()
+    spec0, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                     pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    spec, _ = hjbdp.permute_state_axes(spec0, (0, 2, 3, 1))
+    assert spec.n == (120, 120, 120, 120)
+    X, T, W = np.meshgrid(sx, st[0], sw, indexing="ij")
+    inner = (np.sin(7 * X) + 10.0 * W ** 2 + np.cos(5 * T)).astype(np.float32).reshape(-1, order="F")
+    term = (inner[:, None] * (1.0 + 3.0 * sv[None, :] ** 2).astype(np.float32)).astype(np.float32)          # [120^3, 120]
+    n3 = 120 ** 3
+    with hjbdp.Backup(spec) as bk:
+        need = bk.info()
+        assert need["kernel_variant"] == 7 and need["halo_needed_lo"] == 1 and need["halo_needed_hi"] == 1
+        J1, i1 = bk.backup_stage(term.reshape(-1, order="F"))
+        whole = bk.solve(2, terminal=term.reshape(-1, order="F"))
+    for p in (0, 14, 15, 64, 119):
+        lo, hi = min(1, p), min(1, 119 - p)
+        sub = np.asfortranarray(term[:, p - lo:p + 1 + hi]).reshape(-1, order="F")
+        Jo, io = c_oracle.backup_stage(_abi, spec, sub, slab=(p, p + 1, lo, hi))
+        assert np.array_equal(Jo.reshape(n3, -1, order="F")[:, lo], J1.reshape(n3, 120, order="F")[:, p]), p
+        assert np.array_equal(io, i1.reshape(n3, 120, order="F")[:, p]), p
+    del J1, i1
+    with hjbdp.MultiBackup(spec, [0] * 8) as mb:
+        infos = [mb.slab_info(i) for i in range(8)]
+        multi = mb.solve(2, terminal=term.reshape(-1, order="F"))
+    assert [i["end"] - i["begin"] for i in infos] == [15] * 8 and all(i["split"] for i in infos)
+    assert infos[3]["halo_lo"] == 1 and infos[3]["halo_hi"] == 1
+    assert np.array_equal(multi["J"], whole["J"]) and np.array_equal(multi["idx"], whole["idx"])
+
+
 def test_solver_position_closed_loop_rollout(env):
     """Solver_position.get_optimal_path (:189-311): the policies of simplified_run fly the chaser from 1 km behind
     the target towards it: full positive thrust first (x = -1 lies below the grid: 'nearest' clamps to its edge),
