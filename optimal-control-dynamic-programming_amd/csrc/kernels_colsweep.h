@@ -25,18 +25,27 @@
 // control cost and control number are wave-uniform plan data parked in LDS for the column.  The kernel is a template
 // over the number of groups NG (the maximum over the plans; plans with fewer are padded with member-less groups) and
 // straight-line over groups, rows and slots: the rolling A values sit in registers with static indices.  Groups are
-// visited in plan order, not control order, so a slot visited after a higher-numbered control compares (value, control
-// number) lexicographically: the first-index-wins rule of MATLAB's min holds exactly.
+// visited in plan order, not control order.
+// Slots of a pair are filled from its first one, so a pair's first slot test is the pair's test and an empty slot ends
+// it; a window knot no slot uses (26 of 30 rows remain on C4) is neither gathered nor lerped; a slot visited after a
+// higher-numbered control takes over a TIE first (first index wins, exactly as MATLAB's min).
 //
-// The two axis-0 neighbours (c0, c0 + 1) of a corner row: the L1 path (64 B per clock per CU) is what bounds this
-// kernel (profiles/r02_c4_colsweep_v1_pmc.json: TA busy 87 %), and the two loads of a pair hit the same cache lines.
+// The two axis-0 neighbours (c0, c0 + 1) of a corner row: the first version loaded both (profiles/
+// r02_c4_colsweep_v1_pmc.json: TA busy 87 %, 2.74 ms per stage), and the two loads of a pair hit the same cache lines.
 // One-load form (template DPP, chosen on the host when every wave's axis-0 cells satisfy it): a wave carries 60 states,
-// lane L loads knot kb + L ONCE, and a state's neighbours are the values of lanes L and L + 1, moved by DPP
-// `wave_shl:1` (lane 60 is the halo loader).  A wave with ONE state whose cell sits elsewhere (grid-edge clamping: half
-// of C4's waves) gives that state the spare lane pair 61, 62, so every state lane stays regular; with several, lanes
-// select between (L, L + 1) and (L + 1, L + 2).
-// (Fetching them through the LDS crossbar, ds_bpermute_b32, which takes no vector-ALU slot, was measured slower:
-// 2.90 vs 2.67 ms per stage on C4.)  Same values, same arithmetic: bit-identical to every other variant.
+// lane L loads knot kb + L ONCE, and a state's upper neighbour is lane L + 1's value, taken as the DPP operand of the
+// subtraction (`v_sub_f32_dpp ... wave_shl:1`; lane 60 is the halo loader).  A wave with ONE state whose cell sits
+// elsewhere (grid-edge clamping: half of C4's waves) gives that state the spare lane pair 61, 62, so every state lane
+// is regular; the host admits the form when no 60-state chunk has more than one such state.
+// (Fetching the neighbour through the LDS crossbar, ds_bpermute_b32, was measured slower: 2.90 vs 2.67 ms at the time.)
+//
+// The rest of the schedule, each step of it measured (profiles/r02_c4_experiments.log): gathers issued
+// and awaited by hand in two halves of the group sequence (counted s_waitcnt through a computed jump); results parked
+// in LDS and written out every 20 steps; the four waves of a workgroup - neighbours on the group axis - take every
+// step together (s_barrier) so that they share L1 lines; a launch with few columns (a multi-GPU slab, its boundary
+// strips, a small grid) sweeps each column in several parts, one wave each (DColSweep::split); workgroup b serves XCD
+// b % 8.  C4 (120^4 x 9, float32): 1.81 ms per stage = 1.03e12 backups/s.  Same values, same arithmetic as every
+// other variant: bit-identical results.
 #pragma once
 #include "hjbdp_dev.h"
 #include "kernels_generic.h"
