@@ -28,10 +28,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
         }                                                                                          \
     } while (0)
 
-enum Op { FMA = 0, PKFMA, MIN3, ADD, CNDMASK, DPPMOV, FMA_SALU, FMA_SGPR, PKADD, MUL, NOPS };
+enum Op { FMA = 0, PKFMA, MIN3, ADD, CNDMASK, DPPMOV, FMA_SALU, FMA_SGPR, PKADD, MUL, DPPMOV_ROW, SUBDPP_WAVE, SUBDPP_ROW, SUB, NOPS };
 static const char *kOpName[] = {"v_fma_f32", "v_pk_fma_f32", "v_min3_f32", "v_add_f32", "v_cndmask_b32 (SGPR-pair mask)",
                                 "v_mov_b32_dpp(wave_shl:1)", "v_fma_f32 + s_add_u32 (1:1)", "v_fma_f32 (SGPR operand)",
-                                "v_pk_add_f32", "v_mul_f32"};
+                                "v_pk_add_f32", "v_mul_f32", "v_mov_b32_dpp(row_shl:1)", "v_sub_f32_dpp(wave_shl:1)",
+                                "v_sub_f32_dpp(row_shl:1)", "v_sub_f32"};
 
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
@@ -86,6 +87,22 @@ __global__ void __launch_bounds__(256) k_rate(float *out, int iters, unsigned lo
 #undef X
         } else if (OP == DPPMOV) {
 #define X(i) asm volatile("v_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+            REP16(X)
+#undef X
+        } else if (OP == DPPMOV_ROW) {
+#define X(i) asm volatile("v_mov_b32_dpp %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+            REP16(X)
+#undef X
+        } else if (OP == SUBDPP_WAVE) {
+#define X(i) asm volatile("v_sub_f32_dpp %0, %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(c));
+            REP16(X)
+#undef X
+        } else if (OP == SUBDPP_ROW) {
+#define X(i) asm volatile("v_sub_f32_dpp %0, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(c));
+            REP16(X)
+#undef X
+        } else if (OP == SUB) {
+#define X(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
             REP16(X)
 #undef X
         } else if (OP == FMA_SALU) {
@@ -190,6 +207,10 @@ int main() {
     sweep<MIN3>(iters, dout, dcyc, ncu, json);
     sweep<CNDMASK>(iters, dout, dcyc, ncu, json);
     sweep<DPPMOV>(iters, dout, dcyc, ncu, json);
+    sweep<DPPMOV_ROW>(iters, dout, dcyc, ncu, json);
+    sweep<SUBDPP_WAVE>(iters, dout, dcyc, ncu, json);
+    sweep<SUBDPP_ROW>(iters, dout, dcyc, ncu, json);
+    sweep<SUB>(iters, dout, dcyc, ncu, json);
     sweep<FMA_SGPR>(iters, dout, dcyc, ncu, json);
     sweep<FMA_SALU>(iters, dout, dcyc, ncu, json);
     json.erase(json.size() - 2, 1);   // last comma
