@@ -131,7 +131,9 @@ class ShardedSweep:
                     sub(e - hi_w, e, min(need_lo, (e - hi_w) - b), self.halo_hi)
                 self._comm_stream = torch.cuda.Stream(device=self.device)
                 self._strip_streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+                self._halo_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self.stage_fn = stage_fn
+        self._halo_ops = {}
         # what my neighbours need from me
         self.up_needs = min(need_lo, self.end) if self.rank < world - 1 else 0     # my top planes -> rank+1's lower halo
         self.dn_needs = min(need_hi, nl - self.begin) if self.rank > 0 else 0      # my bottom planes -> rank-1's upper halo
@@ -176,22 +178,27 @@ class ShardedSweep:
             return []
         import torch.distributed as dist
         J = self.J[self.cur]
-        ops, keep = [], []
-        lo0 = self.halo_lo
-        if self.rank > 0:
-            if self.dn_needs:
-                s = J[lo0:lo0 + self.dn_needs].contiguous()
-                keep.append(s)
-                ops.append(dist.P2POp(dist.isend, s, self.rank - 1, group=self.group))
-            if self.halo_lo:
-                ops.append(dist.P2POp(dist.irecv, J[0:self.halo_lo], self.rank - 1, group=self.group))
-        if self.rank < self.world - 1:
-            if self.up_needs:
-                s = J[lo0 + self.owned - self.up_needs:lo0 + self.owned].contiguous()
-                keep.append(s)
-                ops.append(dist.P2POp(dist.isend, s, self.rank + 1, group=self.group))
-            if self.halo_hi:
-                ops.append(dist.P2POp(dist.irecv, J[lo0 + self.owned:], self.rank + 1, group=self.group))
+        cached = self._halo_ops.get(self.cur)           # the two J buffers never move: their send / receive views are built once
+        if cached is None:
+            ops, keep = [], []
+            lo0 = self.halo_lo
+            if self.rank > 0:
+                if self.dn_needs:
+                    s = J[lo0:lo0 + self.dn_needs]          # whole planes of a [planes, inner] buffer: contiguous views
+                    keep.append(s)
+                    ops.append(dist.P2POp(dist.isend, s, self.rank - 1, group=self.group))
+                if self.halo_lo:
+                    ops.append(dist.P2POp(dist.irecv, J[0:self.halo_lo], self.rank - 1, group=self.group))
+            if self.rank < self.world - 1:
+                if self.up_needs:
+                    s = J[lo0 + self.owned - self.up_needs:lo0 + self.owned]
+                    keep.append(s)
+                    ops.append(dist.P2POp(dist.isend, s, self.rank + 1, group=self.group))
+                if self.halo_hi:
+                    ops.append(dist.P2POp(dist.irecv, J[lo0 + self.owned:], self.rank + 1, group=self.group))
+            assert all(o.tensor.is_contiguous() for o in ops)
+            cached = self._halo_ops[self.cur] = (ops, keep)
+        ops, keep = cached
         if ops:
             if J.is_cuda and dist.get_backend(self.group) == "gloo":
                 # test-only transport (several ranks sharing one GPU): gloo moves host memory
@@ -228,6 +235,10 @@ class ShardedSweep:
             self._comm_stream.wait_stream(main)            # the previous stage's output is the data to send
             with t.cuda.stream(self._comm_stream):
                 works = self.exchange_halos(wait=False)
+                for w in works:
+                    w.wait()                               # the copy stream waits for the transfers ...
+                halo_ev = self._halo_ev[self.cur]
+                halo_ev.record(self._comm_stream)          # ... and one event tells the strip streams
             # the boundary strips run on streams of their own, beside the interior: a strip is a few hundred waves, but
             # every launch of the column-sweep kernel lasts at least one column (~0.2 ms) - in line behind the interior
             # two strips would cost more than the exchange they hide
@@ -237,8 +248,7 @@ class ShardedSweep:
             self._hip_part(0, J_in, J_out, self.idx)       # interior: independent of the halos
             for i, s in strips:
                 with t.cuda.stream(s):
-                    for w in works:
-                        w.wait()                           # this stream waits for the transfers
+                    s.wait_event(halo_ev)                  # the halos have landed
                     self._hip_part(i, J_in, J_out, self.idx)
             for _, s in strips:
                 main.wait_stream(s)
