@@ -64,7 +64,9 @@ def build_spec(workload, n_last=None, n=120):
             sv = sym_linspace_pos_att(pa.v_min * n_last / float(n), pa.v_max * n_last / float(n), n_last)
         spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
                                         pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
-        spec, _ = hjbdp.permute_state_axes(spec, (0, 2, 3, 1))            # (x, theta, w, v): v last = the sharded axis
+        order = hjbdp.suggest_axis_order(spec)                            # what the library proposes for the reference's (x, v, theta, w):
+        assert order == (0, 2, 3, 1), order                              # (x, theta, w, v) - v last = the sharded axis
+        spec, _ = hjbdp.permute_state_axes(spec, order)
         if workload == "c5":
             spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32,
                                      index_base=1, j_storage=np.float16)

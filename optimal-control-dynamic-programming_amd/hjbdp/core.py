@@ -332,6 +332,38 @@ class MultiBackup:
                 "sweep_ms": res.sweep_ms, "last_e": res.last_e, "last_e2": res.last_e2}
 
 
+def suggest_axis_order(spec):
+    """The labelling of the state axes under which the library runs its fastest stage kernel on `spec`
+    (hjb_problem_suggest_order, the call a MATLAB host makes through matlab/hjbdp_solve.m): a tuple for
+    `permute_state_axes`, or None when there is nothing to gain.  Needs the library, not a GPU."""
+    lib = load_library()
+    if spec.model is not None:
+        return None
+    b = C.c_void_p()
+    n = (C.c_int32 * spec.D)(*spec.n)
+    m = (C.c_int32 * spec.C)(*spec.m)
+    dt = _abi.HJB_F64 if spec.dtype == np.float64 else _abi.HJB_F32
+
+    def ok(st):
+        if st != _abi.HJB_OK:
+            msg = lib.hjb_problem_last_error(b)
+            raise HjbError(st, (msg or b"").decode())
+    ok(lib.hjb_problem_new(spec.D, spec.C, n, m, dt, spec.index_base, C.byref(b)))
+    try:
+        for a in range(spec.D):
+            k = np.ascontiguousarray(spec.knots[a], dtype=np.float64)
+            ok(lib.hjb_problem_set_knots(b, a, k.ctypes.data_as(C.POINTER(C.c_double)), k.size))
+            for t in spec.next_terms[a]:
+                v = np.ascontiguousarray(np.asarray(t.data, dtype=spec.dtype).reshape(-1, order="F"))
+                ok(lib.hjb_problem_add_next_term(b, a, sum(1 << d for d in t.dims), v.ctypes.data, v.size))
+        order = (C.c_int32 * spec.D)()
+        found = C.c_int32(0)
+        ok(lib.hjb_problem_suggest_order(b, order, C.byref(found)))
+        return tuple(order) if found.value else None
+    finally:
+        lib.hjb_problem_free(b)
+
+
 def solve_many(specs, n_stages, device=0, **solve_kw):
     """Independent sweeps (the three axis channels of Solver_position / Solver_attitude.simplified_run, the four
     runs of Solver_pos_att.simplified_run) in flight together: one handle and one host thread per sweep, each on

@@ -276,3 +276,26 @@ def test_rollout_kinematics_invariants():
     f = np.zeros(12); f[0] = 0.13
     U_M, acc = pa.to_Moments_Forces(f, R0, V0, np.array([0.0, 0.0, 0.0, 1.0]))
     assert np.allclose(U_M, [0.0, 0.13 * pa.T_dist, 0.0])
+
+
+def test_suggest_axis_order_matches_the_mirrors(built):
+    """hjbdp.suggest_axis_order (hjb_problem_suggest_order through the flat builder, no GPU): the labelling the library
+    proposes equals the one the mirrors apply by hand - Solver_pos_att.FAST_AXIS_ORDER up to the choice of the last axis
+    (the bench's (x, theta, w, v)), Solver_attitude.AXIS_ORDER - and nothing is proposed for Kirk's 2-D problem."""
+    import numpy as np
+    import hjbdp
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = "terms"
+    sx, sv, st, sw = pa.grids()
+    spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1,
+                                    pa.Qw1, pa.R1, pa.J2)
+    order = hjbdp.suggest_axis_order(spec)
+    assert order == (0, 2, 3, 1) and set(order[:2]) == set(hjbdp.Solver_pos_att.FAST_AXIS_ORDER[:2])
+    pspec, _ = hjbdp.permute_state_axes(spec, order)
+    assert hjbdp.suggest_axis_order(pspec) is None
+    sa = hjbdp.Solver_attitude()
+    sa.n_mesh_w, sa.n_mesh_q = 4, 5
+    assert hjbdp.suggest_axis_order(sa.build_spec_full()) == hjbdp.Solver_attitude.AXIS_ORDER
+    ds = hjbdp.Dynamic_Solver(precision="double")
+    ds.N, ds.dx, ds.du = 5, 7, 9
+    assert hjbdp.suggest_axis_order(ds.build_spec()) is None
