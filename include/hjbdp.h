@@ -83,7 +83,11 @@ typedef struct hjb_problem {
     /* stage cost g = ordered sum of terms (g_D Dynamic_Solver.m:196-200;
        J_current_reshaped Solver_pos_att.m:784-802; ...)                       */
     int32_t n_cost_terms;
-    int32_t reserved0;
+    int32_t idx_dtype;              /* storage type of the argmin labels (idx_final, idx_stages, d_idx_out):
+                                       HJB_IDX_I32 (0, default), HJB_IDX_U8, HJB_IDX_U16, or HJB_IDX_AUTO = the narrowest
+                                       that holds nU - 1 + index_base (MATLAB's U_Optimal_id of Solver_pos_att.m:272
+                                       carries 9 distinct values: one byte per state instead of four); the width in
+                                       effect is hjb_info.idx_bytes */
     hjb_term cost_terms[HJB_MAX_TERMS];
     /* Slab decomposition along the LAST state axis (multi-GPU; all four zero =
        whole grid).  The handle owns planes [slab_begin, slab_end) and every J
@@ -99,10 +103,27 @@ typedef struct hjb_problem {
        nS-sized next-angle tables, which do not fit at 51^6.  atan2/asin use the library's own
        fixed polynomial forms, so that results are reproducible bit for bit across CPUs/GPUs. */
     int32_t model;
-    int32_t reserved1;
+    int32_t table_dtype;            /* HJB_TAB_DEFAULT (0): next-state terms are arrays of the problem dtype and the
+                                       queries are formed, located and weighted in it.  HJB_TAB_F64 (dtype HJB_F32 /
+                                       HJB_F16S only): the data of every next_terms entry are float64 - the reference's
+                                       pos-att typing (Solver_pos_att.m:299-327 keeps x_next .. w_next in double while
+                                       F_gI.Values is single, :264-265): each query is summed in double, its cell is found
+                                       on the float64 knots, its weight (q - k[c]) * (1 / (k[c+1] - k[c])) is formed in
+                                       double and rounded to float32 ONCE; the blend and the cost stay float32.  The
+                                       (cell, weight) tables are stage-invariant, so this costs nothing per stage; only
+                                       the table-driven stage kernels (variants 5, 6, 7 and the multi-stage 2-D kernel)
+                                       serve such a problem.  cost_terms stay arrays of the problem dtype. */
     double model_h;
     const void *model_tables[4];
 } hjb_problem;
+
+#define HJB_IDX_I32 0
+#define HJB_IDX_U8 1
+#define HJB_IDX_U16 2
+#define HJB_IDX_AUTO 3
+
+#define HJB_TAB_DEFAULT 0
+#define HJB_TAB_F64 1
 
 #define HJB_MODEL_NONE 0
 #define HJB_MODEL_QUAT_EULER321 1
@@ -136,22 +157,28 @@ typedef struct hjb_probe {
 typedef struct hjb_solve_opts {
     int32_t n_stages;        /* number of backups: N-1 (Dynamic_Solver.m:86), N_stage-1 */
     int32_t monitor_period;  /* 0 = off; 50 in Solver_pos_att.m:273                     */
-    double monitor_tol;      /* 1e-2 in Solver_pos_att.m:269.  Deliberate deviation: the sums are exact float64 sums
-                                (fixed reduction tree, reproducible); MATLAB's sum() of the single array F.Values is
-                                a single-precision sum, so |e| < tol can first hold at a different monitor point there */
+    double monitor_tol;      /* 1e-2 in Solver_pos_att.m:269.  By default the two sums are float64 sums (fixed
+                                reduction tree, reproducible); MATLAB's sum() of the single array F.Values is a
+                                single-precision sum, so |e| < tol can first hold at a different monitor point there:
+                                see monitor_single below */
     const void *terminal;    /* J_N [nS] dtype, NULL = zeros (Dynamic_Solver.m:83-84)   */
     void *J_final;           /* out [nS] dtype: J of the last computed stage (may be NULL) */
-    int32_t *idx_final;      /* out [nS]: argmin labels of the last computed stage      */
+    void *idx_final;         /* out [nS] labels of hjb_problem.idx_dtype (int32 by default): argmin of the last
+                                computed stage                                          */
     void *J_stages;          /* out [nS * n_stages] or NULL: stage with reference index
                                 k_s (1-based, counting down from n_stages) is written
                                 to plane k_s-1  (test_coder.m:32 J_star(:,:,k_s))       */
-    int32_t *idx_stages;     /* out [nS * n_stages] or NULL (Dynamic_Solver.m:100)      */
+    void *idx_stages;        /* out [nS * n_stages] labels or NULL (Dynamic_Solver.m:100) */
     hjb_progress_fn progress;
     void *progress_user;
     const hjb_probe *probe;  /* NULL = no debug taps (Dynamic_Solver.m:212-219)                    */
     int32_t progress_every_stage; /* 0: progress is called at monitor points only; 1: after every stage (the reference
                                      prints per stage, Dynamic_Solver.m:101; e, e2 are then 0 between monitor points) */
-    int32_t reserved;
+    int32_t monitor_single;  /* 1: the monitor's sum of J is accumulated in float32, as MATLAB's sum() of the single
+                                array F_gI.Values is (Solver_pos_att.m:274; dtype HJB_F32 / HJB_F16S, one device).
+                                MATLAB's own summation order is not documented; the order used here is the fixed
+                                tree stated in csrc/kernels_reduce.h, restated by the oracle.  The label sum stays
+                                exact (U_Optimal_id is a double array there).  0: float64 sums */
 } hjb_solve_opts;
 
 typedef struct hjb_result {
@@ -170,6 +197,8 @@ typedef struct hjb_info {
     int32_t block, grid;
     int32_t halo_needed_lo;  /* conservative halo the tables imply (planes)             */
     int32_t halo_needed_hi;
+    int32_t idx_bytes;       /* bytes per stored argmin label: 4, 1 or 2 (hjb_problem.idx_dtype resolved) */
+    int32_t table_dtype;     /* HJB_TAB_* in effect                                     */
 } hjb_info;
 
 const char *hjb_version(void);
@@ -191,7 +220,8 @@ int32_t hjb_get_info(hjb_handle h, hjb_info *info);
 /* tuning/testing knobs: "variant" (-1 automatic, 0..7 force a stage kernel; HJB_E_UNSUPPORTED when it does not
  * apply), "graph" (0/1: hipGraph replay inside hjb_solve), "temporal" (several stages per launch inside hjb_solve
  * for local 2-D problems, kernels_tile2d.h: 0 off, 1 when applicable [default], 2 required), "row_lean" (0/1: lean form of
- * stage kernel 6), "lds_pad" (extra dynamic LDS bytes per workgroup: occupancy experiments) */
+ * stage kernel 6), "lds_pad" (extra dynamic LDS bytes per workgroup: occupancy experiments), "monitor_single" (0/1:
+ * hjb_solve_opts.monitor_single for callers of hjb_solve_flat); read-only: "idx_bytes" */
 int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
 /* "prep_mfma" (set): rebuild the handle's stage-invariant (cell, weight) tables - 1: with v_mfma_f32_32x32x2_f32 where an
  * axis' next-state sum splits into (all terms but the last) + (last term) over disjoint grid dims (the affine A x + B u
@@ -210,13 +240,31 @@ int32_t hjb_get_option(hjb_handle h, const char *key, int64_t *value);
 
 /* ONE backup, host buffers (exactly the MATLAB statement above):
  * J_next [j_elems] -> J_out [j_elems] (owned planes written), idx_out [n_states]. */
-int32_t hjb_backup_stage(hjb_handle h, const void *J_next, void *J_out, int32_t *idx_out);
+int32_t hjb_backup_stage(hjb_handle h, const void *J_next, void *J_out, void *idx_out);
 /* ONE backup on device buffers, asynchronous on `stream` (a hipStream_t; NULL =
  * default stream).  For host-driven loops and multi-GPU halo exchange. */
 int32_t hjb_backup_stage_device(hjb_handle h, const void *dJ_next, void *dJ_out,
-                                int32_t *d_idx_out, void *stream);
+                                void *d_idx_out, void *stream);
 /* Non-zero if a previous device-side backup hit HJB_E_HALO (synchronises). */
 int32_t hjb_check_device_status(hjb_handle h, void *stream);
+
+/* ---- device-buffer helpers --------------------------------------------------------------------------------------
+ * hjb_backup_stage_device works on device buffers the CALLER owns.  A host without a HIP binding of its own (MATLAB
+ * through calllib, plain C) gets them here - enough to drive a grid that never exists in host memory (C3: 51^6 states,
+ * 70 GB per buffer).  Pointers returned by hjb_device_malloc are ordinary HIP device pointers (hipMalloc). */
+#define HJB_COPY_H2D 0
+#define HJB_COPY_D2H 1
+#define HJB_COPY_D2D 2
+int32_t hjb_device_malloc(int32_t device, int64_t bytes, void **out);
+int32_t hjb_device_free(int32_t device, void *p);
+int32_t hjb_device_mem_info(int32_t device, int64_t *free_bytes, int64_t *total_bytes);
+int32_t hjb_device_copy(int32_t device, void *dst, const void *src, int64_t bytes, int32_t kind);   /* synchronous */
+/* dJ[s] = ((v0[i0] + v1[i1]) + v2[i2]) + ...  over the handle's whole grid: one add of the arithmetic type per axis,
+ * axis 0 first, stored in the handle's J storage type.  vecs[a]: HOST vector of n[a] elements of the arithmetic type
+ * (float for HJB_F32 / HJB_F16S).  A separable terminal cost for grids too large to build on the host. */
+int32_t hjb_device_fill_separable(hjb_handle h, const void *const *vecs, void *dJ, void *stream);
+/* out[i] = d_src[sel[i]] for elements of elem_bytes (1, 2, 4, 8) bytes: sample a device-resident J or label array */
+int32_t hjb_device_gather(int32_t device, const void *d_src, int32_t elem_bytes, const int64_t *sel, int64_t n_sel, void *out);
 
 /* The whole backward sweep (the `for k` loops of the reference). */
 int32_t hjb_solve(hjb_handle h, const hjb_solve_opts *opts, hjb_result *result);
@@ -246,6 +294,7 @@ int32_t hjb_probe_stage(hjb_handle h, const void *J_next, const hjb_probe *probe
  *   hjb_problem_set_knots(b, axis, knots, len)                      once per state axis
  *   hjb_problem_add_next_term(b, axis, mask, data, count)           in MATLAB's left-to-right order of the sum
  *   hjb_problem_add_cost_term(b, mask, data, count)
+ *   [hjb_problem_set_types(b, idx_dtype, table_dtype)]              right after hjb_problem_new
  *   [hjb_problem_set_slab(b, begin, end, halo_lo, halo_hi)]  [hjb_problem_set_model(b, model, h, t0, t1, t2, t3)]
  *   hjb_create_from(b, device, &h);  hjb_problem_free(b)
  * data: `count` elements of the problem dtype (float for HJB_F32 / HJB_F16S, double for HJB_F64), column-major over
@@ -257,6 +306,9 @@ int32_t hjb_problem_set_knots(hjb_builder b, int32_t axis, const double *knots, 
 int32_t hjb_problem_add_next_term(hjb_builder b, int32_t axis, uint32_t mask, const void *data, int64_t count);
 int32_t hjb_problem_add_cost_term(hjb_builder b, uint32_t mask, const void *data, int64_t count);
 int32_t hjb_problem_set_slab(hjb_builder b, int32_t slab_begin, int32_t slab_end, int32_t halo_lo, int32_t halo_hi);
+/* hjb_problem.idx_dtype (HJB_IDX_*) and hjb_problem.table_dtype (HJB_TAB_*).  Call it right after hjb_problem_new:
+ * with HJB_TAB_F64 the `data` of every hjb_problem_add_next_term that follows is float64 (cost terms stay float). */
+int32_t hjb_problem_set_types(hjb_builder b, int32_t idx_dtype, int32_t table_dtype);
 int32_t hjb_problem_set_model(hjb_builder b, int32_t model, double model_h, const void *t0, const void *t1,
                               const void *t2, const void *t3);
 /* Relabel the state axes of a problem under construction: new axis i = old axis order[i] (terms over several state
@@ -280,7 +332,7 @@ const char *hjb_problem_last_error(hjb_builder b);
 /* hjb_solve without structs: every argument a scalar or a plain array (NULL where hjb_solve_opts allows NULL);
  * the three result scalars may be NULL.  No progress callback, no probe. */
 int32_t hjb_solve_flat(hjb_handle h, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
-                       void *J_final, int32_t *idx_final, void *J_stages, int32_t *idx_stages, int32_t *stages_done,
+                       void *J_final, void *idx_final, void *J_stages, void *idx_stages, int32_t *stages_done,
                        int32_t *stopped_early, double *sweep_ms);
 /* hjb_get_info without the struct: out[0..7] = n_states, n_controls, j_elems, kernel_variant, lds_bytes, grid,
  * halo_needed_lo, halo_needed_hi */
@@ -302,7 +354,7 @@ int32_t hjb_create_multi(const hjb_problem *problem, int32_t n_dev, const int32_
 int32_t hjb_create_multi_from(hjb_builder b, int32_t n_dev, const int32_t *devices, hjb_multi *out);
 int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *opts, hjb_result *result);
 int32_t hjb_solve_multi_flat(hjb_multi m, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
-                             void *J_final, int32_t *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms);
+                             void *J_final, void *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms);
 /* planes [begin, end) of slab `slab`, its halo, whether it runs as interior + strips, its stage kernel (any out may be NULL) */
 int32_t hjb_multi_slab_info(hjb_multi m, int32_t slab, int32_t *begin, int32_t *end, int32_t *halo_lo, int32_t *halo_hi,
                             int32_t *split, int32_t *kernel_variant);

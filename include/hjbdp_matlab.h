@@ -21,6 +21,7 @@ int32_t hjb_problem_set_knots(void *builder, int32_t axis, const double *knots, 
 int32_t hjb_problem_add_next_term(void *builder, int32_t axis, uint32_t mask, const void *data, int64_t count);
 int32_t hjb_problem_add_cost_term(void *builder, uint32_t mask, const void *data, int64_t count);
 int32_t hjb_problem_set_slab(void *builder, int32_t slab_begin, int32_t slab_end, int32_t halo_lo, int32_t halo_hi);
+int32_t hjb_problem_set_types(void *builder, int32_t idx_dtype, int32_t table_dtype);
 int32_t hjb_problem_set_model(void *builder, int32_t model, double model_h, const void *t0, const void *t1, const void *t2, const void *t3);
 int32_t hjb_problem_permute_axes(void *builder, const int32_t *order);
 int32_t hjb_problem_suggest_order(void *builder, int32_t *order_out, int32_t *found);
@@ -31,10 +32,10 @@ const char *hjb_problem_last_error(void *builder);
 /* the stage loops: test/Dynamic_Solver.m:86-102, Solver_position.m:132-141, Solver_attitude.m:236-247 / :280-287,
  * Solver_pos_att.m:270-286 */
 int32_t hjb_solve_flat(void *handle, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
-                       void *J_final, int32_t *idx_final, void *J_stages, int32_t *idx_stages, int32_t *stages_done,
+                       void *J_final, void *idx_final, void *J_stages, void *idx_stages, int32_t *stages_done,
                        int32_t *stopped_early, double *sweep_ms);
 /* one stage: [F.Values, idx] = min(J_stage + F(x_next...), [], ctrl_dim)  (Dynamic_Solver.m:207-210) */
-int32_t hjb_backup_stage(void *handle, const void *J_next, void *J_out, int32_t *idx_out);
+int32_t hjb_backup_stage(void *handle, const void *J_next, void *J_out, void *idx_out);
 int32_t hjb_get_info_flat(void *handle, int64_t *out8);
 int32_t hjb_set_option(void *handle, const char *key, int64_t value);
 int32_t hjb_get_option(void *handle, const char *key, int64_t *value);
@@ -44,7 +45,7 @@ int32_t hjb_destroy(void *handle);
 /* the same loop over several GPUs of this process (slabs of the last state axis) */
 int32_t hjb_create_multi_from(void *builder, int32_t n_dev, const int32_t *devices, void **multi_out);
 int32_t hjb_solve_multi_flat(void *multi, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
-                             void *J_final, int32_t *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms);
+                             void *J_final, void *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms);
 int32_t hjb_multi_set_option(void *multi, const char *key, int64_t value);
 const char *hjb_multi_last_error(void *multi);
 int32_t hjb_destroy_multi(void *multi);

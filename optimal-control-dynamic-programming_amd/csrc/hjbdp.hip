@@ -19,6 +19,7 @@
 
 #include "../../include/hjbdp.h"
 #include "hjbdp_dev.h"
+#include "hjbdp_launch.h"
 #include "kernels_generic.h"
 #include "kernels_nested.h"
 #include "kernels_packed.h"
@@ -33,6 +34,7 @@
 #include "kernels_probe.h"
 #include "kernels_prep_mfma.h"
 #include "kernels_reduce.h"
+#include "kernels_devmem.h"
 
 using namespace hjb;
 
@@ -60,7 +62,10 @@ struct Handle {
     int32_t *d_status = nullptr;
     // work buffers (lazy)
     void *dJ[2] = {nullptr, nullptr};
-    int32_t *d_idx = nullptr;
+    char *d_idx = nullptr;        // argmin labels of the owned states, idx_bytes each
+    int idx_bytes = 4;            // hjb_problem.idx_dtype resolved: 4 (int32), 1 (uint8) or 2 (uint16)
+    bool tab64 = false;           // hjb_problem.table_dtype == HJB_TAB_F64: (cell, t) tables built in float64 from float64 terms
+    DParams *dp64 = nullptr;      // ... the float64 shadow of the axes (knots, 1/dx, next-state terms) the table build reads
     double *d_partials = nullptr;  // monitor reduction scratch
     double *d_sums = nullptr;      // [2]: sum J, sum idx
     DNested hn{};                 // variant 1 (control-nested) parameters
@@ -75,6 +80,7 @@ struct Handle {
     int gexec_variant = -1;
     bool gexec_tiled = false;
     bool use_graph = true;
+    bool monitor_single = false;  // option "monitor_single" (see hjb_solve_opts.monitor_single)
     size_t packed_lds = 0;
     size_t packed2_lds = 0;       // variant 4 (two controls per packed op)
     void *tile_plan = nullptr;    // K9 cached form: per (state, control) stage-invariant record (k_tile2d_plan)
@@ -163,7 +169,7 @@ int64_t term_elems(const hjb_problem *p, uint32_t mask) {
 }
 
 // upload one term, fill strides
-template <typename T>
+template <typename T, typename TS = T>      // T: element type on the device, TS: element type of the caller's array
 int make_term(Handle *h, const hjb_problem *p, const hjb_term &t, DTerm *out) {
     const int G = p->D + p->C;
     int64_t s = 1;
@@ -174,7 +180,8 @@ int make_term(Handle *h, const hjb_problem *p, const hjb_term &t, DTerm *out) {
             s *= (d < p->D) ? p->n[d] : p->m[d - p->D];
         }
     }
-    std::vector<T> host((const T *)t.data, (const T *)t.data + s);
+    std::vector<T> host((size_t)s);
+    for (int64_t i = 0; i < s; ++i) host[(size_t)i] = (T)((const TS *)t.data)[i];
     void *d = nullptr;
     int st = upload(h, host, &d);
     if (st) return st;
@@ -272,6 +279,7 @@ int build(Handle *h, const hjb_problem *p) {
     P.slab_begin = sb;
     P.halo_lo = hlo;
     P.index_base = p->index_base;
+    P.idx_bytes = h->idx_bytes;
 
     const uint32_t state_mask = (1u << D) - 1u;
     for (int a = 0; a < D; ++a) {
@@ -304,7 +312,9 @@ int build(Handle *h, const hjb_problem *p) {
         while (npre < ax.n_terms && (p->next_terms[a][npre].mask & ~state_mask) == 0) ++npre;
         ax.n_prefix = npre;
         for (int k = 0; k < ax.n_terms; ++k) {
-            st = make_term<T>(h, p, p->next_terms[a][k], &ax.t[k]);
+            // table_dtype F64: the caller's next-state terms are float64.  The float32 copy made here serves the host-side
+            // structure analysis only (no stage kernel that evaluates terms is admitted); the tables come from dp64 below
+            st = h->tab64 ? make_term<T, double>(h, p, p->next_terms[a][k], &ax.t[k]) : make_term<T>(h, p, p->next_terms[a][k], &ax.t[k]);
             if (st) return st;
         }
     }
@@ -334,7 +344,10 @@ int build(Handle *h, const hjb_problem *p) {
     {
         const int a = D - 1, n = p->n[a];
         std::vector<double> lo(n, 0.0), hi(n, 0.0);
-        for (int k = 0; k < p->n_next_terms[a]; ++k) term_minmax_along<T>(p, p->next_terms[a][k], a, lo, hi);
+        for (int k = 0; k < p->n_next_terms[a]; ++k) {
+            if (h->tab64) term_minmax_along<double>(p, p->next_terms[a][k], a, lo, hi);
+            else term_minmax_along<T>(p, p->next_terms[a][k], a, lo, hi);
+        }
         std::vector<T> kk(n);
         for (int i = 0; i < n; ++i) kk[i] = (T)p->knots[a][i];
         auto cell_of = [&](double q) {
@@ -357,7 +370,7 @@ int build(Handle *h, const hjb_problem *p) {
         DNested &N = h->hn;
         memset(&N, 0, sizeof N);
         const uint32_t in_bit = 1u << (D + C - 1);
-        bool ok = true;
+        bool ok = !h->tab64;          // variants 1-4 evaluate next-state terms in the kernel, in the problem dtype
         for (int a = 0; a < D - 1 && ok; ++a)
             for (int k = 0; k < p->n_next_terms[a]; ++k)
                 if (p->next_terms[a][k].mask & in_bit) ok = false;
@@ -484,6 +497,39 @@ int build(Handle *h, const hjb_problem *p) {
     if (st) return st;
     h->dp = (DParams *)dpp;
     HIP_TRY(h, hipMemcpy(h->dp, &P, sizeof(DParams), hipMemcpyHostToDevice));
+    if (h->tab64) {
+        // float64 shadow of the axes for the table build (k_prep_axis_table_t<double>): knots as given, 1/dx and the
+        // next-state terms in double - what griddedInterpolant sees in Solver_pos_att.m:299-327 (double grid vectors,
+        // double query tables); the stage kernels never read it
+        DParams Q = P;
+        for (int a = 0; a < D; ++a) {
+            DAxis &ax = Q.axis[a];
+            const int n = p->n[a];
+            std::vector<double> kk(p->knots[a], p->knots[a] + n), rdx((size_t)n, 0.0);
+            for (int i = 0; i + 1 < n; ++i) rdx[(size_t)i] = 1.0 / (kk[(size_t)i + 1] - kk[(size_t)i]);
+            void *dk = nullptr, *dr = nullptr;
+            int s2 = upload(h, kk, &dk);
+            if (!s2) s2 = upload(h, rdx, &dr);
+            if (s2) return s2;
+            ax.knots = dk;
+            ax.rdx = dr;
+            const double hstep = (kk[(size_t)n - 1] - kk[0]) / (n - 1);
+            double dev = 0;
+            for (int i = 0; i < n; ++i) dev = std::max(dev, std::fabs(kk[(size_t)i] - (kk[0] + i * hstep)));
+            ax.uniform = dev <= 1.5 * hstep ? 1 : 0;
+            ax.x0 = kk[0];
+            ax.inv_h = 1.0 / hstep;
+            for (int k = 0; k < ax.n_terms; ++k) {
+                s2 = make_term<double>(h, p, p->next_terms[a][k], &ax.t[k]);
+                if (s2) return s2;
+            }
+        }
+        void *dq = nullptr;
+        int s3 = dev_alloc(h, sizeof(DParams), &dq);
+        if (s3) return s3;
+        h->dp64 = (DParams *)dq;
+        HIP_TRY(h, hipMemcpy(h->dp64, &Q, sizeof(DParams), hipMemcpyHostToDevice));
+    }
     // ---- variant 2: precompute the stage-invariant (cell, weight) tables of the outer axes -------
     if (h->packed_mode) {
         DNested &N = h->hn;
@@ -593,6 +639,8 @@ int build(Handle *h, const hjb_problem *p) {
         h->tabled_ok = false;     // the other stage kernels do not evaluate the model
         h->nested_fast = false;
     }
+    if (h->tab64 && !h->tabled_ok)
+        return fail(h, HJB_E_UNSUPPORTED, "table_dtype HJB_TAB_F64 needs the per-axis (cell, weight) tables to fit (variants 5-7)");
     if (h->nested_ok) {
         void *dnn = nullptr;
         int st2 = dev_alloc(h, sizeof(DNested), &dnn);
@@ -600,6 +648,36 @@ int build(Handle *h, const hjb_problem *p) {
         h->dn = (DNested *)dnn;
         HIP_TRY(h, hipMemcpy(h->dn, &h->hn, sizeof(DNested), hipMemcpyHostToDevice));
     }
+    return HJB_OK;
+}
+
+// float64-built entries narrowed to the float32 tables the stage kernels read: the weight is rounded ONCE, here
+__global__ void __launch_bounds__(256)
+k_tab_narrow(const TabEntry<double> *__restrict__ in, TabEntry<float> *__restrict__ out, int64_t n) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        TabEntry<float> o;
+        o.cell = in[e].cell;
+        o.t = (float)in[e].t;
+        out[e] = o;
+    }
+}
+
+// One axis' (cell, weight) table in the handle's table dtype.
+template <typename T>
+int launch_prep_any(Handle *h, int D, int grid, int a, const int32_t *dsz, int64_t n, TabEntry<T> *tab) {
+    if constexpr (std::is_same<T, float>::value) {
+        if (h->tab64) {
+            void *tmp = nullptr;
+            if (hipMalloc(&tmp, (size_t)n * sizeof(TabEntry<double>)) != hipSuccess) return fail(h, HJB_E_NOMEM, "float64 table build: scratch of %lld entries", (long long)n);
+            launch_prep_t<double>(D, grid, h->dp64, a, dsz, n, (TabEntry<double> *)tmp);
+            hipLaunchKernelGGL(k_tab_narrow, dim3(grid), dim3(256), 0, nullptr, (const TabEntry<double> *)tmp, tab, n);
+            const hipError_t e1 = hipDeviceSynchronize();
+            (void)hipFree(tmp);
+            if (e1 != hipSuccess) return fail(h, HJB_E_DEVICE, "float64 table build: %s", hipGetErrorString(e1));
+            return HJB_OK;
+        }
+    }
+    launch_prep_t<T>(D, grid, h->dp, a, dsz, n, tab);
     return HJB_OK;
 }
 
@@ -629,7 +707,8 @@ int ensure_tabled_t(Handle *h) {
         st3 = dev_alloc(h, (size_t)h->dom_entries[a] * sizeof(TabEntry<T>), &tab);
         if (st3) return st3;
         const int grid = (int)std::min<int64_t>((h->dom_entries[a] + 255) / 256, 65536);
-        launch_prep_t<T>(D, grid, h->dp, a, (const int32_t *)dsz_d, h->dom_entries[a], (TabEntry<T> *)tab);
+        st3 = launch_prep_any<T>(h, D, grid, a, (const int32_t *)dsz_d, h->dom_entries[a], (TabEntry<T> *)tab);
+        if (st3) return st3;
         h->preps.push_back({a, 1, (const int32_t *)dsz_d, dsz, h->dom_entries[a], tab});
         A.tab = tab;
     }
@@ -652,7 +731,7 @@ int ensure_tabled(Handle *h) {
 static bool prep_split(const Handle *h, const Handle::PrepRec &R, DPrepSplit *S) {
     const hjb_problem &p = h->prob;
     const int a = R.axis, nt = p.n_next_terms[a], G = p.D + p.C;
-    if (h->dtype == HJB_F64 || nt < 2) return false;
+    if (h->dtype == HJB_F64 || h->tab64 || nt < 2) return false;
     uint32_t others = 0;
     for (int k = 0; k + 1 < nt; ++k) others |= p.next_terms[a][k].mask;
     const uint32_t last = p.next_terms[a][nt - 1].mask;
@@ -708,7 +787,7 @@ int rebuild_tables(Handle *h, bool mfma) {
             else launch_prep_t<double>(D, grid, h->dp, R.axis, R.dsz_d, R.n, (TabEntry<double> *)R.tab);
         } else {
             if (R.kind == 0) launch_prep<float>(D, grid, h->dp, R.axis, R.dsz_d, R.n, (int2 *)R.tab);
-            else launch_prep_t<float>(D, grid, h->dp, R.axis, R.dsz_d, R.n, (TabEntry<float> *)R.tab);
+            else { const int pst = launch_prep_any<float>(h, D, grid, R.axis, R.dsz_d, R.n, (TabEntry<float> *)R.tab); if (pst) return pst; }
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -1161,8 +1240,7 @@ int examine_tile2d_t(Handle *h) {
         void *d = nullptr;
         st = dev_alloc(h, (size_t)ne * sizeof(TilePlan<T>), &d);
         if (st) return st;
-        hipLaunchKernelGGL((k_tile2d_plan<T>), dim3((unsigned)std::min<int64_t>((ne + 255) / 256, 65536)), dim3(256), 0, nullptr,
-                           h->dp, h->dtb, (TilePlan<T> *)d);
+        (void)stage_tile2d_plan(h->dtype, h->dp, h->dtb, d, ne);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipDeviceSynchronize());
         h->tile_plan = d;
@@ -1174,22 +1252,20 @@ int examine_tile2d(Handle *h) {
     return h->dtype != HJB_F64 ? examine_tile2d_t<float>(h) : examine_tile2d_t<double>(h);
 }
 
-int launch_tile2d(Handle *h, const void *dJn, void *dJo, int32_t *didx, int K, hipStream_t st) {
+int launch_tile2d(Handle *h, const void *dJn, void *dJo, void *didx, int K, hipStream_t st) {
     const DParams &P = h->hp;
-    const int tiles = ((P.n[0] + kTileX - 1) / kTileX) * ((P.n[1] + kTileY - 1) / kTileY);
-    dim3 g(tiles), b(256);
-    const bool cached = h->tile_plan != nullptr;             // stage-invariant per-control data kept in registers
-#define HJB_LAUNCH_TILE(TT, TTJ)                                                                                       \
-    do {                                                                                                               \
-        if (cached)                                                                                                    \
-            hipLaunchKernelGGL((k_backup_tile2d_cached<TT, TTJ>), g, b, 0, st, h->dp, (const TilePlan<TT> *)h->tile_plan, (const TTJ *)dJn, (TTJ *)dJo, didx, K); \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_backup_tile2d<TT, TTJ>), g, b, 0, st, h->dp, h->dtb, (const TTJ *)dJn, (TTJ *)dJo, didx, K); \
-    } while (0)
-    if (h->dtype == HJB_F16S) HJB_LAUNCH_TILE(float, _Float16);
-    else if (h->dtype == HJB_F32) HJB_LAUNCH_TILE(float, float);
-    else HJB_LAUNCH_TILE(double, double);
-#undef HJB_LAUNCH_TILE
+    StageArgs a;
+    a.grid = (unsigned)(((P.n[0] + kTileX - 1) / kTileX) * ((P.n[1] + kTileY - 1) / kTileY));
+    a.block = 256;
+    a.st = st;
+    a.dtype = h->dtype;
+    a.D = P.D;
+    a.dp = h->dp;
+    a.dtb = h->dtb;
+    a.Jn = dJn;
+    a.Jo = dJo;
+    a.idx = didx;
+    (void)stage_tile2d(a, h->tile_plan, K);      // the cached form when its plan exists
     HIP_TRY(h, hipGetLastError());
     return HJB_OK;
 }
@@ -1197,7 +1273,7 @@ int launch_tile2d(Handle *h, const void *dJn, void *dJo, int32_t *didx, int K, h
 void choose_launch(Handle *h) {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     // few states x many controls (Kirk): one wave per state, controls across lanes
-    const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024;
+    const bool want_split = h->nU >= 64 && h->n_owned < 512 * 1024 && !h->tab64;
     // variant 7 (column sweep) wants what variant 6 wants - long axis-0 rows on a large grid - plus its own structure;
     // its plan is built here (never inside a launch: launches may be under graph capture)
     bool cs_auto = false;
@@ -1211,6 +1287,7 @@ void choose_launch(Handle *h) {
     if (h->dtype == HJB_F16S && h->variant >= 1 && h->variant <= 3)     // float16 J storage: variants 0, 4, 5, 6, 7 only
         h->variant = h->forced_variant >= 0 ? h->forced_variant : (cs_auto ? 7 : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0)));
     if (h->variant == 7 && h->cs_state != 1) h->variant = h->row_ok ? 6 : (h->tabled_ok ? 5 : 0);
+    if (h->tab64 && h->variant < 5) h->variant = 5;       // float64-built tables: the table-driven kernels only (tabled_ok holds)
     // build the variant 5/6 tables now (never inside a launch: launches may be under graph capture)
     h->launch_status = HJB_OK;
     if ((h->variant == 5 || h->variant == 6) && (h->launch_status = ensure_tabled(h)) != HJB_OK) h->variant = 0;
@@ -1244,202 +1321,84 @@ void choose_launch(Handle *h) {
     if (h->grid < 1) h->grid = 1;
 }
 
-template <typename T, typename TJ>
-int launch_stage_t(Handle *h, const TJ *dJn, TJ *dJo, int32_t *didx, hipStream_t st) {
-    constexpr bool same = std::is_same<T, TJ>::value;   // variants 1-3 exist for J stored in the arithmetic type only
+// One stage: the handle's variant on (dJn -> dJo, didx).  The kernels live in translation units of their own
+// (stage_*.hip behind hjbdp_launch.h); this is the only place that knows which family serves which variant.
+int launch_stage(Handle *h, const void *dJn, void *dJo, void *didx, hipStream_t st) {
     const int D = h->hp.D;
-    dim3 g(h->grid), b(h->block);
-    if (h->variant == 7) {
-        if (!h->dtb || !h->dcs) return fail(h, HJB_E_DEVICE, "variant 7 plan missing");
-        if constexpr (std::is_same<T, float>::value) {
-#define HJB_LAUNCH_CS2(NG, FC, DP)                                                                                     \
-    do {                                                                                                               \
-        if (h->hcs.gax == 3) hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 3, NG, FC, DP>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
-        else hipLaunchKernelGGL((k_backup_colsweep<T, TJ, 2, NG, FC, DP>), g, b, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
-    } while (0)
-#define HJB_LAUNCH_CS(NG)                                                                                              \
-    case NG:                                                                                                           \
-        if (fastcost) { if (dppf) HJB_LAUNCH_CS2(NG, true, true); else HJB_LAUNCH_CS2(NG, true, false); }              \
-        else { if (dppf) HJB_LAUNCH_CS2(NG, false, true); else HJB_LAUNCH_CS2(NG, false, false); }                     \
-        break;
+    const bool f32 = h->dtype != HJB_F64;              // float32 arithmetic (J stored as float32 or binary16)
+    const bool same = h->dtype != HJB_F16S;            // J stored in the arithmetic type
+    StageArgs a;
+    a.grid = (unsigned)h->grid;
+    a.block = (unsigned)h->block;
+    a.st = st;
+    a.dtype = h->dtype;
+    a.D = D;
+    a.dp = h->dp;
+    a.dn = h->dn;
+    a.dtb = h->dtb;
+    a.dcs = h->dcs;
+    a.Jn = dJn;
+    a.Jo = dJo;
+    a.idx = didx;
+    int miss = 0;
+    switch (h->variant) {
+        case 7: {
+            if (!h->dtb || !h->dcs) return fail(h, HJB_E_DEVICE, "variant 7 plan missing");
+            if (!f32) return fail(h, HJB_E_UNSUPPORTED, "variant 7 is float32 arithmetic only");
             const bool fastcost = h->hcs.ncu == 1 && h->hp.n_cost_prefix > 0;    // state terms + one control term
-            const bool dppf = h->hcs.dpp != 0;
             // cooperative form: its staging loads are 16 bytes wide (a J pointer handed in unaligned runs the other form)
             if (h->hcs.coop && h->cc_grid > 0 && h->hcs.ng <= kCcNCG && ((uintptr_t)dJn & 15u) == 0) {
-                constexpr int EPL = 16 / (int)sizeof(TJ);
-                dim3 gc(h->cc_grid), bc(kCcW * 64);
-#define HJB_LAUNCH_CC2(NG, FC)                                                                                         \
-    do {                                                                                                               \
-        if (h->hcs.gax == 3) hipLaunchKernelGGL((k_backup_colcoop<T, TJ, 3, NG, FC, EPL>), gc, bc, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
-        else hipLaunchKernelGGL((k_backup_colcoop<T, TJ, 2, NG, FC, EPL>), gc, bc, 0, st, h->dp, h->dtb, h->dcs, dJn, dJo, didx); \
-    } while (0)
-#define HJB_LAUNCH_CC(NG)                                                                                              \
-    case NG:                                                                                                           \
-        if (fastcost) HJB_LAUNCH_CC2(NG, true); else HJB_LAUNCH_CC2(NG, false);                                        \
-        break;
-                switch (h->hcs.ng) {
-                    HJB_LAUNCH_CC(1) HJB_LAUNCH_CC(2) HJB_LAUNCH_CC(3) HJB_LAUNCH_CC(4) HJB_LAUNCH_CC(5)
-                    default: return fail(h, HJB_E_DEVICE, "variant 7: %d groups", h->hcs.ng);
-                }
-#undef HJB_LAUNCH_CC2
-#undef HJB_LAUNCH_CC
-                HIP_TRY(h, hipGetLastError());
-                return HJB_OK;
+                a.grid = (unsigned)h->cc_grid;
+                miss = stage_colcoop(a, h->hcs.gax, h->hcs.ng, fastcost);
+            } else {
+                miss = stage_colsweep(a, h->hcs.gax, h->hcs.ng, fastcost, h->hcs.dpp != 0);
             }
-            switch (h->hcs.ng) {
-                HJB_LAUNCH_CS(1) HJB_LAUNCH_CS(2) HJB_LAUNCH_CS(3) HJB_LAUNCH_CS(4) HJB_LAUNCH_CS(5) HJB_LAUNCH_CS(6)
-                default: return fail(h, HJB_E_DEVICE, "variant 7: %d groups", h->hcs.ng);
-            }
-#undef HJB_LAUNCH_CS2
-#undef HJB_LAUNCH_CS
-            HIP_TRY(h, hipGetLastError());
-            return HJB_OK;
-        } else {
-            return fail(h, HJB_E_UNSUPPORTED, "variant 7 is float32 arithmetic only");
+            if (miss) return fail(h, HJB_E_DEVICE, "variant 7: %d groups", h->hcs.ng);
+            break;
         }
-    }
-    if (h->variant == 6) {
-        if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 6 tables missing");
-        const bool lean = h->row_lean && h->row_lean_ok && !h->htb.ax[0].has_ctrl;
-        const size_t lean_wave = (((size_t)h->nU * 4 + 15) & ~(size_t)15) + (((size_t)h->nU * (D - 1 + kLeanMaxCu) * sizeof(T) + 15) & ~(size_t)15);
-        const size_t lds = lean ? 4 * lean_wave + (size_t)h->nU * 12 : 0;
-#define HJB_LAUNCH_ROW(DD)                                                                                             \
-    case DD:                                                                                                           \
-        if (lean) hipLaunchKernelGGL((k_backup_rowlean<T, TJ, DD>), g, b, lds, st, h->dp, h->dtb, dJn, dJo, didx);      \
-        else hipLaunchKernelGGL((k_backup_rowwise<T, TJ, DD>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx);             \
-        break;
-        switch (D) {
-            HJB_LAUNCH_ROW(2) HJB_LAUNCH_ROW(3) HJB_LAUNCH_ROW(4) HJB_LAUNCH_ROW(5) HJB_LAUNCH_ROW(6)
-            default: return fail(h, HJB_E_UNSUPPORTED, "variant 6 with D=%d", D);
+        case 6: {
+            if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 6 tables missing");
+            const bool lean = h->row_lean && h->row_lean_ok && !h->htb.ax[0].has_ctrl;
+            const size_t tsz = f32 ? 4 : 8;
+            const size_t lean_wave = (((size_t)h->nU * 4 + 15) & ~(size_t)15) + (((size_t)h->nU * (D - 1 + kLeanMaxCu) * tsz + 15) & ~(size_t)15);
+            a.lds = lean ? 4 * lean_wave + (size_t)h->nU * 12 : 0;
+            miss = stage_rowwise(a, lean);
+            break;
         }
-#undef HJB_LAUNCH_ROW
-        HIP_TRY(h, hipGetLastError());
-        return HJB_OK;
+        case 5:
+            if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 5 tables missing");
+            miss = stage_tabled(a);
+            break;
+        case 4:
+            if (!f32) return fail(h, HJB_E_UNSUPPORTED, "variant 4 is float32 only");
+            a.lds = h->packed2_lds + h->lds_pad;
+            miss = stage_packed2(a, h->packed_pre);
+            break;
+        case 3:
+            if (!same) return fail(h, HJB_E_UNSUPPORTED, "variant 3 does not support float16 J storage (use 0, 4 or 5)");
+            a.lds = h->split_j_in_lds ? (size_t)h->j_elems * h->esz : 0;
+            miss = stage_ctrlsplit(a, h->split_j_in_lds);
+            break;
+        case 2:
+            if (!same) return fail(h, HJB_E_UNSUPPORTED, "variant 2 does not support float16 J storage (use 0, 4 or 5)");
+            if (!f32) return fail(h, HJB_E_UNSUPPORTED, "variant 2 is float32 only");
+            a.lds = h->packed_lds;
+            miss = stage_packed(a);
+            break;
+        case 1:
+            if (!same) return fail(h, HJB_E_UNSUPPORTED, "variant 1 does not support float16 J storage (use 0, 4 or 5)");
+            a.lds = h->nested_lds;
+            miss = stage_nested(a, h->nested_fast);
+            break;
+        case 0:
+            miss = stage_generic(a);
+            break;
+        default:    // never fall through to the generic kernel silently
+            return fail(h, HJB_E_DEVICE, "internal: kernel variant %d was not dispatched", h->variant);
     }
-    if (h->variant == 5) {
-        if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 5 tables missing");
-        switch (D) {
-            case 1: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 1>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 2: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 2>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 3: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 3>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 4: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 4>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 5: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 5>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            case 6: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 6>), g, b, 0, st, h->dp, h->dtb, dJn, dJo, didx); break;
-            default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
-        }
-        HIP_TRY(h, hipGetLastError());
-        return HJB_OK;
-    }
-    if (h->variant == 4) {
-        if constexpr (std::is_same<T, float>::value) {
-            const size_t lds = h->packed2_lds + h->lds_pad;
-#define HJB_LAUNCH_PACKED2(DD)                                                                                       \
-    case DD:                                                                                                         \
-        if (DD == 3 && h->packed_pre == 1)                                                                           \
-            hipLaunchKernelGGL((k_backup_packed2<TJ, 3, 1>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);            \
-        else if (DD == 6 && h->packed_pre == 3)                                                                      \
-            hipLaunchKernelGGL((k_backup_packed2<TJ, 6, 3>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);            \
-        else if (DD >= 4 && h->packed_pre == 2)                                                                      \
-            hipLaunchKernelGGL((k_backup_packed2<TJ, (DD >= 4 ? DD : 4), 2>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx); \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_backup_packed2<TJ, DD, 0>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);           \
-        break;
-            switch (D) {
-                HJB_LAUNCH_PACKED2(1) HJB_LAUNCH_PACKED2(2) HJB_LAUNCH_PACKED2(3) HJB_LAUNCH_PACKED2(4)
-                HJB_LAUNCH_PACKED2(5) HJB_LAUNCH_PACKED2(6)
-                default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
-            }
-#undef HJB_LAUNCH_PACKED2
-            HIP_TRY(h, hipGetLastError());
-            return HJB_OK;
-        } else {
-            return fail(h, HJB_E_UNSUPPORTED, "variant 4 is float32 only");
-        }
-    }
-    if (h->variant >= 1 && h->variant <= 3 && !same)
-        return fail(h, HJB_E_UNSUPPORTED, "variant %d does not support float16 J storage (use 0, 4 or 5)", h->variant);
-    if constexpr (same) {
-    if (h->variant == 3) {
-        const size_t lds = h->split_j_in_lds ? (size_t)h->j_elems * sizeof(T) : 0;
-#define HJB_LAUNCH_SPLIT(DD)                                                                                         \
-    case DD:                                                                                                         \
-        if (h->split_j_in_lds) hipLaunchKernelGGL((k_backup_ctrlsplit<T, DD, true>), g, b, lds, st, h->dp, dJn, dJo, didx); \
-        else hipLaunchKernelGGL((k_backup_ctrlsplit<T, DD, false>), g, b, 0, st, h->dp, dJn, dJo, didx);              \
-        break;
-        switch (D) {
-            HJB_LAUNCH_SPLIT(1) HJB_LAUNCH_SPLIT(2) HJB_LAUNCH_SPLIT(3) HJB_LAUNCH_SPLIT(4) HJB_LAUNCH_SPLIT(5)
-            HJB_LAUNCH_SPLIT(6)
-            default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
-        }
-#undef HJB_LAUNCH_SPLIT
-        HIP_TRY(h, hipGetLastError());
-        return HJB_OK;
-    }
-    if (h->variant == 2) {
-        if constexpr (std::is_same<T, float>::value) {
-            const size_t lds = h->packed_lds;
-#define HJB_LAUNCH_PACKED(DD)                                                                                        \
-    case DD:                                                                                                         \
-        hipLaunchKernelGGL((k_backup_packed<DD>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);                       \
-        break;
-            switch (D) {
-                HJB_LAUNCH_PACKED(1) HJB_LAUNCH_PACKED(2) HJB_LAUNCH_PACKED(3) HJB_LAUNCH_PACKED(4) HJB_LAUNCH_PACKED(5)
-                HJB_LAUNCH_PACKED(6)
-                default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
-            }
-#undef HJB_LAUNCH_PACKED
-            HIP_TRY(h, hipGetLastError());
-            return HJB_OK;
-        } else {
-            return fail(h, HJB_E_UNSUPPORTED, "variant 2 is float32 only");
-        }
-    }
-    if (h->variant == 1) {
-        const size_t lds = h->nested_lds;
-        switch (D) {
-            case 1: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 1, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    else hipLaunchKernelGGL((k_backup_nested<T, 1, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    break;
-            case 2: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 2, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    else hipLaunchKernelGGL((k_backup_nested<T, 2, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    break;
-            case 3: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 3, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    else hipLaunchKernelGGL((k_backup_nested<T, 3, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    break;
-            case 4: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 4, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    else hipLaunchKernelGGL((k_backup_nested<T, 4, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    break;
-            case 5: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 5, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    else hipLaunchKernelGGL((k_backup_nested<T, 5, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    break;
-            case 6: if (h->nested_fast) hipLaunchKernelGGL((k_backup_nested<T, 6, true>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    else hipLaunchKernelGGL((k_backup_nested<T, 6, false>), g, b, lds, st, h->dp, h->dn, dJn, dJo, didx);
-                    break;
-            default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
-        }
-        HIP_TRY(h, hipGetLastError());
-        return HJB_OK;
-    }
-    }  // if constexpr (same)
-    if (h->variant != 0)   // every other variant returned above: never fall through to the generic kernel silently
-        return fail(h, HJB_E_DEVICE, "internal: kernel variant %d was not dispatched", h->variant);
-    switch (D) {
-        case 1: hipLaunchKernelGGL((k_backup_generic<T, TJ, 1>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 2: hipLaunchKernelGGL((k_backup_generic<T, TJ, 2>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 3: hipLaunchKernelGGL((k_backup_generic<T, TJ, 3>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 4: hipLaunchKernelGGL((k_backup_generic<T, TJ, 4>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 5: hipLaunchKernelGGL((k_backup_generic<T, TJ, 5>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        case 6: hipLaunchKernelGGL((k_backup_generic<T, TJ, 6>), g, b, 0, st, h->dp, dJn, dJo, didx); break;
-        default: return fail(h, HJB_E_UNSUPPORTED, "D=%d", D);
-    }
+    if (miss) return fail(h, HJB_E_UNSUPPORTED, "variant %d has no kernel for D=%d, dtype %d", h->variant, D, h->dtype);
     HIP_TRY(h, hipGetLastError());
     return HJB_OK;
-}
-
-int launch_stage(Handle *h, const void *dJn, void *dJo, int32_t *didx, hipStream_t st) {
-    if (h->dtype == HJB_F16S) return launch_stage_t<float, _Float16>(h, (const _Float16 *)dJn, (_Float16 *)dJo, didx, st);
-    if (h->dtype == HJB_F32) return launch_stage_t<float, float>(h, (const float *)dJn, (float *)dJo, didx, st);
-    return launch_stage_t<double, double>(h, (const double *)dJn, (double *)dJo, didx, st);
 }
 
 int ensure_work(Handle *h) {
@@ -1450,9 +1409,9 @@ int ensure_work(Handle *h) {
         HIP_TRY(h, hipMemset(h->dJ[i], 0, (size_t)h->j_elems * h->esz));
     }
     void *d = nullptr;
-    int st = dev_alloc(h, (size_t)h->n_owned * sizeof(int32_t), &d);
+    int st = dev_alloc(h, (size_t)h->n_owned * h->idx_bytes, &d);
     if (st) return st;
-    h->d_idx = (int32_t *)d;
+    h->d_idx = (char *)d;
     st = dev_alloc(h, sizeof(double) * 2 * kReduceBlocks, &d);
     if (st) return st;
     h->d_partials = (double *)d;
@@ -1477,6 +1436,7 @@ int check_status(Handle *h, hipStream_t st) {
 // ---- probe block (Dynamic_Solver.m:212-219) -------------------------------------------------------------------
 int make_probe(Handle *h, const hjb_probe *pb, DProbe *out) {
     if (h->hp.model) return fail(h, HJB_E_UNSUPPORTED, "the probe block is not available for problems with a state model");
+    if (h->tab64) return fail(h, HJB_E_UNSUPPORTED, "the probe block reports float32 next states; not available with table_dtype HJB_TAB_F64");
     memset(out, 0, sizeof *out);
     int64_t B = 1;
     for (int a = 0; a < h->hp.D; ++a) {
@@ -1623,6 +1583,10 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
         for (int i = 0; i < 4; ++i)
             if (!p->model_tables[i]) return fail(nullptr, HJB_E_INVALID, "model_tables[%d] is null", i);
     }
+    if (p->idx_dtype < HJB_IDX_I32 || p->idx_dtype > HJB_IDX_AUTO) return fail(nullptr, HJB_E_INVALID, "idx_dtype %d", p->idx_dtype);
+    if (p->table_dtype != HJB_TAB_DEFAULT && p->table_dtype != HJB_TAB_F64) return fail(nullptr, HJB_E_INVALID, "table_dtype %d", p->table_dtype);
+    if (p->table_dtype == HJB_TAB_F64 && (p->dtype == HJB_F64 || p->model))
+        return fail(nullptr, HJB_E_INVALID, "table_dtype HJB_TAB_F64 is for float32 arithmetic without a state model (a float64 problem is float64 throughout)");
     const int G = p->D + p->C;
     int64_t nS = 1, nU = 1;
     for (int a = 0; a < p->D; ++a) {
@@ -1664,8 +1628,18 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, HJB_E_DEVICE, "no HIP device visible (libhjbdp has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(nullptr, HJB_E_INVALID, "device %d not in 0..%d", device, ndev - 1);
+    int idx_bytes = 4;
+    {
+        const int64_t top = nU - 1 + p->index_base;                       // the largest label
+        if (p->idx_dtype == HJB_IDX_U8 || (p->idx_dtype == HJB_IDX_AUTO && top <= 255)) idx_bytes = 1;
+        else if (p->idx_dtype == HJB_IDX_U16 || (p->idx_dtype == HJB_IDX_AUTO && top <= 65535)) idx_bytes = 2;
+        if ((idx_bytes == 1 && top > 255) || (idx_bytes == 2 && top > 65535))
+            return fail(nullptr, HJB_E_INVALID, "idx_dtype %d cannot hold the label %lld", p->idx_dtype, (long long)top);
+    }
     Handle *h = new Handle();
     h->device = device;
+    h->idx_bytes = idx_bytes;
+    h->tab64 = p->table_dtype == HJB_TAB_F64;
     h->dtype = p->dtype;
     h->esz = p->dtype == HJB_F16S ? 2 : (p->dtype == HJB_F32 ? 4 : 8);
     h->prob = *p;
@@ -1721,6 +1695,8 @@ int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
     info->grid = h->grid;
     info->halo_needed_lo = h->halo_need_lo;
     info->halo_needed_hi = h->halo_need_hi;
+    info->idx_bytes = h->idx_bytes;
+    info->table_dtype = h->tab64 ? HJB_TAB_F64 : HJB_TAB_DEFAULT;
     return HJB_OK;
 }
 
@@ -1743,6 +1719,9 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
                         "no axis other than axis 0 depending on state dim 0");
         if (h->dtype == HJB_F16S && value >= 1 && value <= 3)
             return fail(h, HJB_E_UNSUPPORTED, "variant %lld does not support float16 J storage (use 0, 4, 5 or 6)", (long long)value);
+        if (h->tab64 && value >= 0 && value <= 4)
+            return fail(h, HJB_E_UNSUPPORTED, "variant %lld evaluates the next-state terms in the kernel, in float32; a problem with "
+                        "table_dtype HJB_TAB_F64 runs on the table-driven kernels (5, 6, 7)", (long long)value);
         if (h->hp.model && value != -1 && value != 4)
             return fail(h, HJB_E_UNSUPPORTED, "a problem with a state model runs on variant 4 only");
         if (value == 5 && !h->tabled_ok)
@@ -1851,6 +1830,10 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         h->use_graph = value != 0;
         return HJB_OK;
     }
+    if (!strcmp(key, "monitor_single")) {   // hjb_solve_opts.monitor_single for callers of the flat API (hjb_solve_flat)
+        h->monitor_single = value != 0;
+        return HJB_OK;
+    }
     return fail(h, HJB_E_INVALID, "unknown option '%s'", key);
 }
 
@@ -1859,6 +1842,8 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     if (!h || !key || !value) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) *value = h->variant;
     else if (!strcmp(key, "graph")) *value = h->use_graph ? 1 : 0;
+    else if (!strcmp(key, "monitor_single")) *value = h->monitor_single ? 1 : 0;
+    else if (!strcmp(key, "idx_bytes")) *value = h->idx_bytes;
     else if (!strcmp(key, "temporal")) *value = h->use_temporal;
     else if (!strcmp(key, "row_lean")) *value = h->row_lean ? 1 : 0;
     else if (!strcmp(key, "lds_pad")) *value = (int64_t)h->lds_pad;
@@ -1887,7 +1872,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     return HJB_OK;
 }
 
-int32_t hjb_backup_stage_device(hjb_handle hh, const void *dJ_next, void *dJ_out, int32_t *d_idx_out, void *stream) {
+int32_t hjb_backup_stage_device(hjb_handle hh, const void *dJ_next, void *dJ_out, void *d_idx_out, void *stream) {
     Handle *h = (Handle *)hh;
     if (!h || !dJ_next || !dJ_out) return fail(h, HJB_E_INVALID, "null argument");
     if (dJ_next == dJ_out) return fail(h, HJB_E_INVALID, "J_next and J_out must not alias");
@@ -1902,7 +1887,7 @@ int32_t hjb_check_device_status(hjb_handle hh, void *stream) {
     return check_status(h, (hipStream_t)stream);
 }
 
-int32_t hjb_backup_stage(hjb_handle hh, const void *J_next, void *J_out, int32_t *idx_out) {
+int32_t hjb_backup_stage(hjb_handle hh, const void *J_next, void *J_out, void *idx_out) {
     Handle *h = (Handle *)hh;
     if (!h || !J_next || !J_out) return fail(h, HJB_E_INVALID, "null argument");
     std::shared_lock<std::shared_mutex> lk(g_capture_mu);
@@ -1918,7 +1903,7 @@ int32_t hjb_backup_stage(hjb_handle hh, const void *J_next, void *J_out, int32_t
     st = check_status(h, nullptr);
     if (st) return st;
     HIP_TRY(h, hipMemcpy(J_out, h->dJ[1], jb, hipMemcpyDeviceToHost));
-    if (idx_out) HIP_TRY(h, hipMemcpy(idx_out, h->d_idx, (size_t)h->n_owned * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (idx_out) HIP_TRY(h, hipMemcpy(idx_out, h->d_idx, (size_t)h->n_owned * h->idx_bytes, hipMemcpyDeviceToHost));
     return HJB_OK;
 }
 
@@ -1938,7 +1923,8 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     hipStream_t stream = h->stream;
     // optional per-stage capture: kernels write straight into the stage planes
     char *dJst = nullptr;
-    int32_t *dIst = nullptr;
+    char *dIst = nullptr;
+    const size_t ib = (size_t)nS * h->idx_bytes;      // bytes of one plane of labels
     if (o->J_stages) {
         void *d = nullptr;
         if (hipMalloc(&d, jb * o->n_stages) != hipSuccess) return fail(h, HJB_E_NOMEM, "cannot hold %d J stages on the device", o->n_stages);
@@ -1947,12 +1933,12 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     }
     if (o->idx_stages) {
         void *d = nullptr;
-        if (hipMalloc(&d, (size_t)nS * 4 * o->n_stages) != hipSuccess) {
+        if (hipMalloc(&d, ib * o->n_stages) != hipSuccess) {
             if (dJst) (void)hipFree(dJst);
             return fail(h, HJB_E_NOMEM, "cannot hold %d idx stages on the device", o->n_stages);
         }
-        dIst = (int32_t *)d;
-        if (hipMemset(dIst, 0, (size_t)nS * 4 * o->n_stages) != hipSuccess) {
+        dIst = (char *)d;
+        if (hipMemset(dIst, 0, ib * o->n_stages) != hipSuccess) {
             if (dJst) (void)hipFree(dJst);
             (void)hipFree(dIst);
             return fail(h, HJB_E_DEVICE, "hipMemset of the idx stage planes failed");
@@ -1980,9 +1966,15 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
         if (st) { cleanup(); return st; }
         const size_t pb = (size_t)pr.B * tsz;
         void *d = nullptr;
-        if (o->probe->g) { if (hipMalloc(&d, pb * o->n_stages) != hipSuccess) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); } dPg = (char *)d; }
-        if (o->probe->x_next) { if (hipMalloc(&d, pb * h->hp.D * o->n_stages) != hipSuccess) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); } dPx = (char *)d; }
-        if (o->probe->j_interp) { if (hipMalloc(&d, pb * o->n_stages) != hipSuccess) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); } dPj = (char *)d; }
+        // zero-filled: planes of stages an early stop never runs come back as zeros, like J_stages / idx_stages
+        auto grab = [&](size_t bytes, char **out) {
+            if (hipMalloc(&d, bytes) != hipSuccess) return false;
+            *out = (char *)d;
+            return hipMemset(d, 0, bytes) == hipSuccess;
+        };
+        if (o->probe->g && !grab(pb * o->n_stages, &dPg)) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); }
+        if (o->probe->x_next && !grab(pb * h->hp.D * o->n_stages, &dPx)) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); }
+        if (o->probe->j_interp && !grab(pb * o->n_stages, &dPj)) { cleanup(); return fail(h, HJB_E_NOMEM, "probe buffers"); }
     }
     const bool every_stage = o->progress && o->progress_every_stage;
 #define SOLVE_TRY(expr)                                                                            \
@@ -2047,7 +2039,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     SOLVE_TRY(hipEventRecord(ev0, stream));
     const void *cur = h->dJ[0];
     int pp = 1;  // next ping-pong target
-    int32_t *cur_idx = h->d_idx;
+    const char *cur_idx = h->d_idx;
     int done = 0, early = 0;
     double fprev = 0, iprev = 0, e = 0, e2 = 0;
     int k_s = o->n_stages;
@@ -2078,7 +2070,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
         }
         for (; run > 0; --run, --k_s) {
             void *outJ = dJst ? (void *)(dJst + (size_t)(k_s - 1) * jb) : h->dJ[pp];
-            int32_t *outI = dIst ? dIst + (size_t)(k_s - 1) * nS : h->d_idx;
+            char *outI = dIst ? dIst + (size_t)(k_s - 1) * ib : h->d_idx;
             if (o->probe) {                              // taps of stage k_s: tables at the block, J_{k+1} = cur
                 const size_t pb = (size_t)pr.B * tsz;
                 pr.g = dPg ? dPg + (size_t)(k_s - 1) * pb : nullptr;
@@ -2104,14 +2096,13 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
         // here k_s == stop - 1; the stage just computed has reference index `stop`
         if (o->monitor_period > 0 && (stop % o->monitor_period) == 0) {
             // Solver_pos_att.m:273-285: fsum50 = sum(F.Values(:)), idsum50 = sum(U_Optimal_id(:))
-            st = launch_monitor_sums(h->dtype, cur, cur_idx, nS, h->d_partials, h->d_sums, stream);
+            st = launch_monitor_sums(h->dtype, o->monitor_single != 0 || h->monitor_single, cur, cur_idx, h->idx_bytes, nS, h->d_partials, h->d_sums, stream);
             if (st != HJB_OK) { cleanup(); return fail(h, HJB_E_DEVICE, "monitor reduction launch failed"); }
             double sums[2];
-            {
-                std::shared_lock<std::shared_mutex> lk(g_capture_mu);
-                SOLVE_TRY(hipMemcpyAsync(sums, h->d_sums, sizeof sums, hipMemcpyDeviceToHost, stream));
-                SOLVE_TRY(hipStreamSynchronize(stream));
-            }
+            unsafe_lk.lock();        // the handle's one lock (cleanup() on a failure below sees it held: no second shared lock)
+            SOLVE_TRY(hipMemcpyAsync(sums, h->d_sums, sizeof sums, hipMemcpyDeviceToHost, stream));
+            SOLVE_TRY(hipStreamSynchronize(stream));
+            unsafe_lk.unlock();
             e = sums[0] - fprev;
             e2 = sums[1] - iprev;
             fprev = sums[0];
@@ -2134,12 +2125,12 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     st = check_status(h, stream);
     if (st) { cleanup(); return st; }
     if (o->J_final) SOLVE_TRY(hipMemcpy(o->J_final, cur, jb, hipMemcpyDeviceToHost));
-    if (o->idx_final) SOLVE_TRY(hipMemcpy(o->idx_final, cur_idx, (size_t)nS * 4, hipMemcpyDeviceToHost));
+    if (o->idx_final) SOLVE_TRY(hipMemcpy(o->idx_final, cur_idx, ib, hipMemcpyDeviceToHost));
     if (dPg) SOLVE_TRY(hipMemcpy(o->probe->g, dPg, (size_t)pr.B * tsz * o->n_stages, hipMemcpyDeviceToHost));
     if (dPx) SOLVE_TRY(hipMemcpy(o->probe->x_next, dPx, (size_t)pr.B * tsz * h->hp.D * o->n_stages, hipMemcpyDeviceToHost));
     if (dPj) SOLVE_TRY(hipMemcpy(o->probe->j_interp, dPj, (size_t)pr.B * tsz * o->n_stages, hipMemcpyDeviceToHost));
     if (o->J_stages) SOLVE_TRY(hipMemcpy(o->J_stages, dJst, jb * o->n_stages, hipMemcpyDeviceToHost));
-    if (o->idx_stages) SOLVE_TRY(hipMemcpy(o->idx_stages, dIst, (size_t)nS * 4 * o->n_stages, hipMemcpyDeviceToHost));
+    if (o->idx_stages) SOLVE_TRY(hipMemcpy(o->idx_stages, dIst, ib * o->n_stages, hipMemcpyDeviceToHost));
     cleanup();
     if (res) {
         res->stages_done = done;
@@ -2257,12 +2248,30 @@ int32_t hjb_problem_set_knots(hjb_builder b, int32_t axis, const double *knots, 
     return HJB_OK;
 }
 
-static int add_term(hjb_builder b, hjb_term *slot, uint32_t mask, const void *data, int64_t count, const char *what) {
+// bytes per element of a term array the caller hands in: next-state terms are float64 under table_dtype HJB_TAB_F64
+static size_t term_esz(const hjb_problem &p, bool next_term) {
+    return (p.dtype == HJB_F64 || (next_term && p.table_dtype == HJB_TAB_F64)) ? 8 : 4;
+}
+
+int32_t hjb_problem_set_types(hjb_builder b, int32_t idx_dtype, int32_t table_dtype) {
+    if (!b) return bfail(b, HJB_E_INVALID, "null builder");
+    if (idx_dtype < HJB_IDX_I32 || idx_dtype > HJB_IDX_AUTO) return bfail(b, HJB_E_INVALID, "idx_dtype %d", idx_dtype);
+    if (table_dtype != HJB_TAB_DEFAULT && table_dtype != HJB_TAB_F64) return bfail(b, HJB_E_INVALID, "table_dtype %d", table_dtype);
+    if (table_dtype == HJB_TAB_F64 && b->p.dtype == HJB_F64) return bfail(b, HJB_E_INVALID, "table_dtype HJB_TAB_F64 is for float32 arithmetic");
+    if (table_dtype != b->p.table_dtype)
+        for (int a = 0; a < b->p.D; ++a)
+            if (b->p.n_next_terms[a]) return bfail(b, HJB_E_INVALID, "set the table dtype before adding next-state terms (it is their element type)");
+    b->p.idx_dtype = idx_dtype;
+    b->p.table_dtype = table_dtype;
+    return HJB_OK;
+}
+
+static int add_term(hjb_builder b, hjb_term *slot, uint32_t mask, const void *data, int64_t count, const char *what, bool next_term) {
     if (!data) return bfail(b, HJB_E_INVALID, "%s: null data", what);
     if (mask >> (b->p.D + b->p.C)) return bfail(b, HJB_E_INVALID, "%s: mask 0x%x names a grid dim >= %d", what, mask, b->p.D + b->p.C);
     const int64_t need = term_elems(&b->p, mask);
     if (count != need) return bfail(b, HJB_E_INVALID, "%s: mask 0x%x spans %lld elements, %lld given", what, mask, (long long)need, (long long)count);
-    const size_t esz = b->p.dtype == HJB_F64 ? 8 : 4;
+    const size_t esz = term_esz(b->p, next_term);
     b->blobs.emplace_back((const unsigned char *)data, (const unsigned char *)data + (size_t)count * esz);
     slot->mask = mask;
     slot->reserved = 0;
@@ -2275,7 +2284,7 @@ int32_t hjb_problem_add_next_term(hjb_builder b, int32_t axis, uint32_t mask, co
     if (axis < 0 || axis >= b->p.D) return bfail(b, HJB_E_INVALID, "axis %d not in 0..%d", axis, b->p.D - 1);
     if (b->p.n_next_terms[axis] >= HJB_MAX_TERMS) return bfail(b, HJB_E_UNSUPPORTED, "more than %d terms for axis %d", HJB_MAX_TERMS, axis);
     hjb_term *slot = &b->p.next_terms[axis][b->p.n_next_terms[axis]];
-    const int st = add_term(b, slot, mask, data, count, "next term");
+    const int st = add_term(b, slot, mask, data, count, "next term", true);
     if (st) return st;
     slot->reserved = (uint32_t)b->blobs.size();          // 1-based blob number until hjb_create_from binds the pointer
     ++b->p.n_next_terms[axis];
@@ -2286,7 +2295,7 @@ int32_t hjb_problem_add_cost_term(hjb_builder b, uint32_t mask, const void *data
     if (!b) return bfail(b, HJB_E_INVALID, "null builder");
     if (b->p.n_cost_terms >= HJB_MAX_TERMS) return bfail(b, HJB_E_UNSUPPORTED, "more than %d cost terms", HJB_MAX_TERMS);
     hjb_term *slot = &b->p.cost_terms[b->p.n_cost_terms];
-    const int st = add_term(b, slot, mask, data, count, "cost term");
+    const int st = add_term(b, slot, mask, data, count, "cost term", false);
     if (st) return st;
     slot->reserved = (uint32_t)b->blobs.size();
     ++b->p.n_cost_terms;
@@ -2337,8 +2346,8 @@ int32_t hjb_problem_permute_axes(hjb_builder b, const int32_t *order) {
     int gn[HJB_MAX_G];                                           // old grid sizes of all dims
     for (int a = 0; a < D; ++a) gn[a] = p.n[a];
     for (int c = 0; c < C; ++c) gn[D + c] = p.m[c];
-    const size_t esz = p.dtype == HJB_F64 ? 8 : 4;
-    auto remap = [&](hjb_term &t) {
+    auto remap = [&](hjb_term &t, bool next_term) {
+        const size_t esz = term_esz(p, next_term);
         int od[HJB_MAX_G], k = 0;                                // the term's dims, ascending (old labels) = its storage order
         for (int d = 0; d < D + C; ++d) if ((t.mask >> d) & 1u) od[k++] = d;
         uint32_t nm = 0;
@@ -2372,8 +2381,8 @@ int32_t hjb_problem_permute_axes(hjb_builder b, const int32_t *order) {
         blob.swap(out);
     };
     for (int a = 0; a < D; ++a)
-        for (int k = 0; k < p.n_next_terms[a]; ++k) remap(p.next_terms[a][k]);
-    for (int k = 0; k < p.n_cost_terms; ++k) remap(p.cost_terms[k]);
+        for (int k = 0; k < p.n_next_terms[a]; ++k) remap(p.next_terms[a][k], true);
+    for (int k = 0; k < p.n_cost_terms; ++k) remap(p.cost_terms[k], false);
     hjb_problem q = p;
     std::vector<std::vector<double>> kn((size_t)D);
     for (int i = 0; i < D; ++i) {
@@ -2437,7 +2446,7 @@ int32_t hjb_problem_suggest_order(hjb_builder b, int32_t *order_out, int32_t *fo
             const std::vector<unsigned char> &bl = b->blobs[t.reserved - 1];
             double tl = 0, th = 0;
             for (int u = 0; u < p.m[0]; ++u) {
-                const double v = p.dtype == HJB_F64 ? ((const double *)bl.data())[u] : (double)((const float *)bl.data())[u];
+                const double v = term_esz(p, true) == 8 ? ((const double *)bl.data())[u] : (double)((const float *)bl.data())[u];
                 tl = u == 0 ? v : std::min(tl, v);
                 th = u == 0 ? v : std::max(th, v);
             }
@@ -2509,7 +2518,7 @@ int32_t hjb_problem_free(hjb_builder b) {
 }
 
 int32_t hjb_solve_flat(hjb_handle h, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
-                       void *J_final, int32_t *idx_final, void *J_stages, int32_t *idx_stages, int32_t *stages_done,
+                       void *J_final, void *idx_final, void *J_stages, void *idx_stages, int32_t *stages_done,
                        int32_t *stopped_early, double *sweep_ms) {
     hjb_solve_opts o{};
     o.n_stages = n_stages;
@@ -2559,7 +2568,7 @@ struct hjb_multi_s {
     std::vector<Slab> slabs;
     int need_lo = 0, need_hi = 0, nl = 0, dtype = HJB_F32;
     int64_t inner = 0;
-    size_t esz = 4;
+    size_t esz = 4, isz = 4;                 // bytes per J element / per argmin label
     std::string err;
 };
 
@@ -2619,6 +2628,7 @@ int32_t hjb_create_multi(const hjb_problem *p, int32_t n_dev, const int32_t *dev
     m->dtype = p->dtype;
     m->esz = p->dtype == HJB_F16S ? 2 : (p->dtype == HJB_F32 ? 4 : 8);
     m->inner = pin.n_states / nl;
+    m->isz = (size_t)pin.idx_bytes;
     m->slabs.resize((size_t)n_dev);
     const int base = nl / n_dev, rem = nl % n_dev;
     int b = 0;
@@ -2722,6 +2732,10 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
     if (o->n_stages < 1) return mfail(m, HJB_E_INVALID, "n_stages=%d", o->n_stages);
     if (o->probe)
         return mfail(m, HJB_E_UNSUPPORTED, "hjb_solve_multi takes no probe block (use one device, or drive the slabs yourself)");
+    if (o->monitor_single && o->monitor_period > 0)
+        return mfail(m, HJB_E_UNSUPPORTED, "monitor_single (a float32 running sum in one fixed order over the whole grid) is for one device; "
+                     "hjb_solve_multi adds exact float64 sums over the slabs");
+    const bool every_stage = o->progress && o->progress_every_stage;
     const int n = (int)m->slabs.size();
     const int64_t inner = m->inner;
     const size_t esz = m->esz, plane_b = (size_t)inner * esz;
@@ -2745,7 +2759,7 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
         const int64_t row0 = k < 0 ? 0 : S.part_row0[k], own0 = k < 0 ? 0 : S.part_own0[k];
         const char *in = (const char *)S.whole->dJ[cur] + plane_b * row0;
         char *outp = (char *)S.whole->dJ[cur ^ 1] + plane_b * row0;
-        const int st = launch_stage(h, in, outp, S.whole->d_idx + inner * own0, stream);
+        const int st = launch_stage(h, in, outp, S.whole->d_idx + (size_t)(inner * own0) * m->isz, stream);
         if (st) m->err = h->err;
         return st;
     };
@@ -2809,15 +2823,28 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
             }
             if (st) return mfail(m, st, "stage launch on slab %d: %s", i, m->err.c_str());
             MULTI_TRY(hipEventRecord(S.done[par], S.sc));
-            // per-stage planes (Dynamic_Solver.m:100,105): plane k_s - 1 of the host arrays, this slab's states; the copies
-            // run behind the stage on its compute stream (the output buffer is rewritten two stages on, idx one stage on)
-            const size_t own = (size_t)(S.end - S.begin);
-            const size_t at = (size_t)(k_s - 1) * (size_t)inner * (size_t)m->nl + (size_t)inner * (size_t)S.begin;
-            if (o->J_stages)
-                MULTI_TRY(hipMemcpyAsync((char *)o->J_stages + at * esz, (const char *)S.whole->dJ[cur ^ 1] + plane_b * S.hlo, plane_b * own,
-                                         hipMemcpyDeviceToHost, S.sc));
-            if (o->idx_stages)
-                MULTI_TRY(hipMemcpyAsync(o->idx_stages + at, S.whole->d_idx, (size_t)inner * own * 4, hipMemcpyDeviceToHost, S.sc));
+        }
+        // per-stage planes (Dynamic_Solver.m:100,105): plane k_s - 1 of the host arrays, each slab's states.  Issued once
+        // EVERY slab's stage is enqueued: a copy into pageable host memory holds the host until that slab's stage has
+        // finished, and the other slabs must be computing meanwhile (the output buffer is rewritten two stages on, idx one)
+        if (o->J_stages || o->idx_stages)
+            for (int i = 0; i < n; ++i) {
+                auto &S = m->slabs[(size_t)i];
+                MULTI_TRY(hipSetDevice(S.device));
+                const size_t own = (size_t)(S.end - S.begin);
+                const size_t at = (size_t)(k_s - 1) * (size_t)inner * (size_t)m->nl + (size_t)inner * (size_t)S.begin;
+                if (o->J_stages)
+                    MULTI_TRY(hipMemcpyAsync((char *)o->J_stages + at * esz, (const char *)S.whole->dJ[cur ^ 1] + plane_b * S.hlo, plane_b * own,
+                                             hipMemcpyDeviceToHost, S.sc));
+                if (o->idx_stages)
+                    MULTI_TRY(hipMemcpyAsync((char *)o->idx_stages + at * m->isz, S.whole->d_idx, (size_t)inner * own * m->isz, hipMemcpyDeviceToHost, S.sc));
+            }
+        if (every_stage && !(o->monitor_period > 0 && (k_s % o->monitor_period) == 0)) {    // Dynamic_Solver.m:101: one line per stage
+            for (auto &S : m->slabs) {
+                MULTI_TRY(hipSetDevice(S.device));
+                MULTI_TRY(hipStreamSynchronize(S.sc));
+            }
+            o->progress(o->progress_user, k_s, 0.0, 0.0, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         }
         cur ^= 1;
         // ---- the early-stop monitor (Solver_pos_att.m:273-285): per-slab sums, added on the host ----------------------
@@ -2826,7 +2853,7 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
             for (auto &S : m->slabs) {
                 MULTI_TRY(hipSetDevice(S.device));
                 const char *Jown = (const char *)S.whole->dJ[cur] + plane_b * S.hlo;
-                if (launch_monitor_sums(m->dtype, Jown, S.whole->d_idx, inner * (S.end - S.begin), S.whole->d_partials, S.whole->d_sums, S.sc) != HJB_OK)
+                if (launch_monitor_sums(m->dtype, false, Jown, S.whole->d_idx, (int32_t)m->isz, inner * (S.end - S.begin), S.whole->d_partials, S.whole->d_sums, S.sc) != HJB_OK)
                     return mfail(m, HJB_E_DEVICE, "monitor reduction launch failed");
             }
             for (auto &S : m->slabs) {
@@ -2860,7 +2887,7 @@ int32_t hjb_solve_multi(hjb_multi m, const hjb_solve_opts *o, hjb_result *res) {
             }
         const size_t own = (size_t)(S.end - S.begin);
         if (o->J_final) MULTI_TRY(hipMemcpy((char *)o->J_final + plane_b * S.begin, (const char *)S.whole->dJ[cur] + plane_b * S.hlo, plane_b * own, hipMemcpyDeviceToHost));
-        if (o->idx_final) MULTI_TRY(hipMemcpy(o->idx_final + inner * S.begin, S.whole->d_idx, (size_t)inner * own * 4, hipMemcpyDeviceToHost));
+        if (o->idx_final) MULTI_TRY(hipMemcpy((char *)o->idx_final + (size_t)(inner * S.begin) * m->isz, S.whole->d_idx, (size_t)inner * own * m->isz, hipMemcpyDeviceToHost));
     }
     if (res) {
         res->stages_done = done;
@@ -2884,7 +2911,7 @@ int32_t hjb_create_multi_from(hjb_builder b, int32_t n_dev, const int32_t *devic
 }
 
 int32_t hjb_solve_multi_flat(hjb_multi m, int32_t n_stages, int32_t monitor_period, double monitor_tol, const void *terminal,
-                             void *J_final, int32_t *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms) {
+                             void *J_final, void *idx_final, int32_t *stages_done, int32_t *stopped_early, double *sweep_ms) {
     hjb_solve_opts o{};
     o.n_stages = n_stages;
     o.monitor_period = monitor_period;
@@ -2898,6 +2925,101 @@ int32_t hjb_solve_multi_flat(hjb_multi m, int32_t n_stages, int32_t monitor_peri
     if (stopped_early) *stopped_early = r.stopped_early;
     if (sweep_ms) *sweep_ms = r.sweep_ms;
     return st;
+}
+
+// ---- device-buffer helpers -------------------------------------------------------------------------------------------
+// hjb_backup_stage_device runs on buffers the caller owns.  A host without a HIP binding of its own (MATLAB, plain C)
+// gets them here: allocation, copies, free memory, a separable fill and a gather - enough to drive grids that never
+// exist on the host (C3: 51^6 states, 70 GB per buffer).
+int32_t hjb_device_malloc(int32_t device, int64_t bytes, void **out) {
+    if (!out || bytes < 0) return fail(nullptr, HJB_E_INVALID, "hjb_device_malloc: bad argument");
+    *out = nullptr;
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hipSetDevice(%d) failed", device);
+    void *d = nullptr;
+    const hipError_t e = hipMalloc(&d, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) return fail(nullptr, HJB_E_NOMEM, "hipMalloc of %lld bytes: %s", (long long)bytes, hipGetErrorString(e));
+    *out = d;
+    return HJB_OK;
+}
+
+int32_t hjb_device_free(int32_t device, void *p) {
+    if (!p) return HJB_OK;
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hipSetDevice(%d) failed", device);
+    (void)hipDeviceSynchronize();
+    return hipFree(p) == hipSuccess ? HJB_OK : fail(nullptr, HJB_E_DEVICE, "hipFree failed");
+}
+
+int32_t hjb_device_mem_info(int32_t device, int64_t *free_bytes, int64_t *total_bytes) {
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hipSetDevice(%d) failed", device);
+    size_t f = 0, t = 0;
+    if (hipMemGetInfo(&f, &t) != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hipMemGetInfo failed");
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return HJB_OK;
+}
+
+int32_t hjb_device_copy(int32_t device, void *dst, const void *src, int64_t bytes, int32_t kind) {
+    if (!dst || !src || bytes < 0) return fail(nullptr, HJB_E_INVALID, "hjb_device_copy: bad argument");
+    const hipMemcpyKind k = kind == HJB_COPY_H2D ? hipMemcpyHostToDevice : kind == HJB_COPY_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (kind < HJB_COPY_H2D || kind > HJB_COPY_D2D) return fail(nullptr, HJB_E_INVALID, "hjb_device_copy: kind %d", kind);
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hipSetDevice(%d) failed", device);
+    const hipError_t e = hipMemcpy(dst, src, (size_t)bytes, k);
+    return e == hipSuccess ? HJB_OK : fail(nullptr, HJB_E_DEVICE, "hipMemcpy: %s", hipGetErrorString(e));
+}
+
+int32_t hjb_device_fill_separable(hjb_handle hh, const void *const *vecs, void *dJ, void *stream) {
+    Handle *h = (Handle *)hh;
+    if (!h || !vecs || !dJ) return fail(h, HJB_E_INVALID, "null argument");
+    if (h->j_elems != h->n_owned) return fail(h, HJB_E_UNSUPPORTED, "hjb_device_fill_separable fills whole grids");
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int D = h->hp.D;
+    const size_t tsz = h->dtype == HJB_F64 ? 8 : 4;
+    DSeparable S{};
+    std::vector<void *> tmp;
+    for (int a = 0; a < D; ++a) {
+        if (!vecs[a]) return fail(h, HJB_E_INVALID, "vecs[%d] is null", a);
+        void *d = nullptr;
+        if (hipMalloc(&d, (size_t)h->prob.n[a] * tsz) != hipSuccess) { for (void *t : tmp) (void)hipFree(t); return fail(h, HJB_E_NOMEM, "fill vectors"); }
+        tmp.push_back(d);
+        if (hipMemcpy(d, vecs[a], (size_t)h->prob.n[a] * tsz, hipMemcpyHostToDevice) != hipSuccess) { for (void *t : tmp) (void)hipFree(t); return fail(h, HJB_E_DEVICE, "fill vectors"); }
+        S.v[a] = d;
+        S.n[a] = h->prob.n[a];
+    }
+    S.D = D;
+    S.total = h->n_owned;
+    const unsigned grid = (unsigned)std::min<int64_t>((h->n_owned + 255) / 256, 256 * 64);
+    if (h->dtype == HJB_F16S) hipLaunchKernelGGL((k_fill_separable<float, _Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, S, (_Float16 *)dJ);
+    else if (h->dtype == HJB_F32) hipLaunchKernelGGL((k_fill_separable<float, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, S, (float *)dJ);
+    else hipLaunchKernelGGL((k_fill_separable<double, double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, S, (double *)dJ);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // the vectors are freed below
+    for (void *t : tmp) (void)hipFree(t);
+    if (e != hipSuccess) return fail(h, HJB_E_DEVICE, "hjb_device_fill_separable: %s", hipGetErrorString(e));
+    return HJB_OK;
+}
+
+int32_t hjb_device_gather(int32_t device, const void *d_src, int32_t elem_bytes, const int64_t *sel, int64_t n_sel, void *out) {
+    if (!d_src || !sel || !out || n_sel < 0) return fail(nullptr, HJB_E_INVALID, "hjb_device_gather: bad argument");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return fail(nullptr, HJB_E_INVALID, "hjb_device_gather: elem_bytes %d", elem_bytes);
+    if (n_sel == 0) return HJB_OK;
+    std::shared_lock<std::shared_mutex> lk(g_capture_mu);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hipSetDevice(%d) failed", device);
+    void *dsel = nullptr, *dout = nullptr;
+    hipError_t e = hipMalloc(&dsel, (size_t)n_sel * 8);
+    if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n_sel * elem_bytes);
+    if (e == hipSuccess) e = hipMemcpy(dsel, sel, (size_t)n_sel * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather_bytes, dim3((unsigned)std::min<int64_t>((n_sel + 255) / 256, 65536)), dim3(256), 0, nullptr,
+                           (const unsigned char *)d_src, elem_bytes, (const int64_t *)dsel, n_sel, (unsigned char *)dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n_sel * elem_bytes, hipMemcpyDeviceToHost);
+    if (dsel) (void)hipFree(dsel);
+    if (dout) (void)hipFree(dout);
+    return e == hipSuccess ? HJB_OK : fail(nullptr, HJB_E_DEVICE, "hjb_device_gather: %s", hipGetErrorString(e));
 }
 
 }  // extern "C"

@@ -41,7 +41,7 @@ struct DParams {
     int32_t halo_lo;
     int32_t index_base;
     int32_t n_cost, n_cost_prefix;
-    int32_t pad0;
+    int32_t idx_bytes;        // width of a stored argmin label: 4 (int32), 1 (uint8) or 2 (uint16) - hjb_problem.idx_dtype
     int32_t *status;          // device word, set to 1 when a query leaves the slab
     DAxis axis[HJB_MAX_D];
     DTerm cost[HJB_MAX_TERMS];
@@ -63,5 +63,13 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half_t;
 template <typename T, typename TJ> __device__ __forceinline__ T ldj(const TJ *__restrict__ p, int64_t i) { return (T)p[i]; }
 template <typename T, typename TJ> __device__ __forceinline__ void stj(TJ *__restrict__ p, int64_t i, T v) { p[i] = (TJ)v; }
+
+// Argmin labels are stored as int32, uint8 or uint16 (hjb_problem.idx_dtype; MATLAB's U_Optimal_id of
+// Solver_pos_att.m:272 holds 9 distinct values).  `bytes` is wave-uniform: a scalar branch around one store.
+__device__ __forceinline__ void st_idx(void *__restrict__ base, int64_t i, int32_t v, int32_t bytes) {
+    if (bytes == 4) ((int32_t *)base)[i] = v;
+    else if (bytes == 1) ((uint8_t *)base)[i] = (uint8_t)v;
+    else ((uint16_t *)base)[i] = (uint16_t)v;
+}
 
 }  // namespace hjb

@@ -1,0 +1,43 @@
+// hjbdp_launch.h - the seam between the host side of libhjbdp (hjbdp.hip) and the stage-kernel families, each
+// compiled in a translation unit of its own (stage_*.hip) so that a cold build runs them in parallel
+// (__graft_entry__.build()).  Plain arguments only: a family knows nothing of the handle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hjbdp_dev.h"
+
+namespace hjb {
+
+struct DNested;
+struct DTabled;
+struct DColSweep;
+
+struct StageArgs {
+    unsigned grid = 1, block = 256;
+    size_t lds = 0;
+    hipStream_t st = nullptr;
+    int dtype = HJB_F32;           // HJB_F32 / HJB_F64 / HJB_F16S (float32 arithmetic, binary16 J storage)
+    int D = 1;
+    const DParams *dp = nullptr;
+    const DNested *dn = nullptr;
+    const DTabled *dtb = nullptr;
+    const DColSweep *dcs = nullptr;
+    const void *Jn = nullptr;
+    void *Jo = nullptr;
+    void *idx = nullptr;           // argmin labels, width DParams::idx_bytes
+};
+
+// Each returns 0 when a kernel was enqueued, 1 when the family has no instantiation for (dtype, D, flags).
+int stage_generic(const StageArgs &a);                                           // variant 0
+int stage_nested(const StageArgs &a, bool fast);                                 // variant 1
+int stage_packed(const StageArgs &a);                                            // variant 2
+int stage_ctrlsplit(const StageArgs &a, bool j_in_lds);                          // variant 3
+int stage_packed2(const StageArgs &a, int mode);                                 // variant 4
+int stage_tabled(const StageArgs &a);                                            // variant 5
+int stage_rowwise(const StageArgs &a, bool lean);                                // variant 6
+int stage_colsweep(const StageArgs &a, int gax, int ng, bool fastcost, bool dpp);   // variant 7
+int stage_colcoop(const StageArgs &a, int gax, int ng, bool fastcost);           // variant 7, cooperative form
+int stage_tile2d(const StageArgs &a, const void *plan, int K);                   // K9 (several stages per launch)
+int stage_tile2d_plan(int dtype, const DParams *dp, const DTabled *dtb, void *plan, int64_t n_entries);
+
+}  // namespace hjb

@@ -39,7 +39,7 @@ static_assert(2 + 2 * kCcNCG <= kCcWgWords, "workgroup words");
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, int EPL>
 __global__ void __launch_bounds__(kCcW * 64)
 k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
-                 const TJ *__restrict__ Jn, TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+                 const TJ *__restrict__ Jn, TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");
     static_assert(NG <= kCcNCG, "staged group-axis cells");
     constexpr int D = 4, NW = kCsNW, MM = kCsMMax, W = kCcW, NV = kCcNV, XW = sizeof(TJ) == 2 ? kCcXWh : kCcXW;
@@ -148,7 +148,7 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
     const uint32_t out_col = (uint32_t)i0 + (uint32_t)P->jstride[2] * (uint32_t)i2 + (uint32_t)P->jstride[3] * (uint32_t)(i3 + P->halo_lo);
     const uint32_t idx_col = (uint32_t)i0 + (uint32_t)n0 * (uint32_t)n1 * ((uint32_t)i2 + (uint32_t)n2 * (uint32_t)i3);
     const uint32_t js1 = (uint32_t)P->jstride[1];
-    const int index_base = P->index_base;
+    const int index_base = P->index_base, idx_bytes = P->idx_bytes;
     lds_char *stage = (lds_char *)&s_stage[0];
     typedef __attribute__((address_space(3))) const f4 lds_f4;
     lds_f4 *slots = (lds_f4 *)&s_slots[wave][0];
@@ -226,7 +226,7 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
         stage_load(c1n + 1);                                  // the rows of the next step: a whole step to land
         if (i1 > 0 && valid) {                                // the previous step's results
             stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)(i1 - 1)), best);
-            if (idx_out) idx_out[idx_col + (uint32_t)n0 * (uint32_t)(i1 - 1)] = best_u + index_base;
+            if (idx_out) st_idx(idx_out, idx_col + (uint32_t)n0 * (uint32_t)(i1 - 1), best_u + index_base, idx_bytes);
         }
         // ---- this state's cost without the control terms -----------------------------------------------
         gstep = gcol;
@@ -283,7 +283,7 @@ k_backup_colcoop(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
     }
     if (valid) {
         stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)(n1 - 1)), best);
-        if (idx_out) idx_out[idx_col + (uint32_t)n0 * (uint32_t)(n1 - 1)] = best_u + index_base;
+        if (idx_out) st_idx(idx_out, idx_col + (uint32_t)n0 * (uint32_t)(n1 - 1), best_u + index_base, idx_bytes);
     }
 }
 

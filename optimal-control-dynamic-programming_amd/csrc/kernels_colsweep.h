@@ -254,7 +254,7 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DPP && NG <= 5) ? 5 : 1, (DPP && NG <= 5) ? 5 : 4)))
 k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
-                  const TJ *__restrict__ Jn, TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+                  const TJ *__restrict__ Jn, TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");
     constexpr int D = 4, NW = kCsNW, MM = kCsMMax, LANES = DPP ? kCsDppLanes : 64;
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -382,7 +382,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     const uint32_t out_col = (uint32_t)i0 + (uint32_t)P->jstride[2] * (uint32_t)i2 + (uint32_t)P->jstride[3] * (uint32_t)(i3 + P->halo_lo);
     const uint32_t idx_col = (uint32_t)i0 + (uint32_t)n0 * (uint32_t)n1 * ((uint32_t)i2 + (uint32_t)n2 * (uint32_t)i3);
     const uint32_t js1 = (uint32_t)P->jstride[1];
-    const int index_base = P->index_base;
+    const int index_base = P->index_base, idx_bytes = P->idx_bytes;
     __builtin_amdgcn_wave_barrier();
 
     // the axis-0 lerp of one corner row from the value(s) a lane loaded
@@ -560,7 +560,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                 const int first = i1 - slot;
                 for (int j = 0; j <= slot; ++j) {
                     stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)(first + j)), s_best[wave][j][lane]);
-                    if (idx_out) idx_out[idx_col + (uint32_t)n0 * (uint32_t)(first + j)] = (int32_t)s_idx[wave][j][lane] + index_base;
+                    if (idx_out) st_idx(idx_out, idx_col + (uint32_t)n0 * (uint32_t)(first + j), (int32_t)s_idx[wave][j][lane] + index_base, idx_bytes);
                 }
             }
             // let the stores finish here (and with them the gathers in flight): the counted waits above rely on no

@@ -20,7 +20,7 @@ namespace hjb {
 template <typename T, int D, bool J_IN_LDS>
 __global__ void __launch_bounds__(256)
 k_backup_ctrlsplit(const DParams *__restrict__ P, const T *__restrict__ Jn, T *__restrict__ Jout,
-                   int32_t *__restrict__ idx_out) {
+                   void *__restrict__ idx_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *s_J = reinterpret_cast<T *>(smem_raw);
     const int C = P->C;
@@ -157,7 +157,7 @@ k_backup_ctrlsplit(const DParams *__restrict__ P, const T *__restrict__ Jn, T *_
             }
             const int64_t in_plane = ls % P->inner, pl = ls / P->inner;
             Jout[in_plane + P->inner * (pl + P->halo_lo)] = best;
-            if (idx_out) idx_out[ls] = (int32_t)(label + P->index_base);
+            if (idx_out) st_idx(idx_out, ls, (int32_t)(label + P->index_base), P->idx_bytes);
         }
     }
 }

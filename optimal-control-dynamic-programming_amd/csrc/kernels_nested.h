@@ -123,7 +123,7 @@ __device__ __forceinline__ int term_offset(const DTerm &t, const int (&si)[D], c
 template <typename T, int D, bool FAST>
 __global__ void __launch_bounds__(256)
 k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, const T *__restrict__ Jn,
-                T *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+                T *__restrict__ Jout, void *__restrict__ idx_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const DAxis &axl = P->axis[D - 1];
     const int nl = axl.n;
@@ -398,7 +398,7 @@ k_backup_nested(const DParams *__restrict__ P, const DNested *__restrict__ N, co
         }
         const int64_t in_plane = ls % P->inner, pl = ls / P->inner;
         Jout[in_plane + P->inner * (pl + P->halo_lo)] = best;
-        if (idx_out) idx_out[ls] = (int32_t)(label + P->index_base);
+        if (idx_out) st_idx(idx_out, ls, (int32_t)(label + P->index_base), P->idx_bytes);
     }
 }
 

@@ -116,7 +116,7 @@ constexpr bool kPackedUnroll3 = false;
 template <int D>
 __global__ void __launch_bounds__(256)
 k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, const float *__restrict__ Jn,
-                float *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+                float *__restrict__ Jout, void *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const DAxis &axl = P->axis[D - 1];
@@ -463,7 +463,7 @@ k_backup_packed(const DParams *__restrict__ P, const DNested *__restrict__ N, co
             }
             const int in_plane = ls[s] % inner_sz, pl = ls[s] / inner_sz;
             Jout[in_plane + inner_sz * (pl + P->halo_lo)] = best[s];
-            if (idx_out) idx_out[ls[s]] = label + P->index_base;
+            if (idx_out) st_idx(idx_out, ls[s], label + P->index_base, P->idx_bytes);
         }
     }
 }

@@ -155,7 +155,7 @@ __device__ __forceinline__ float contract_df(const TJ *__restrict__ Jn, int off,
 template <typename TJ, int D, int MODE>
 __global__ void __launch_bounds__(256)
 k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
-                 TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+                 TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
     constexpr bool HIER = MODE != 0;
     constexpr int AX_A = D >= 3 ? D - 3 : 0, AX_B = D >= 2 ? D - 2 : 0;   // the level-0 / level-1 axes of modes 1, 2
@@ -821,7 +821,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             }
             const sidx_t in_plane = ls % inner_sz, pl = ls / inner_sz;
             Jout[in_plane + (sidx_t)inner_sz * (pl + P->halo_lo)] = (TJ)best;
-            if (idx_out) idx_out[ls] = label + P->index_base;
+            if (idx_out) st_idx(idx_out, ls, label + P->index_base, P->idx_bytes);
         }
     }
 }

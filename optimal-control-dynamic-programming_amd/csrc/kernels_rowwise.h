@@ -36,7 +36,7 @@ __device__ __forceinline__ double uniform_value(double x) {
 template <typename T, typename TJ, int D>
 __global__ void __launch_bounds__(256)
 k_backup_rowwise(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
-                 TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+                 TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(D >= 2, "one wave per row needs a second axis");
     constexpr int DR = D - 1;                         // axes 1..D-1: wave-uniform
     constexpr int NR = 1 << (D - 1);                  // corner rows
@@ -194,7 +194,7 @@ k_backup_rowwise(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
                 mul *= P->n[a];
             }
             stj<T, TJ>(Jout, lj, best);
-            if (idx_out) idx_out[ls] = (int32_t)(label + P->index_base);
+            if (idx_out) st_idx(idx_out, ls, (int32_t)(label + P->index_base), P->idx_bytes);
         }
     }
 }
@@ -221,7 +221,7 @@ constexpr int kLeanMaxCu = 4;
 template <typename T, typename TJ, int D>
 __global__ void __launch_bounds__(256)
 k_backup_rowlean(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
-                 TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+                 TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(D >= 2, "one wave per row needs a second axis");
     constexpr int DR = D - 1;
     constexpr int NR = 1 << (D - 1);
@@ -384,7 +384,7 @@ k_backup_rowlean(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
                 mul *= (uint32_t)P->n[a];
             }
             stj<T, TJ>(Jout, lj, best);
-            if (idx_out) idx_out[ls] = label + P->index_base;
+            if (idx_out) st_idx(idx_out, ls, label + P->index_base, P->idx_bytes);
         }
     }
 }

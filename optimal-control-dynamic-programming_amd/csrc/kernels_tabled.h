@@ -67,7 +67,7 @@ k_prep_axis_table_t(const DParams *__restrict__ P, int a, const int32_t *__restr
 template <typename T, typename TJ, int D>
 __global__ void __launch_bounds__(256)
 k_backup_tabled(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
-                TJ *__restrict__ Jout, int32_t *__restrict__ idx_out) {
+                TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     const int C = P->C;
     const int64_t n_owned = P->n_owned;
     const int64_t nU = P->nU;
@@ -187,7 +187,7 @@ k_backup_tabled(const DParams *__restrict__ P, const DTabled *__restrict__ TB, c
         }
         const int64_t in_plane = ls % P->inner, pl = ls / P->inner;
         stj<T, TJ>(Jout, in_plane + P->inner * (pl + P->halo_lo), best);
-        if (idx_out) idx_out[ls] = (int32_t)(label + P->index_base);
+        if (idx_out) st_idx(idx_out, ls, (int32_t)(label + P->index_base), P->idx_bytes);
     }
 }
 

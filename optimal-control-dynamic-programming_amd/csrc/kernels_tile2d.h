@@ -66,7 +66,7 @@ k_tile2d_plan(const DParams *__restrict__ P, const DTabled *__restrict__ TB, Til
 template <typename T, typename TJ>
 __global__ void __launch_bounds__(256)
 k_backup_tile2d_cached(const DParams *__restrict__ P, const TilePlan<T> *__restrict__ plan_, const TJ *__restrict__ Jn,
-                       TJ *__restrict__ Jout, int32_t *__restrict__ idx_out, int K) {
+                       TJ *__restrict__ Jout, void *__restrict__ idx_out, int K) {
     __shared__ T patch[2][kPatchY * kPatchX];
     const int n0 = P->n[0], n1 = P->n[1];
     const int tiles_x = (n0 + kTileX - 1) / kTileX;
@@ -133,7 +133,7 @@ k_backup_tile2d_cached(const DParams *__restrict__ P, const TilePlan<T> *__restr
             dst[(gy - py0) * kPatchX + (gx - px0)] = (T)(TJ)best;
             if (s == K) {
                 Jout[gx + (int64_t)n0 * gy] = (TJ)best;
-                if (idx_out) idx_out[gx + (int64_t)n0 * gy] = best_u + P->index_base;
+                if (idx_out) st_idx(idx_out, gx + (int64_t)n0 * gy, best_u + P->index_base, P->idx_bytes);
             }
         }
         __syncthreads();
@@ -143,7 +143,7 @@ k_backup_tile2d_cached(const DParams *__restrict__ P, const TilePlan<T> *__restr
 template <typename T, typename TJ>
 __global__ void __launch_bounds__(256)
 k_backup_tile2d(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
-                TJ *__restrict__ Jout, int32_t *__restrict__ idx_out, int K) {
+                TJ *__restrict__ Jout, void *__restrict__ idx_out, int K) {
     __shared__ T patch[2][kPatchY * kPatchX];
     const int n0 = P->n[0], n1 = P->n[1];
     const int tiles_x = (n0 + kTileX - 1) / kTileX;
@@ -233,7 +233,7 @@ k_backup_tile2d(const DParams *__restrict__ P, const DTabled *__restrict__ TB, c
                         const int j1 = rr % m1, j0 = rr / m1;
                         label = j0 + (int64_t)P->m[0] * (j1 + (int64_t)m1 * j2);
                     }
-                    idx_out[gx + (int64_t)n0 * gy] = (int32_t)(label + P->index_base);
+                    st_idx(idx_out, gx + (int64_t)n0 * gy, (int32_t)(label + P->index_base), P->idx_bytes);
                 }
             }
         }

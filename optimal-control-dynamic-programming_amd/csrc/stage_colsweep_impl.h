@@ -1,0 +1,31 @@
+// stage_colsweep_impl.h - the instantiations of k_backup_colsweep for one (J storage, group axis) (see stage_colsweep.hip)
+#pragma once
+#include "hjbdp_launch.h"
+#include "kernels_colsweep.h"
+
+namespace hjb {
+
+template <typename TJ, int GAX>
+static int colsweep_go(const StageArgs &a, int ng, bool fastcost, bool dpp) {
+    const dim3 g(a.grid), b(a.block);
+    const TJ *Jn = (const TJ *)a.Jn;
+    TJ *Jo = (TJ *)a.Jo;
+#define HJB_CS(NG)                                                                                                     \
+    case NG:                                                                                                           \
+        if (fastcost) {                                                                                                \
+            if (dpp) hipLaunchKernelGGL((k_backup_colsweep<float, TJ, GAX, NG, true, true>), g, b, 0, a.st, a.dp, a.dtb, a.dcs, Jn, Jo, a.idx);   \
+            else hipLaunchKernelGGL((k_backup_colsweep<float, TJ, GAX, NG, true, false>), g, b, 0, a.st, a.dp, a.dtb, a.dcs, Jn, Jo, a.idx);      \
+        } else {                                                                                                       \
+            if (dpp) hipLaunchKernelGGL((k_backup_colsweep<float, TJ, GAX, NG, false, true>), g, b, 0, a.st, a.dp, a.dtb, a.dcs, Jn, Jo, a.idx);  \
+            else hipLaunchKernelGGL((k_backup_colsweep<float, TJ, GAX, NG, false, false>), g, b, 0, a.st, a.dp, a.dtb, a.dcs, Jn, Jo, a.idx);     \
+        }                                                                                                              \
+        break;
+    switch (ng) {
+        HJB_CS(1) HJB_CS(2) HJB_CS(3) HJB_CS(4) HJB_CS(5) HJB_CS(6)
+        default: return 1;
+    }
+#undef HJB_CS
+    return 0;
+}
+
+}  // namespace hjb

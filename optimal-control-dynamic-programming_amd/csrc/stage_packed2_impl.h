@@ -1,0 +1,34 @@
+// stage_packed2_impl.h - the instantiations of k_backup_packed2 for one J storage type (see stage_packed2.hip)
+#pragma once
+#include "hjbdp_launch.h"
+#include "kernels_packed2.h"
+
+namespace hjb {
+
+template <typename TJ>
+static int packed2_go(const StageArgs &a, int mode) {
+    const dim3 g(a.grid), b(a.block);
+    const TJ *Jn = (const TJ *)a.Jn;
+    TJ *Jo = (TJ *)a.Jo;
+#define HJB_PACKED2(DD)                                                                                              \
+    case DD:                                                                                                         \
+        if (DD == 3 && mode == 1)                                                                                    \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, 3, 1>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
+        else if (DD == 6 && mode == 3)                                                                               \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, 6, 3>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
+        else if (DD >= 4 && mode == 2)                                                                               \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, (DD >= 4 ? DD : 4), 2>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx); \
+        else if (mode == 0)                                                                                          \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, DD, 0>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);          \
+        else                                                                                                         \
+            return 1;                                                                                                \
+        break;
+    switch (a.D) {
+        HJB_PACKED2(1) HJB_PACKED2(2) HJB_PACKED2(3) HJB_PACKED2(4) HJB_PACKED2(5) HJB_PACKED2(6)
+        default: return 1;
+    }
+#undef HJB_PACKED2
+    return 0;
+}
+
+}  // namespace hjb

@@ -24,6 +24,18 @@ HJB_F32 = 0
 HJB_F64 = 1
 HJB_F16S = 2
 
+HJB_IDX_I32 = 0
+HJB_IDX_U8 = 1
+HJB_IDX_U16 = 2
+HJB_IDX_AUTO = 3
+
+HJB_TAB_DEFAULT = 0
+HJB_TAB_F64 = 1
+
+HJB_COPY_H2D = 0
+HJB_COPY_D2H = 1
+HJB_COPY_D2D = 2
+
 HJB_MODEL_NONE = 0
 HJB_MODEL_QUAT_EULER321 = 1
 
@@ -44,14 +56,14 @@ class hjb_problem(C.Structure):
         ("n_next_terms", C.c_int32 * HJB_MAX_D),
         ("next_terms", (hjb_term * HJB_MAX_TERMS) * HJB_MAX_D),
         ("n_cost_terms", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("idx_dtype", C.c_int32),
         ("cost_terms", hjb_term * HJB_MAX_TERMS),
         ("slab_begin", C.c_int32),
         ("slab_end", C.c_int32),
         ("halo_lo", C.c_int32),
         ("halo_hi", C.c_int32),
         ("model", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("table_dtype", C.c_int32),
         ("model_h", C.c_double),
         ("model_tables", C.c_void_p * 4),
     ]
@@ -86,7 +98,7 @@ class hjb_solve_opts(C.Structure):
         ("progress_user", C.c_void_p),
         ("probe", C.POINTER(hjb_probe)),
         ("progress_every_stage", C.c_int32),
-        ("reserved", C.c_int32),
+        ("monitor_single", C.c_int32),
     ]
 
 
@@ -111,6 +123,8 @@ class hjb_info(C.Structure):
         ("grid", C.c_int32),
         ("halo_needed_lo", C.c_int32),
         ("halo_needed_hi", C.c_int32),
+        ("idx_bytes", C.c_int32),
+        ("table_dtype", C.c_int32),
     ]
 
 
@@ -132,6 +146,13 @@ SYMBOLS = {
     "hjb_policy_lookup": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                       C.POINTER(C.POINTER(C.c_double)), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                       C.c_void_p]),
+    # device-buffer helpers
+    "hjb_device_malloc": (C.c_int32, [C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "hjb_device_free": (C.c_int32, [C.c_int32, C.c_void_p]),
+    "hjb_device_mem_info": (C.c_int32, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hjb_device_copy": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "hjb_device_fill_separable": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    "hjb_device_gather": (C.c_int32, [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.c_void_p]),
     "hjb_probe_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(hjb_probe)]),
     # flat builder API (primitives and plain arrays only: what MATLAB's calllib can marshal)
     "hjb_problem_new": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
@@ -140,6 +161,7 @@ SYMBOLS = {
     "hjb_problem_add_next_term": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_int64]),
     "hjb_problem_add_cost_term": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]),
     "hjb_problem_set_slab": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "hjb_problem_set_types": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     "hjb_problem_set_model": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_problem_permute_axes": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hjb_problem_suggest_order": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

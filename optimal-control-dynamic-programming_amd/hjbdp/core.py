@@ -93,6 +93,64 @@ def policy_lookup(knots, values, points, method="nearest", device=0):
     return out
 
 
+class DeviceBuffer:
+    """A device allocation owned through the library (hjb_device_malloc): what a host without a HIP binding of its
+    own hands to Backup.backup_stage_device.  `ptr` is an ordinary HIP device pointer."""
+
+    def __init__(self, nbytes, device=0):
+        self.lib = load_library()
+        self.device, self.nbytes = int(device), int(nbytes)
+        p = C.c_void_p()
+        _check(self.lib, None, self.lib.hjb_device_malloc(self.device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def __int__(self):
+        return self.ptr
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        _check(self.lib, None, self.lib.hjb_device_copy(self.device, self.ptr, a.ctypes.data, a.nbytes, _abi.HJB_COPY_H2D))
+
+    def download(self, dtype, count=None):
+        dt = np.dtype(dtype)
+        out = np.empty(self.nbytes // dt.itemsize if count is None else int(count), dtype=dt)
+        _check(self.lib, None, self.lib.hjb_device_copy(self.device, out.ctypes.data, self.ptr, out.nbytes, _abi.HJB_COPY_D2H))
+        return out
+
+    def gather(self, dtype, sel):
+        """out[i] = buffer[sel[i]] (elements of `dtype`): sample a device-resident array."""
+        dt = np.dtype(dtype)
+        s = np.ascontiguousarray(sel, dtype=np.int64)
+        out = np.empty(s.size, dtype=dt)
+        _check(self.lib, None, self.lib.hjb_device_gather(self.device, self.ptr, dt.itemsize,
+                                                          s.ctypes.data_as(C.POINTER(C.c_int64)), s.size, out.ctypes.data))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.hjb_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def device_mem_info(device=0):
+    lib = load_library()
+    f, t = C.c_int64(), C.c_int64()
+    _check(lib, None, lib.hjb_device_mem_info(int(device), C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
+
 class Backup:
     """A problem resident on one GPU.  Mirrors the C handle one to one."""
 
@@ -151,7 +209,7 @@ class Backup:
         if Jn.size != inf["j_elems"]:
             raise ValueError("J_next has %d elements, the handle's J layout has %d" % (Jn.size, inf["j_elems"]))
         Jo = np.empty_like(Jn)
-        idx = np.empty(inf["n_states"], dtype=np.int32)
+        idx = np.empty(inf["n_states"], dtype=self.spec.idx_np_dtype)
         st = self.lib.hjb_backup_stage(self._h, Jn.ctypes.data, Jo.ctypes.data, idx.ctypes.data)
         _check(self.lib, self._h, st)
         return Jo, idx
@@ -165,12 +223,19 @@ class Backup:
         st = self.lib.hjb_backup_stage_device(self._h, ptr(dJ_next), ptr(dJ_out), ptr(d_idx), int(stream) or None)
         _check(self.lib, self._h, st)
 
+    def fill_separable(self, vecs, dJ, stream=0):
+        """dJ[s] = ((vecs[0][i0] + vecs[1][i1]) + ...) over the whole grid (hjb_device_fill_separable)."""
+        vs = [np.ascontiguousarray(v, dtype=self.spec.dtype) for v in vecs]
+        ptrs = (C.c_void_p * len(vs))(*[v.ctypes.data for v in vs])
+        dp = int(dJ.data_ptr()) if hasattr(dJ, "data_ptr") else int(dJ)
+        _check(self.lib, self._h, self.lib.hjb_device_fill_separable(self._h, ptrs, dp, int(stream) or None))
+
     def check_device_status(self, stream=0):
         _check(self.lib, self._h, self.lib.hjb_check_device_status(self._h, int(stream) or None))
 
     # -- the whole sweep -----------------------------------------------------
     def solve(self, n_stages, terminal=None, keep_J=False, keep_idx=False, monitor_period=0, monitor_tol=0.0,
-              progress=None, progress_every_stage=False, probe=None):
+              progress=None, progress_every_stage=False, probe=None, monitor_single=False):
         """Backward sweep of n_stages backups.  Returns a dict with J (final), idx
         (final), optional J_stages/idx_stages [nS, n_stages] with reference stage
         k_s at column k_s-1, stages_done, stopped_early, sweep_ms.
@@ -190,20 +255,21 @@ class Backup:
             keep.append(t)
             o.terminal = t.ctypes.data
         J = np.empty(nS, dtype=dt)
-        idx = np.empty(nS, dtype=np.int32)
+        idx = np.empty(nS, dtype=self.spec.idx_np_dtype)
         o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
         Js = Is = None
         if keep_J:
             Js = np.zeros((nS, n_stages), dtype=dt, order="F")
             o.J_stages = Js.ctypes.data
         if keep_idx:
-            Is = np.zeros((nS, n_stages), dtype=np.int32, order="F")
+            Is = np.zeros((nS, n_stages), dtype=self.spec.idx_np_dtype, order="F")
             o.idx_stages = Is.ctypes.data
         if progress is not None:
             cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
             keep.append(cb)
             o.progress = cb
         o.progress_every_stage = 1 if progress_every_stage else 0
+        o.monitor_single = 1 if monitor_single else 0
         pout = None
         if probe is not None:
             pout, pb = self._make_probe(probe, n_stages)
@@ -301,7 +367,8 @@ class MultiBackup:
     def set_option(self, key, value):
         self._check(self.lib.hjb_multi_set_option(self._m, key.encode(), int(value)))
 
-    def solve(self, n_stages, terminal=None, keep_J=False, keep_idx=False, monitor_period=0, monitor_tol=0.0, progress=None):
+    def solve(self, n_stages, terminal=None, keep_J=False, keep_idx=False, monitor_period=0, monitor_tol=0.0, progress=None,
+              progress_every_stage=False):
         nS, dt = self.spec.nS, self.spec.j_dtype
         o = _abi.hjb_solve_opts()
         o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
@@ -313,19 +380,20 @@ class MultiBackup:
             keep.append(t)
             o.terminal = t.ctypes.data
         J = np.empty(nS, dtype=dt)
-        idx = np.empty(nS, dtype=np.int32)
+        idx = np.empty(nS, dtype=self.spec.idx_np_dtype)
         o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
         Js = Is = None
         if keep_J:
             Js = np.zeros((nS, n_stages), dtype=dt, order="F")
             o.J_stages = Js.ctypes.data
         if keep_idx:
-            Is = np.zeros((nS, n_stages), dtype=np.int32, order="F")
+            Is = np.zeros((nS, n_stages), dtype=self.spec.idx_np_dtype, order="F")
             o.idx_stages = Is.ctypes.data
         if progress is not None:
             cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
             keep.append(cb)
             o.progress = cb
+        o.progress_every_stage = 1 if progress_every_stage else 0
         res = _abi.hjb_result()
         self._check(self.lib.hjb_solve_multi(self._m, C.byref(o), C.byref(res)))
         return {"J": J, "idx": idx, "J_stages": Js, "idx_stages": Is, "stages_done": res.stages_done, "stopped_early": bool(res.stopped_early),
@@ -350,11 +418,13 @@ def suggest_axis_order(spec):
             raise HjbError(st, (msg or b"").decode())
     ok(lib.hjb_problem_new(spec.D, spec.C, n, m, dt, spec.index_base, C.byref(b)))
     try:
+        if spec.table_dtype is not None:
+            ok(lib.hjb_problem_set_types(b, _abi.HJB_IDX_I32, _abi.HJB_TAB_F64))
         for a in range(spec.D):
             k = np.ascontiguousarray(spec.knots[a], dtype=np.float64)
             ok(lib.hjb_problem_set_knots(b, a, k.ctypes.data_as(C.POINTER(C.c_double)), k.size))
             for t in spec.next_terms[a]:
-                v = np.ascontiguousarray(np.asarray(t.data, dtype=spec.dtype).reshape(-1, order="F"))
+                v = np.ascontiguousarray(np.asarray(t.data, dtype=spec.table_dtype or spec.dtype).reshape(-1, order="F"))
                 ok(lib.hjb_problem_add_next_term(b, a, sum(1 << d for d in t.dims), v.ctypes.data, v.size))
         order = (C.c_int32 * spec.D)()
         found = C.c_int32(0)

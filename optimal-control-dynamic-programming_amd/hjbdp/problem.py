@@ -40,10 +40,26 @@ class Term:
 class ProblemSpec:
     """knots[D] grid vectors (float64 values, rounded to `dtype` by the library -
     pass `single(linspace(..))`-rounded values to mirror test/Dynamic_Solver.m:69),
-    m[C] control grid sizes, next_terms[D][*], cost_terms[*]."""
+    m[C] control grid sizes, next_terms[D][*], cost_terms[*].
 
-    def __init__(self, knots, m, next_terms, cost_terms, dtype=np.float64, index_base=0, j_storage=None, model=None):
+    idx_dtype: storage type of the argmin labels - None / np.int32 (default), np.uint8, np.uint16 or "auto" (the
+    narrowest that holds nU - 1 + index_base; hjbdp.h hjb_problem.idx_dtype).
+    table_dtype: None, or np.float64 with float32 arithmetic = the reference's pos-att typing
+    (Solver_pos_att.m:299-327: double query tables, single F_gI.Values): next_terms are kept in float64, each query
+    is formed, located and weighted in double and the weight rounded to float32 once (hjbdp.h HJB_TAB_F64)."""
+
+    def __init__(self, knots, m, next_terms, cost_terms, dtype=np.float64, index_base=0, j_storage=None, model=None,
+                 idx_dtype=None, table_dtype=None):
         self.dtype = np.dtype(dtype)
+        self.table_dtype = None if table_dtype is None else np.dtype(table_dtype)
+        if self.table_dtype is not None and not (self.table_dtype == np.float64 and self.dtype == np.float32 and model is None):
+            raise ValueError("table_dtype must be float64 with float32 arithmetic (and no state model)")
+        if idx_dtype is None or idx_dtype == "auto":
+            self.idx_dtype = idx_dtype
+        else:
+            self.idx_dtype = np.dtype(idx_dtype)
+            if self.idx_dtype not in (np.dtype(np.int32), np.dtype(np.uint8), np.dtype(np.uint16)):
+                raise ValueError("idx_dtype must be int32, uint8, uint16 or 'auto'")
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise ValueError("dtype must be float32 or float64")
         # j_storage=np.float16: J buffers are IEEE half (float32 arithmetic) - HJB_F16S
@@ -61,7 +77,7 @@ class ProblemSpec:
         if not (1 <= self.C <= _abi.HJB_MAX_C):
             raise ValueError("C=%d not in 1..%d" % (self.C, _abi.HJB_MAX_C))
         g = self.n + self.m
-        self.next_terms = [[self._check(t, g) for t in ts] for ts in next_terms]
+        self.next_terms = [[self._check(t, g, self.table_dtype or self.dtype) for t in ts] for ts in next_terms]
         self.cost_terms = [self._check(t, g) for t in cost_terms]
         if len(self.next_terms) != self.D:
             raise ValueError("need one term list per state axis")
@@ -87,12 +103,22 @@ class ProblemSpec:
         self.nS = int(np.prod(self.n))
         self.nU = int(np.prod(self.m))
 
-    def _check(self, t, g):
+    @property
+    def idx_np_dtype(self):
+        """numpy dtype of the labels the library writes for this spec."""
+        if self.idx_dtype is None:
+            return np.dtype(np.int32)
+        if self.idx_dtype == "auto":
+            top = self.nU - 1 + self.index_base
+            return np.dtype(np.uint8 if top <= 255 else (np.uint16 if top <= 65535 else np.int32))
+        return self.idx_dtype
+
+    def _check(self, t, g, dtype=None):
         for ax, d in enumerate(t.dims):
             if not (0 <= d < self.G) or t.data.shape[ax] != g[d]:
                 raise ValueError("term over dims %s has shape %s, grid is %s" % (t.dims, t.data.shape, g))
         # column-major bytes in the working dtype
-        return Term(t.dims, np.asfortranarray(t.data, dtype=self.dtype))
+        return Term(t.dims, np.asfortranarray(t.data, dtype=dtype or self.dtype))
 
     def to_c(self, slab=None):
         """-> (hjb_problem, keepalive list).  slab = (begin, end, halo_lo, halo_hi)."""
@@ -111,6 +137,9 @@ class ProblemSpec:
             p.m[c] = self.m[c]
         p.dtype = (_abi.HJB_F16S if self.j_dtype == np.float16 else _abi.HJB_F32) if self.dtype == np.float32 else _abi.HJB_F64
         p.index_base = self.index_base
+        p.idx_dtype = {None: _abi.HJB_IDX_I32, "auto": _abi.HJB_IDX_AUTO, np.dtype(np.int32): _abi.HJB_IDX_I32,
+                       np.dtype(np.uint8): _abi.HJB_IDX_U8, np.dtype(np.uint16): _abi.HJB_IDX_U16}[self.idx_dtype]
+        p.table_dtype = _abi.HJB_TAB_F64 if self.table_dtype is not None else _abi.HJB_TAB_DEFAULT
         p.n_cost_terms = len(self.cost_terms)
         for k, t in enumerate(self.cost_terms):
             p.cost_terms[k].mask = t.mask
@@ -151,7 +180,8 @@ def permute_state_axes(spec: ProblemSpec, order):
     nxt = [[remap(t) for t in spec.next_terms[a]] for a in order]
     cost = [remap(t) for t in spec.cost_terms]
     new = ProblemSpec(knots, spec.m, nxt, cost, dtype=spec.dtype, index_base=spec.index_base,
-                      j_storage=None if spec.j_dtype == spec.dtype else spec.j_dtype)
+                      j_storage=None if spec.j_dtype == spec.dtype else spec.j_dtype,
+                      idx_dtype=spec.idx_dtype, table_dtype=spec.table_dtype)
     inv = [order.index(a) for a in range(D)]
 
     def to_old(flat):

@@ -9,13 +9,20 @@ restated as intended: idsum50_prev is read before assignment in the reference).
 The reference saves each controller to a .mat file (:289); here the same four
 variables are kept in `self.controllers[file_name]`.
 
-Typing: the reference keeps J single (`zeros(...,'single')`, :265) with double
-query tables; libhjbdp computes a problem in ONE dtype, so the sweep runs in
-float32 end to end (coordinates and weights included) - the choice SURVEY 8a
-note 6 documents as unpinned by any reference artefact.  The stage cost is by
-default passed as ONE full-mask term holding single(double sum), which is exactly
-`J_current_M = single(...)` (:800-801); cost_mode='terms' passes the five
-separable operands instead (float32 sums, ~1 ulp different, no nS*nU table).
+Typing: the reference keeps J single (`zeros(...,'single')`, :265) with DOUBLE
+grid vectors and query tables (x_next .. w_next, :299-327).  `table_dtype =
+np.float64` (the default here) is that typing: the next-state terms go to the
+library in float64, each query is formed, located and weighted in double and the
+weight rounded to float32 once (hjbdp.h HJB_TAB_F64) - the (cell, weight) tables
+are stage-invariant, so it costs nothing per stage; `table_dtype = None` runs
+float32 end to end.  The stage cost is by default passed as ONE full-mask term
+holding single(double sum), which is exactly `J_current_M = single(...)`
+(:800-801); cost_mode='terms' passes the five separable operands instead (float32
+sums, ~1 ulp different, no nS*nU table: what the large grids use).
+`monitor_single` (default True): the early-stop monitor's `sum(F_gI.Values(:))`
+of a single array is a single-precision sum in MATLAB (:274); its order there is
+not documented, the library's is (csrc/kernels_reduce.h).  U_Optimal_id is kept
+in the narrowest label type (uint8: nine thruster combinations).
 Policy use / forward simulation (:404-847): hjbdp/rollout.py (host-side, get_optimal_path below).
 """
 from __future__ import annotations
@@ -42,11 +49,14 @@ def vectors_allcomb(f1, f2, f3, f4):
 
 
 class Solver_pos_att:
-    # Relabelling of the state axes (x, v, theta, w) -> (x, theta, v, w) for large grids: the two axes whose next value
+    # Relabelling of the state axes (x, v, theta, w) -> (x, theta, w, v) for large grids: the two axes whose next value
     # does not depend on the thrusters (x+ over (x, v), theta+ over (theta, w), :299-328) come first, which is the
-    # shape of libhjbdp's column-sweep stage kernel (csrc/kernels_colsweep.h).  Pure bookkeeping: the 1-D lerps of the
-    # interpolation are taken in the new order (results agree with the reference order to a few ulp).
-    FAST_AXIS_ORDER = (0, 2, 1, 3)
+    # shape of libhjbdp's column-sweep stage kernel (csrc/kernels_colsweep.h); of the two thruster-driven axes the
+    # less-moved one (v: < 1 cell per stage; w moves up to 8 on a 120^4 grid) comes last, where a multi-GPU run shards
+    # with a one-plane halo.  It is what hjb_problem_suggest_order returns for a channel (tests/test_host_solvers.py),
+    # and what axis_order = "auto" asks the library for.  Pure bookkeeping: the 1-D lerps of the interpolation are
+    # taken in the new order (results agree with the reference order to a few ulp per stage).
+    FAST_AXIS_ORDER = (0, 2, 3, 1)
 
     def __init__(self):
         # Solver_pos_att.m:96-195
@@ -78,7 +88,10 @@ class Solver_pos_att:
         self.monitor_period = 50      # :273
         self.monitor_tol = 1e-2       # :269
         self.cost_mode = "exact"
-        self.axis_order = None        # e.g. FAST_AXIS_ORDER: sweep on relabelled axes, results mapped back
+        self.axis_order = None        # FAST_AXIS_ORDER or "auto": sweep on relabelled axes, results mapped back
+        self.table_dtype = np.float64 # the reference's typing of the query tables (:299-327); None = float32 queries
+        self.idx_dtype = "auto"       # U_Optimal_id storage: uint8 for the 9 (6) thruster combinations
+        self.monitor_single = True    # sum(F_gI.Values(:)) as a single-precision sum (:274)
         self.device = 0
         self.controllers = {}
 
@@ -118,7 +131,8 @@ class Solver_pos_att:
                     Term((2,), Qt * s_t ** 2), Term((4,), cu)]
         else:
             raise ValueError("cost_mode must be 'exact' or 'terms'")
-        spec = ProblemSpec([s_x, s_v, s_t, s_w], [len(fa)], nxt, cost, dtype=np.float32, index_base=1)
+        spec = ProblemSpec([s_x, s_v, s_t, s_w], [len(fa)], nxt, cost, dtype=np.float32, index_base=1,
+                           idx_dtype=self.idx_dtype, table_dtype=self.table_dtype)
         return spec, (fa, fb, fc, fd)
 
     def calculate_one_channel_U_Opt(self, s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw, R, J, file_name,
@@ -127,15 +141,20 @@ class Solver_pos_att:
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
         run_spec, to_old = self._relabel(spec)
         with Backup(run_spec, device=self.device) as bk:
-            out = bk.solve(n_st, monitor_period=self.monitor_period, monitor_tol=self.monitor_tol, progress=progress)
+            out = bk.solve(n_st, monitor_period=self.monitor_period, monitor_tol=self.monitor_tol, progress=progress,
+                           monitor_single=self.monitor_single)
         out = self._map_back(out, to_old)
         return self._store_controller(file_name, (s_x, s_v, s_t, s_w), spec.n, combos, out)
 
     def _relabel(self, spec):
-        if self.axis_order is None:
+        order = self.axis_order
+        if order == "auto":
+            from .core import suggest_axis_order
+            order = suggest_axis_order(spec)
+        if order is None:
             return spec, None
         from .problem import permute_state_axes
-        return permute_state_axes(spec, self.axis_order)
+        return permute_state_axes(spec, order)
 
     @staticmethod
     def _map_back(out, to_old):
@@ -213,7 +232,7 @@ class Solver_pos_att:
         rel = [self._relabel(b[0]) for b in built]
         outs, self.wall_ms, _ = solve_many([r[0] for r in rel], n_st, device=self.device,
                                            monitor_period=self.monitor_period, monitor_tol=self.monitor_tol,
-                                           progress=progress)
+                                           progress=progress, monitor_single=self.monitor_single)
         for (args, name), (spec, combos), out, r in zip(jobs, built, outs, rel):
             self._store_controller(name, args[:4], spec.n, combos, self._map_back(out, r[1]))
         return self

@@ -98,12 +98,14 @@ def backup_stage(abi, spec, J_next, slab=None, nthreads=0, impl="scalar"):
 
 
 def sweep(abi, spec, n_stages, terminal=None, keep_J=False, keep_idx=False, monitor_period=0, monitor_tol=0.0,
-          nthreads=0):
+          nthreads=0, monitor_single=False):
+    """Labels come back as int32 whatever spec.idx_dtype says (compare with np.array_equal: it widens)."""
     l = lib(abi)
     p, keep = spec.to_c()
     nS, dt = spec.nS, spec.j_dtype
     o = abi.hjb_solve_opts()
     o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
+    o.monitor_single = 1 if monitor_single else 0
     if terminal is not None:
         t = np.ascontiguousarray(np.asarray(terminal, dtype=dt).reshape(-1, order="F"))
         keep.append(t)

@@ -25,6 +25,12 @@
  *   argmin: strict '<' while visiting controls with control dim 0 SLOWEST
  *           (= cascade min over dims D+C-1, ..., D of Solver_attitude.m:400-409)
  * Compile with -ffp-contract=off so only the explicit fma() contracts.
+ *
+ * hjb_problem.table_dtype == HJB_TAB_F64 (float32 problems): the reference's pos-att typing, Solver_pos_att.m:299-327 -
+ * next-state terms are float64 arrays; q, the cell search (on the float64 knots as given) and the weight
+ * (q - k[c]) * (1 / (k[c+1] - k[c])) are float64, the weight is rounded to float32 once; blend and cost stay float32.
+ * Argmin labels are always written as int32 here, whatever hjb_problem.idx_dtype says (the wrapper widens the
+ * library's labels before comparing).
  */
 #include <immintrin.h>
 #include <math.h>
@@ -153,6 +159,7 @@ static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float
         /* sel != NULL: only the listed (whole-grid) states, outputs compact [nsel];                  \
            jsep != NULL: J_next(i) = ((jsep[0][i0] + jsep[1][i1]) + ...) instead of an array */        \
         const int D = p->D, C = p->C;                                                                  \
+        const int tab64 = p->table_dtype == HJB_TAB_F64 && sizeof(T) == 4;                             \
         T *knots[HJB_MAX_D], *rdx[HJB_MAX_D];                                                          \
         term_t nt[HJB_MAX_D][HJB_MAX_TERMS], ct[HJB_MAX_TERMS];                                        \
         int64_t jstride[HJB_MAX_D];                                                                    \
@@ -201,7 +208,33 @@ static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float
                 T v[1 << HJB_MAX_D];                                                                   \
                 T tw[HJB_MAX_D];                                                                       \
                 int64_t base = 0;                                                                      \
-                for (int a = 0; a < D; ++a) {                                                          \
+                for (int a = 0; a < D && tab64; ++a) {       /* Solver_pos_att.m:299-327: double queries */ \
+                    double q = 0;                                                                      \
+                    for (int k = 0; k < p->n_next_terms[a]; ++k) {                                     \
+                        int64_t off = 0;                                                               \
+                        for (int d = 0; d < D + C; ++d) off += nt[a][k].stride[d] * gi[d];             \
+                        const double x = ((const double *)nt[a][k].data)[off];                         \
+                        q = (k == 0) ? x : q + x;                                                      \
+                    }                                                                                  \
+                    const double *kk = p->knots[a];                                                    \
+                    int lo = 0, hi = p->n[a] - 1;                                                      \
+                    while (hi - lo > 1) {                                                              \
+                        int mid = (lo + hi) >> 1;                                                      \
+                        if (kk[mid] <= q) lo = mid; else hi = mid;                                     \
+                    }                                                                                  \
+                    const double r = 1.0 / (kk[lo + 1] - kk[lo]);                                      \
+                    tw[a] = (T)((q - kk[lo]) * r);               /* rounded to the blend's type once */ \
+                    int cell = lo;                                                                     \
+                    if (a == D - 1) {                                                                  \
+                        cell -= plane0;                                                                \
+                        if (cell < 0 || cell + 1 >= nplanes) {                                         \
+                            err = 1;                                                                   \
+                            cell = cell < 0 ? 0 : nplanes - 2;                                         \
+                        }                                                                              \
+                    }                                                                                  \
+                    base += jstride[a] * cell;                                                         \
+                }                                                                                      \
+                for (int a = 0; a < D && !tab64; ++a) {                                                \
                     T q = (p->model == HJB_MODEL_QUAT_EULER321 && a < 3) ? (T)mq[a] : (T)0;           \
                     for (int k = 0; k < p->n_next_terms[a]; ++k) {                                     \
                         int64_t off = 0;                                                               \
@@ -284,7 +317,7 @@ DEFINE_BACKUP(double, backup_f64, fma)
  * (float32 / float16 storage), no state model, J < 2^31 elements; anything else returns HJB_E_UNSUPPORTED. */
 static int backup_f32_avx2(const hjb_problem *p, const float *Jn, float *Jout, int32_t *idx_out, int nthreads) {
     const int D = p->D, C = p->C;
-    if (p->model) return HJB_E_UNSUPPORTED;
+    if (p->model || p->table_dtype == HJB_TAB_F64) return HJB_E_UNSUPPORTED;
     float *knots[HJB_MAX_D], *rdx[HJB_MAX_D];
     term_t nt[HJB_MAX_D][HJB_MAX_TERMS], ct[HJB_MAX_TERMS];
     int32_t jstride[HJB_MAX_D];
@@ -477,6 +510,41 @@ int orc_backup_states(const hjb_problem *p, const float *const *jsep, const int6
     return backup_f32(p, NULL, J_out, idx_out, nthreads, states, nstates, jsep);
 }
 
+/* hjb_solve_opts.monitor_single: MATLAB's sum(F_gI.Values(:)) of a single array (Solver_pos_att.m:274) is a
+ * single-precision sum in an order MathWorks does not document.  The library states ITS order (csrc/kernels_reduce.h)
+ * and this is that order, element for element, in float32:
+ *   accumulator a (0 <= a < 131072) takes elements a, a + 131072, ... in ascending order;
+ *   block b = a / 256 reduces its 256 accumulators by pairwise halving (s = 128 .. 1: acc[t] += acc[t + s]);
+ *   accumulator t (0 <= t < 256) of the final pass adds block sums t, t + 256 in that order; pairwise halving again. */
+static float single_sum(int dtype, const void *A, int64_t n) {
+    enum { NB = 512, NT = 256 };
+    float *acc = (float *)calloc((size_t)NB * NT, sizeof(float));
+    float part[NB], fin[NT];
+    for (int64_t a = 0; a < (int64_t)NB * NT; ++a) {
+        float s = 0.0f;
+        for (int64_t i = a; i < n; i += (int64_t)NB * NT) {
+            const float x = dtype == HJB_F16S ? h2f(((const uint16_t *)A)[i]) : ((const float *)A)[i];
+            s = s + x;
+        }
+        acc[a] = s;
+    }
+    for (int b = 0; b < NB; ++b) {
+        float *v = acc + (size_t)b * NT;
+        for (int s = NT / 2; s > 0; s >>= 1)
+            for (int t = 0; t < s; ++t) v[t] = v[t] + v[t + s];
+        part[b] = v[0];
+    }
+    for (int t = 0; t < NT; ++t) {
+        float s = 0.0f;
+        for (int b = t; b < NB; b += NT) s = s + part[b];
+        fin[t] = s;
+    }
+    for (int s = NT / 2; s > 0; s >>= 1)
+        for (int t = 0; t < s; ++t) fin[t] = fin[t] + fin[t + s];
+    free(acc);
+    return fin[0];
+}
+
 /* whole-grid backward sweep with the same outputs as hjb_solve. */
 int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, int nthreads) {
     int st = validate(p);
@@ -498,7 +566,7 @@ int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, in
         char *t = A; A = B; B = t;
         ++done;
         if (o->J_stages) memcpy((char *)o->J_stages + (size_t)(k_s - 1) * nS * es, A, nS * es);
-        if (o->idx_stages) memcpy(o->idx_stages + (size_t)(k_s - 1) * nS, idx, nS * sizeof(int32_t));
+        if (o->idx_stages) memcpy((int32_t *)o->idx_stages + (size_t)(k_s - 1) * nS, idx, nS * sizeof(int32_t));
         if (o->monitor_period > 0 && (k_s % o->monitor_period) == 0) {
             double fs = 0, is = 0;
             for (int64_t i = 0; i < nS; ++i) {
@@ -506,6 +574,7 @@ int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, in
                                            : (p->dtype == HJB_F32 ? (double)((float *)A)[i] : ((double *)A)[i]);
                 is += (double)idx[i];
             }
+            if (o->monitor_single && p->dtype != HJB_F64) fs = (double)single_sum(p->dtype, A, nS);
             e = fs - fprev; e2 = is - iprev;
             fprev = fs; iprev = is;
             if (o->progress) o->progress(o->progress_user, k_s, e, e2, 0.0);

@@ -1,4 +1,7 @@
+import faulthandler
+import os
 import sys
+import time
 from pathlib import Path
 
 import pytest
@@ -9,9 +12,53 @@ for p in (str(PKG), str(ROOT)):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# A test that stalls must say where and must not eat the whole run's budget: after
+# HJB_TEST_WATCHDOG_S seconds inside one test every thread's stack goes to stderr and to
+# gpurun_out/pytest_watchdog.log and the process exits (the driver's record then names the test).
+WATCHDOG_S = int(os.environ.get("HJB_TEST_WATCHDOG_S", "240"))
+_wd_file = None
+_t0 = time.time()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "order(n): collection rank (lower runs earlier; default 50)")
+    config.addinivalue_line("markers", "watchdog(seconds): this test's own stall limit (it waits on child processes)")
+
+
+def _watchdog_stream():
+    global _wd_file
+    if _wd_file is None:
+        try:
+            d = ROOT / "gpurun_out"
+            d.mkdir(exist_ok=True)
+            _wd_file = open(d / "pytest_watchdog.log", "a", buffering=1)
+        except OSError:
+            _wd_file = sys.stderr
+    return _wd_file
+
+
+def pytest_runtest_setup(item):
+    if WATCHDOG_S > 0:
+        f = _watchdog_stream()
+        if f is not sys.stderr:
+            f.write("%8.1f s  start %s\n" % (time.time() - _t0, item.nodeid))
+        m = item.get_closest_marker("watchdog")
+        faulthandler.dump_traceback_later(int(m.args[0]) if m else WATCHDOG_S, exit=True, file=f)
+
+
+def pytest_runtest_teardown(item, nextitem):
+    if WATCHDOG_S > 0:
+        faulthandler.cancel_dump_traceback_later()
+
+
+def pytest_collection_modifyitems(config, items):
+    """BASELINE-size parity tests first, torch / torchrun-dependent and stress tests last
+    (stable within a rank): whatever budget a run has, the headline evidence lands first."""
+    def rank(it):
+        m = it.get_closest_marker("order")
+        return m.args[0] if m else 50
+    items.sort(key=rank)
 
 
 @pytest.fixture(scope="session")

@@ -43,7 +43,7 @@ def test_struct_layout_matches_header(lib):
     assert C.sizeof(_abi.hjb_solve_opts) == 4 + 4 + 8 + 8 * 5 + 8 + 8 + 8 + 4 + 4
     assert C.sizeof(_abi.hjb_probe) == 4 * 6 * 2 + 4 * 3 + 4 + 8 * 3
     assert C.sizeof(_abi.hjb_result) == 32
-    assert C.sizeof(_abi.hjb_info) == 48
+    assert C.sizeof(_abi.hjb_info) == 56
 
 
 def test_invalid_problems_are_rejected_with_status(lib):

@@ -22,6 +22,7 @@ def env(built):
     return hjbdp, _abi, c_oracle
 
 
+@pytest.mark.order(1)
 def test_kirk_fixture_through_the_flat_api_only(env, golden):
     """C1a (test/obj_1.txt: 35x35 states x 100 controls, N = 130, float64) solved with nothing but the flat entry
     points, exactly as the MATLAB shim matlab/hjbdp_solve.m drives them: J* within 1e-12 of test/obj_1.mat on all 129

@@ -18,6 +18,7 @@ def env(built):
     return hjbdp, _abi, c_oracle
 
 
+@pytest.mark.order(7)
 def test_solver_position_reference_grid(env):
     """Solver_position.simplified_run on the reference's own 201x201x3 grid, 60 stages."""
     hjbdp, _abi, c_oracle = env
@@ -37,6 +38,7 @@ def test_solver_position_reference_grid(env):
     assert sp.U1_Opt(0.3, 0.2) == -0.26 and sp.U1_Opt(-0.3, -0.2) == 0.26
 
 
+@pytest.mark.order(7)
 def test_solver_position_value_is_monotone_in_horizon(env):
     hjbdp, _abi, c_oracle = env
     sp = hjbdp.Solver_position()
@@ -48,6 +50,7 @@ def test_solver_position_value_is_monotone_in_horizon(env):
     assert np.all(Js[:, :-1] >= Js[:, 1:] - 1e-12)             # J_k non-decreasing as the horizon grows
 
 
+@pytest.mark.order(7)
 def test_solver_attitude_simplified(env):
     hjbdp, _abi, c_oracle = env
     sa = hjbdp.Solver_attitude(n_mesh_t=70, n_mesh_w_simplified=150)
@@ -59,6 +62,7 @@ def test_solver_attitude_simplified(env):
         assert np.array_equal(sa.U_idx[ch].reshape(-1, order="F"), ref["idx"])
 
 
+@pytest.mark.order(7)
 def test_solver_attitude_relabelled_axes(env):
     """run() hands the library the axes with w3 last (control-nested kernel); bit-exact against the
     oracle on the SAME relabelled problem, and equal to the reference labelling up to lerp-order
@@ -75,6 +79,7 @@ def test_solver_attitude_relabelled_axes(env):
     assert np.max(np.abs(sa.F_values.reshape(-1, order="F") - plain["J"]) / np.maximum(1e-3, np.abs(plain["J"]))) < 2e-5
 
 
+@pytest.mark.order(7)
 def test_solver_attitude_on_the_fly_model(env):
     """HJB_MODEL_QUAT_EULER321: next angles computed in the stage kernel (variant 4 mode 3).  Bit-exact against
     the oracle's restatement of the same model; equal to the tabulated form up to the few-ulp difference
@@ -111,48 +116,50 @@ def test_solver_attitude_on_the_fly_model(env):
     assert np.array_equal(out["J"], refh["J"]) and np.array_equal(out["idx"], refh["idx"])
 
 
-def test_c3_full_size_51_pow_6(env):
-    """BASELINE C3: 51^6 = 1.76e10 states x 11^3 torques, one backup on one GPU.  J_k+1, J_k and
-    the argmin table are 70.4 GB each (211 GB of the 288 GB HBM).  J_k+1 is a separable sum of per-axis vectors
-    (built on the device with broadcast adds) so that the CPU checker can evaluate any state without holding
-    the grid: a sample of states must agree with the oracle bit for bit."""
-    import torch
-    hjbdp, _abi, c_oracle = env
-    free, total = torch.cuda.mem_get_info()
-    if free < 225 * 2 ** 30:
-        pytest.skip("needs 225 GB of free HBM, have %.0f GB" % (free / 2 ** 30))
-    sa = hjbdp.Solver_attitude(n_mesh_w=51, n_mesh_q=51)
-    sa.U_vector = np.linspace(-0.11, 0.11, 11)
-    spec = sa.build_spec_model()
-    assert spec.nS == 51 ** 6 and spec.nU == 1331
-    rng = np.random.default_rng(51)
-    vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
-    dev = torch.device("cuda:0")
-    J = torch.empty(spec.nS, dtype=torch.float32, device=dev)
-    Jv = J.view(*reversed(spec.n))                      # torch dim 5-a <-> state axis a (axis 0 fastest)
-    for a, v in enumerate(vecs):
-        shape = [1] * 6
-        shape[5 - a] = -1
-        t = torch.from_numpy(v).to(dev).view(*shape)
-        if a == 0:
-            Jv.copy_(t.expand_as(Jv))
-        else:
-            Jv.add_(t)                                  # one float32 add per element, like the checker
-    Jo = torch.empty_like(J)
-    idx = torch.empty(spec.nS, dtype=torch.int32, device=dev)
+def _separable_backup_on_device(hjbdp, spec, vecs, timed=False):
+    """One backup of `spec` from the separable cost-to-go J(i) = ((vecs[0][i0] + vecs[1][i1]) + ...) built on the device
+    (hjb_device_fill_separable: one float32 add per axis, like the checker): J_next, J and the labels live in HBM only
+    (library-owned buffers - no torch in this process).  -> (dJ_out, d_idx, seconds or None); caller frees."""
+    import time
+    isz = spec.idx_np_dtype.itemsize
+    dJ = hjbdp.DeviceBuffer(spec.nS * 4)
+    dO = hjbdp.DeviceBuffer(spec.nS * 4)
+    dI = hjbdp.DeviceBuffer(spec.nS * isz)
+    secs = None
     with hjbdp.Backup(spec) as bk:
         info = bk.info()
-        assert info["kernel_variant"] == 4 and info["n_states"] == 51 ** 6
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        t0 = torch.cuda.Event(enable_timing=True)
-        t1 = torch.cuda.Event(enable_timing=True)
-        t0.record()
-        bk.backup_stage_device(J, Jo, idx, stream=stream)
-        t1.record()
-        torch.cuda.synchronize()
-        bk.check_device_status(stream)
-        ms = t0.elapsed_time(t1)
-    print("C3 51^6 x 11^3: %.1f s per stage, %.3e backups/s" % (ms * 1e-3, spec.nS * spec.nU / (ms * 1e-3)))
+        assert info["kernel_variant"] == 4 and info["n_states"] == spec.nS
+        bk.fill_separable(vecs, dJ)
+        bk.check_device_status()                       # synchronises
+        t0 = time.perf_counter()
+        bk.backup_stage_device(dJ, dO, dI)
+        bk.check_device_status()
+        if timed:
+            secs = time.perf_counter() - t0
+    dJ.free()
+    return dO, dI, secs
+
+
+@pytest.mark.order(6)
+def test_c3_full_size_51_pow_6(env):
+    """BASELINE C3: 51^6 = 1.76e10 states x 11^3 torques, one backup on one GPU.  J_k+1 and J_k are
+    70.4 GB each, the argmin labels (uint16: 1331 torque triples) 35 GB: 176 GB of the 288 GB HBM.  J_k+1 is a
+    separable sum of per-axis vectors built on the device so that the CPU checker can evaluate any state without
+    holding the grid: a sample of states must agree with the oracle bit for bit."""
+    hjbdp, _abi, c_oracle = env
+    free, total = hjbdp.device_mem_info(0)
+    if free < 190 * 2 ** 30:
+        pytest.skip("needs 190 GB of free HBM, have %.0f GB" % (free / 2 ** 30))
+    sa = hjbdp.Solver_attitude(n_mesh_w=51, n_mesh_q=51)
+    sa.U_vector = np.linspace(-0.11, 0.11, 11)
+    spec0 = sa.build_spec_model()
+    spec = hjbdp.ProblemSpec(spec0.knots, spec0.m, spec0.next_terms, spec0.cost_terms, dtype=np.float32, index_base=spec0.index_base,
+                             model=spec0.model, idx_dtype="auto")
+    assert spec.nS == 51 ** 6 and spec.nU == 1331 and spec.idx_np_dtype == np.uint16
+    rng = np.random.default_rng(51)
+    vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
+    dO, dI, secs = _separable_backup_on_device(hjbdp, spec, vecs, timed=True)
+    print("C3 51^6 x 11^3: %.1f s per stage, %.3e backups/s" % (secs, spec.nS * spec.nU / secs))
     n = np.array(spec.n, dtype=np.int64)
     sel = rng.integers(0, spec.nS, 300)
     # plus grid corners / edges and the very last state (64-bit indexing)
@@ -160,18 +167,20 @@ def test_c3_full_size_51_pow_6(env):
                for cs in ((0,) * 6, (50,) * 6, (50, 0, 50, 0, 50, 0), (0, 50, 0, 50, 0, 50), (25,) * 6, (50, 50, 50, 0, 0, 50))]
     sel = np.unique(np.concatenate([sel, np.array(corners, dtype=np.int64), [spec.nS - 1, 2 ** 31 - 1, 2 ** 31, 2 ** 32 + 5]]))
     Jr, ir = c_oracle.backup_states(_abi, spec, vecs, sel)
-    ts = torch.from_numpy(sel).to(dev)
-    assert np.array_equal(Jo[ts].cpu().numpy(), Jr)
-    assert np.array_equal(idx[ts].cpu().numpy(), ir)
+    try:
+        assert np.array_equal(dO.gather(np.float32, sel), Jr)
+        assert np.array_equal(dI.gather(np.uint16, sel), ir)
+    finally:
+        dO.free(); dI.free()
 
 
+@pytest.mark.order(5)
 @pytest.mark.parametrize("form", ["tabulated", "on_the_fly"])
 def test_6d_24_pow_6_sampled_states(env, form):
     """The 6-D figure DESIGN.md quotes next to C3: Solver_attitude.run's model on a 24^6 = 1.9e8-state grid x 11^3 torques
     (SURVEY 8d), with the next angles tabulated as the reference does (`Solver_attitude.m:449-504`, K3 mode 2) and
     computed on the fly (mode 3).  One backup from a separable J_k+1; a sample of states - corners, edges, random -
     must agree with the oracle bit for bit."""
-    import torch
     hjbdp, _abi, c_oracle = env
     sa = hjbdp.Solver_attitude(n_mesh_w=24, n_mesh_q=24)
     sa.U_vector = np.linspace(-0.11, 0.11, 11)
@@ -182,37 +191,21 @@ def test_6d_24_pow_6_sampled_states(env, form):
     assert spec.nS == 24 ** 6 and spec.nU == 1331
     rng = np.random.default_rng(24)
     vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
-    dev = torch.device("cuda:0")
-    J = torch.empty(spec.nS, dtype=torch.float32, device=dev)
-    Jv = J.view(*reversed(spec.n))                      # torch dim 5-a <-> state axis a (axis 0 fastest)
-    for a, v in enumerate(vecs):
-        shape = [1] * 6
-        shape[5 - a] = -1
-        t = torch.from_numpy(v).to(dev).view(*shape)
-        if a == 0:
-            Jv.copy_(t.expand_as(Jv))
-        else:
-            Jv.add_(t)                                  # one float32 add per element, like the checker
-    Jo = torch.empty_like(J)
-    idx = torch.empty(spec.nS, dtype=torch.int32, device=dev)
-    with hjbdp.Backup(spec) as bk:
-        info = bk.info()
-        assert info["kernel_variant"] == 4 and info["n_states"] == 24 ** 6
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        bk.backup_stage_device(J, Jo, idx, stream=stream)
-        torch.cuda.synchronize()
-        bk.check_device_status(stream)
+    dO, dI, _ = _separable_backup_on_device(hjbdp, spec, vecs)
     n = np.array(spec.n, dtype=np.int64)
     sel = rng.integers(0, spec.nS, 400)
     corners = [sum(int(c) * int(np.prod(n[:a])) for a, c in enumerate(cs))
                for cs in ((0,) * 6, (23,) * 6, (23, 0, 23, 0, 23, 0), (0, 23, 0, 23, 0, 23), (12,) * 6, (23, 23, 23, 0, 0, 23))]
     sel = np.unique(np.concatenate([sel, np.array(corners, dtype=np.int64), [spec.nS - 1]]))
     Jr, ir = c_oracle.backup_states(_abi, spec, vecs, sel)
-    ts = torch.from_numpy(sel).to(dev)
-    assert np.array_equal(Jo[ts].cpu().numpy(), Jr)
-    assert np.array_equal(idx[ts].cpu().numpy(), ir)
+    try:
+        assert np.array_equal(dO.gather(np.float32, sel), Jr)
+        assert np.array_equal(dI.gather(spec.idx_np_dtype, sel), ir)
+    finally:
+        dO.free(); dI.free()
 
 
+@pytest.mark.order(7)
 def test_solver_attitude_full_6d(env):
     """Solver_attitude.run semantics (6-D x 3-D, single) at a reduced size."""
     hjbdp, _abi, c_oracle = env
@@ -226,6 +219,7 @@ def test_solver_attitude_full_6d(env):
     assert set(np.unique(sa.U1_Opt)).issubset({np.float32(-0.11), np.float32(0), np.float32(0.11)})
 
 
+@pytest.mark.order(7)
 def test_solver_pos_att_channel_reference_grid(env):
     """One pos-att channel on the reference's 30x30x20x15x9 grid, 12 stages."""
     hjbdp, _abi, c_oracle = env
@@ -240,6 +234,7 @@ def test_solver_pos_att_channel_reference_grid(env):
     assert c["U_Optimal_id"].min() >= 1 and c["U_Optimal_id"].max() <= 9
 
 
+@pytest.mark.order(7)
 def test_solver_pos_att_all_channels_with_monitor(env):
     """simplified_run (4 channels incl. the thruster-failure one) on a small grid
     with the early-stop monitor; stop stage and results equal the oracle's."""
@@ -263,6 +258,7 @@ def test_solver_pos_att_all_channels_with_monitor(env):
     assert events and all(k % 10 == 0 for k in events)
 
 
+@pytest.mark.order(7)
 def test_dynamic_solver_default_config_runs(env):
     """C1b: the committed constructor defaults (100x100x1000, N=200, single)."""
     hjbdp, _abi, c_oracle = env
@@ -277,6 +273,7 @@ def test_dynamic_solver_default_config_runs(env):
     assert ds.ssu_tol == 0.0 and ds.ssu_err_first == 0.0
 
 
+@pytest.mark.order(3)
 def test_c4_full_size_plane_vs_oracle(env):
     """BASELINE configs[3] size (pos-att channel on 120^4 = 2.07e8 cells x 9 thruster combinations,
     non-uniform sym_linspace knots): one stage on the GPU from a smooth terminal cost; one whole
@@ -306,6 +303,7 @@ def test_c4_full_size_plane_vs_oracle(env):
     assert np.array_equal(io, idx.reshape(n3, 120, order="F")[:, p])
 
 
+@pytest.mark.order(3)
 @pytest.mark.parametrize("j_storage", [None, np.float16])
 def test_c4_c5_full_size_colsweep_plane_vs_oracle(env, j_storage):
     """BASELINE configs[3] and [4] (C4: pos-att 120^4 x 9 float32; C5: the same with float16 cost-to-go storage) on the
@@ -319,7 +317,7 @@ def test_c4_c5_full_size_colsweep_plane_vs_oracle(env, j_storage):
     sx, sv, st, sw = pa.grids()
     spec0, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
                                      pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
-    spec, _ = hjbdp.permute_state_axes(spec0, hjbdp.Solver_pos_att.FAST_AXIS_ORDER)
+    spec, _ = hjbdp.permute_state_axes(spec0, (0, 2, 1, 3))        # (x, theta, v, w): the w-last labelling, wide halo
     if j_storage is not None:
         spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=1,
                                  j_storage=j_storage)
@@ -342,6 +340,7 @@ def test_c4_c5_full_size_colsweep_plane_vs_oracle(env, j_storage):
         assert np.array_equal(io, idx.reshape(n3, 120, order="F")[:, p]), p
 
 
+@pytest.mark.order(4)
 def test_c4_bench_order_as_eight_slabs_full_size(env):
     """BASELINE configs[3] as bench.py runs it - pos-att 120^4 x 9, axes (x, theta, w, v), the last axis v sharded - in
     its 8-GPU form on the one GPU of the box: hjb_solve_multi with eight slabs of 15 planes (halo of ONE plane each way,

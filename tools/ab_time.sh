@@ -1,12 +1,9 @@
 #!/bin/bash
 # A/B timing of two builds of the library on ONE box (the pool's boxes clock 2.15 - 2.21 GHz): build/ab/A.so, build/ab/B.so
+# (the loader takes the alternate build from HJBDP_LIB, hjbdp/core.py: the in-tree library is never overwritten)
 cd "$GRAFT_REPO_ROOT" || exit 1
-L=optimal-control-dynamic-programming_amd/hjbdp/libhjbdp.so
-cp $L /tmp/orig.so
 for rep in 1 2; do
 for v in A B; do
-  cp build/ab/$v.so $L
-  ORDER=0,2,3,1 timeout 300 python3 tools/time_posatt.py 120 50 7 2>&1 | grep "ran 7" | sed "s/^/$v: /"
+  HJBDP_LIB="$PWD/build/ab/$v.so" ORDER=0,2,3,1 timeout 300 python3 tools/time_posatt.py 120 50 7 2>&1 | grep "ran 7" | sed "s/^/$v: /"
 done
 done
-cp /tmp/orig.so $L

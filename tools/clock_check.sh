@@ -4,7 +4,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/clock; rm -rf $O; mkdir -p $O
 export ORDER=0,2,3,1
-if [ -n "$LIB" ]; then cp optimal-control-dynamic-programming_amd/hjbdp/libhjbdp.so /tmp/keep.so; cp "$LIB" optimal-control-dynamic-programming_amd/hjbdp/libhjbdp.so; fi
+# an alternate build is handed to the loader (hjbdp/core.py reads HJBDP_LIB); the in-tree library is never overwritten
+if [ -n "$LIB" ]; then export HJBDP_LIB="$(realpath "$LIB")"; fi
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/p -- python3 bench.py --pmc-child --workload c4 --steps 30 --warmup 5 > $O/log.txt 2>&1
 python3 - <<PY
 import csv, glob
