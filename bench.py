@@ -4,10 +4,13 @@
 Metric  : Bellman backups/s (state x control x stage)                     [BASELINE.json `metric`]
 Workload: C4, the configuration the north-star target is quoted on ("the 6-D pos-att grid", BASELINE.json
           configs[3]): ONE channel of Solver_pos_att (pos-att/Solver_pos_att.m:244-297) on a 120^4 = 2.07e8-cell
-          sym_linspace grid x the 9 thruster combinations, float32, zero terminal cost
-          (Solver_pos_att.m:264-265), state axes relabelled (x, theta, w, v) - see Solver_pos_att.FAST_AXIS_ORDER.
+          sym_linspace grid x the 9 thruster combinations, the reference's typing (single J and
+          cost, DOUBLE query tables :299-327 = table_dtype float64; U_Optimal_id as one byte per state), zero terminal
+          cost (Solver_pos_att.m:264-265), state axes relabelled (x, theta, w, v) = Solver_pos_att.FAST_AXIS_ORDER.
           The other BASELINE configs are measured in the same run as extra keys of the line (`other_workloads`:
-          C5 = C4 with float16 cost-to-go storage, C2 = Solver_position 101^3 x 21^3); they are also parity tests.
+          C5 = C4 with float16 cost-to-go storage, C2 = Solver_position 101^3 x 21^3, 6D = the attitude model of
+          Solver_attitude.run on 24^6 states x 11^3 torques - SURVEY 8(d)'s "6-D" figure), each with its own roofline
+          object from the same live counter passes; they are also parity tests.
 Step    : ONE stage of the backward sweep = one fused backup kernel over the whole grid (1.866e9 backups).
 N GPUs  : one process per GPU (torchrun), the FIXED grid sharded along its last state axis (v: next states move
           < 1 plane, so the halo is one plane each side) = STRONG scaling; neighbour halo exchange per stage over RCCL
@@ -43,6 +46,11 @@ PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_CYCLES_PER_WAVE_INSTR = 2.0   # wave64 on a SIMD-32 (MI355X_MICROARCH.md; profiles/r02_valu_rate.json)
 KERNEL_OF_VARIANT = {7: "k_backup_colsweep", 6: "k_backup_row", 5: "k_backup_tabled", 4: "k_backup_packed2",
                      2: "k_backup_packed", 1: "k_backup_nested", 3: "k_backup_ctrlsplit", 0: "k_backup_generic"}
+# how the stage kernel of each workload is told apart in one rocprofv3 pass over all of them (demangled names)
+# (substring the name must hold, substring it must not hold): the binary16 type is spelt differently by demanglers
+KERNEL_FILTER = {"c4": ("k_backup_colsweep<float, float", None), "c5": ("k_backup_colsweep<float, ", "k_backup_colsweep<float, float"),
+                 "c2": ("k_backup_packed2<float, 3", None), "6d": ("k_backup_packed2<float, 6", None)}
+EXTRA_STEPS = {"c5": 20, "c2": 20, "6d": 4}
 
 
 def f_alg(D):
@@ -66,18 +74,32 @@ def build_spec(workload, n_last=None, n=120):
                                         pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
         order = hjbdp.suggest_axis_order(spec)                            # what the library proposes for the reference's (x, v, theta, w):
         assert order == (0, 2, 3, 1), order                              # (x, theta, w, v) - v last = the sharded axis
+        assert order == hjbdp.Solver_pos_att.FAST_AXIS_ORDER
         spec, _ = hjbdp.permute_state_axes(spec, order)
         if workload == "c5":
             spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32,
-                                     index_base=1, j_storage=np.float16)
-        name = "%s Solver_pos_att channel x: %s states (x,theta,w,v) x %d thruster combinations, %s, 1 stage per step" % (
+                                     index_base=1, j_storage=np.float16, idx_dtype=spec.idx_dtype, table_dtype=spec.table_dtype)
+        assert spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8
+        name = "%s Solver_pos_att channel x: %s states (x,theta,w,v) x %d thruster combinations, %s, float64-built query tables, uint8 argmin, 1 stage per step" % (
             workload.upper(), "x".join(str(k) for k in spec.n), spec.nU,
             "float32" if workload == "c4" else "float32 arithmetic, float16 cost-to-go storage")
         return spec, name
+    if workload == "6d":
+        # "also a 6-D 24^6 variant of C3's model for the north-star '6-D' figure": Solver_attitude.run
+        # (attitude-control/Solver_attitude.m:261-300) with next angles tabulated as the reference does (:449-504)
+        sa = hjbdp.Solver_attitude(n_mesh_w=24, n_mesh_q=24)
+        sa.U_vector = np.linspace(-0.11, 0.11, 11)
+        spec0 = sa.build_spec_full()
+        spec, _ = hjbdp.permute_state_axes(spec0, sa.AXIS_ORDER)
+        spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=spec.index_base,
+                                 idx_dtype="auto")
+        return spec, "6D Solver_attitude.run model: %s states (yaw,pitch,roll,w1,w2,w3) x 11^3 torques, float32, uint16 argmin, 1 stage per step" % "x".join(str(k) for k in spec.n)
     if workload == "c2":
         from hjbdp.synthetic import position3d_spec
         spec = position3d_spec(n=101, mu=21, n_last=n_last)
-        return spec, "C2 Solver_position 3-DOF: %s states x 21^3 controls, float32, 1 stage per step" % "x".join(str(k) for k in spec.n)
+        spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=spec.index_base,
+                                 idx_dtype="auto")
+        return spec, "C2 Solver_position 3-DOF: %s states x 21^3 controls, float32, uint16 argmin, 1 stage per step" % "x".join(str(k) for k in spec.n)
     raise ValueError(workload)
 
 
@@ -138,15 +160,17 @@ def cpu_baseline(spec, budget_s=15.0, dataflow_spec=None):
     return out
 
 
-def collect_pmc(argv_child, kernel_filter, timeout_s=240):
+def collect_pmc(argv_child, kernel_filters, timeout_s=420):
     """rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) on child processes running
-    `bench.py --pmc-child ...`; mean per launch of the stage kernel.  Runs BEFORE this process touches the GPU."""
+    `bench.py --pmc-child ...` over every workload of this run; mean per launch of each workload's stage kernel
+    (kernel_filters: workload -> substring of the demangled kernel name).  Runs BEFORE this process touches the GPU.
+    -> ({workload: {counter: mean per launch}}, note)"""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(rocprof).exists():
         return None, "rocprofv3 not found"
     sets = [["FETCH_SIZE"], ["WRITE_SIZE"],
             ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]]
-    out, notes = {}, []
+    out, notes = {w: {} for w in kernel_filters}, []
     tmp = tempfile.mkdtemp(prefix="hjb_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
     try:
@@ -162,19 +186,22 @@ def collect_pmc(argv_child, kernel_filter, timeout_s=240):
             if r.returncode != 0:
                 notes.append("pass %d rc=%d" % (i, r.returncode))
                 continue
-            acc = {}
+            acc = {w: {} for w in kernel_filters}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if kernel_filter in row["Kernel_Name"]:
-                            a = acc.setdefault(row["Counter_Name"], [0.0, 0])
-                            a[0] += float(row["Counter_Value"])
-                            a[1] += 1
-            for k, (s, n) in acc.items():
-                out[k] = s / n
-                out.setdefault("_launches", {})[k] = n
+                        for w, (kf, knot) in kernel_filters.items():
+                            if kf in row["Kernel_Name"] and not (knot and knot in row["Kernel_Name"]):
+                                # one row per (dispatch, counter[, dimension instance]): sum the instances of a dispatch, then
+                                # average over the dispatches
+                                a = acc[w].setdefault(row["Counter_Name"], {})
+                                a[row["Dispatch_Id"]] = a.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            for w in kernel_filters:
+                for k, per in acc[w].items():
+                    out[w][k] = sum(per.values()) / len(per)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    out = {w: v for w, v in out.items() if v}
     return (out or None), "; ".join(notes)
 
 
@@ -182,7 +209,7 @@ def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=Fal
     """Times `steps` stages of `workload` on this rank's slab.  -> dict of measurements."""
     import torch
     from hjbdp.sharded import ShardedSweep
-    n = args.grid_n if workload != "c2" else 101
+    n = {"c2": 101, "6d": 24}.get(workload, args.grid_n)
     spec, name = build_spec(workload, n_last=n * world if weak else None, n=args.grid_n)
     sw = ShardedSweep(spec, rank, world, dev, overlap=not args.no_overlap)
     if args.variant is not None:
@@ -229,7 +256,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c5", "c2"], help="headline workload (default: C4)")
+    ap.add_argument("--workload", default="c4", choices=["c4", "c5", "c2", "6d"], help="headline workload (default: C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs / the weak-scaling figure")
@@ -250,13 +277,19 @@ def main():
         args.gpus = world
 
     # ---- PMC passes on child processes, before this process initialises the GPU ------------------------------
-    pmc, pmc_note = None, "not collected"
+    extras = [w for w in ("c5", "c2", "6d") if w != args.workload] if (world == 1 and not args.no_extras and args.grid_n == 120) else []
+    pmc_all, pmc_note = None, "not collected"
     if world == 1 and not args.pmc_child and not args.no_pmc:
-        child = ["--workload", args.workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-pmc",
+        child = ["--workload", args.workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc",
                  "--grid-n", str(args.grid_n)]
+        if not extras:
+            child.append("--no-extras")
         if args.variant is not None:
             child += ["--variant", str(args.variant)]
-        pmc, pmc_note = collect_pmc(child, "k_backup_")
+        filt = {w: KERNEL_FILTER[w] for w in [args.workload] + extras}
+        if args.variant is not None:
+            filt[args.workload] = (KERNEL_OF_VARIANT.get(args.variant, "k_backup_"), None)
+        pmc_all, pmc_note = collect_pmc(child, filt)
 
     import numpy as np  # noqa: F401
     import torch
@@ -278,27 +311,54 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     head = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist)
-    if args.pmc_child:
+    if args.pmc_child:                      # the counter passes: a few launches of every workload's stage kernel, nothing else
+        for w in extras:
+            run_workload(args, w, 2, 1, world, rank, dev, dist)
         return
     spec, info = head["spec"], head["info"]
     value = head["total_backups"] / head["wall"]
-    launch_ms = head["dev_ms"] / args.steps                       # rank 0's stage time (one fused kernel; N > 1: + boundary launches)
-    D = spec.D
-    backups_per_launch = head["states_rank"] * spec.nU
-    alg_flops = f_alg(D) * backups_per_launch
-    alg_bytes = (2 * spec.j_dtype.itemsize + 4) * head["states_rank"]   # read J_{k+1}, write J_k + int32 argmin
-    tflops = alg_flops / (launch_ms * 1e-3) / 1e12
-    gbs = alg_bytes / (launch_ms * 1e-3) / 1e9
-    kname = KERNEL_OF_VARIANT.get(info["kernel_variant"], "k_backup")
-    traffic = valu_util = None
-    pmc_out = None
-    if pmc:
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # rocprofv3 reports KiB
-        if "SQ_INSTS_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
-            cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                                   # summed over the 8 XCDs
-            valu_util = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_WAVE_INSTR / (1024.0 * cyc)
-        pmc_out = {k: v for k, v in pmc.items() if not k.startswith("_")}
+
+    def roofline_of(res, workload):
+        """The roofline object of one workload: algorithmic flops and bytes per launch over the HIP-event launch time,
+        the executed-instruction view and the HBM traffic from this run's own counter passes."""
+        sp, inf = res["spec"], res["info"]
+        launch_ms = res["dev_ms"] / res["steps"]                   # rank 0's stage time (one fused kernel; N > 1: + boundary launches)
+        backups = res["states_rank"] * sp.nU
+        bytes_state = 2 * sp.j_dtype.itemsize + sp.idx_np_dtype.itemsize      # read J_{k+1}, write J_k + the argmin label
+        tflops = f_alg(sp.D) * backups / (launch_ms * 1e-3) / 1e12
+        gbs = bytes_state * res["states_rank"] / (launch_ms * 1e-3) / 1e9
+        kname = KERNEL_OF_VARIANT.get(inf["kernel_variant"], "k_backup")
+        pmc = (pmc_all or {}).get(workload)
+        traffic = valu_util = None
+        if pmc:
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # rocprofv3 reports KiB
+            if "SQ_INSTS_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
+                cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                                   # summed over the 8 XCDs
+                valu_util = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_WAVE_INSTR / (1024.0 * cyc)
+        rf = {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
+              "traffic": traffic, "kernel": kname, "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(sp.D),
+              "alg_bytes_per_launch": bytes_state * res["states_rank"], "valu_issue_util": valu_util, "pmc": pmc,
+              "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "alg_bytes_per_state": bytes_state}}
+        if rf["frac"] > 1.0:
+            # F_alg prices every backup at a full N-linear interpolation; this kernel contracts the axes the innermost
+            # controls do not move once per outer control step, so it executes a fraction of those flops: the credit is
+            # not a utilisation.  The executed-instruction view (valu_issue_util) is the fraction to read.
+            rf["alg_flops_credit_TFLOPs"] = tflops
+            rf["achieved"] = None if valu_util is None else valu_util * PEAK_FP32_TFLOPS
+            rf["frac"] = valu_util
+            rf["frac_is"] = "valu_issue_util (F_alg credit %.1f TFLOP/s exceeds the vector peak: shared interpolation work)" % tflops
+        return rf
+
+    rf = roofline_of(head, args.workload)
+    kname = rf["kernel"]
+    rf["pmc_source"] = ("rocprofv3 --pmc passes made by this run on `bench.py --pmc-child --workload %s --steps 3` (one child per "
+                        "counter set, every workload of this line in it; mean per launch of each stage kernel; FETCH_SIZE / "
+                        "WRITE_SIZE in KiB, dword-per-lane accesses count 1x)" % args.workload) if pmc_all else pmc_note
+    rf["note"] = ("fp32 VALU binds (SURVEY 8d), not HBM and not MFMA (interpolation is a gather; K = D <= 6); peak = fp32 vector "
+                  "peak = f32-input MFMA peak.  achieved = ALGORITHMIC flops (F_alg(D) per backup) / launch time; the "
+                  "kernel shares the control-independent lerps between the controls, so it executes fewer.  "
+                  "valu_issue_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8): the executed-instruction view")
     out = {
         "metric": "bellman_backups_per_s", "value": value, "unit": "backups/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["wall"] * 1e3 / args.steps,
@@ -311,32 +371,17 @@ def main():
                                    "RCCL" if args.backend == "nccl" else args.backend + " (test transport)",
                                    "" if args.no_overlap else ", overlapped with the interior planes")) if world > 1 else "none",
                    "kernel_variant": info["kernel_variant"]},
-        "roofline": {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                     "kernel": kname, "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(D),
-                     "valu_issue_util": valu_util,
-                     "pmc": pmc_out, "pmc_source": ("rocprofv3 --pmc passes made by this run on `bench.py --pmc-child --workload %s --steps 3` "
-                                                    "(mean per launch of %s*; FETCH_SIZE/WRITE_SIZE in KiB, dword-per-lane accesses count 1x)"
-                                                    % (args.workload, kname)) if pmc else pmc_note,
-                     "note": "fp32 VALU binds (SURVEY 8d), not HBM and not MFMA (interpolation is a gather; K = D <= 6); peak = fp32 vector "
-                             "peak = f32-input MFMA peak.  achieved = ALGORITHMIC flops (F_alg(4) = 71 per backup) / launch time; the "
-                             "kernel shares the two control-independent lerps between the 9 controls, so it executes fewer.  "
-                             "valu_issue_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8): the executed-instruction view",
-                     "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                             "alg_bytes_per_state": 2 * spec.j_dtype.itemsize + 4}},
+        "roofline": rf,
         "checksum_sum_J": head["checksum"],
     }
     if not args.no_extras:
         if world == 1:
             others = {}
-            for w in ("c5", "c2"):
-                if w == args.workload:
-                    continue
-                r = run_workload(args, w, 20, 3, world, rank, dev, dist)
+            for w in extras:
+                r = run_workload(args, w, EXTRA_STEPS[w], 2, world, rank, dev, dist)
                 others[w] = {"workload": r["name"], "value": r["total_backups"] / r["wall"], "unit": "backups/s",
                              "ms_per_step": r["wall"] * 1e3 / r["steps"], "kernel_variant": r["info"]["kernel_variant"],
-                             "alg_TFLOPs": f_alg(r["spec"].D) * r["total_backups"] / r["wall"] / 1e12,
-                             "checksum_sum_J": r["checksum"]}
+                             "roofline": roofline_of(r, w), "checksum_sum_J": r["checksum"]}
             out["other_workloads"] = others
         else:
             r = run_workload(args, args.workload, max(10, args.steps // 2), 3, world, rank, dev, dist, weak=True)
@@ -344,7 +389,12 @@ def main():
                                    "ms_per_step": r["wall"] * 1e3 / r["steps"], "states_per_gpu": r["states_rank"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         small = build_spec(args.workload, n=32)[0] if args.workload in ("c4", "c5") else None
-        out["cpu_baseline"] = cpu_baseline(spec, dataflow_spec=small)
+        # the CPU forms locate their queries in float32 (the AVX2 twin has no float64-query mode): same grid, same
+        # controls, same number of operations - the typing of the weights is the only difference from the GPU workload
+        cspec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=spec.dtype, index_base=spec.index_base,
+                                  j_storage=None if spec.j_dtype == spec.dtype else spec.j_dtype)
+        out["cpu_baseline"] = cpu_baseline(cspec, dataflow_spec=small)
+        out["cpu_baseline"]["sample"] += "; float32 queries (the GPU line uses float64-built query tables)"
     if world > 1:
         dist.barrier()
     if rank == 0:

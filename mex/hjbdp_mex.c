@@ -12,7 +12,11 @@
  *   prob.cost_terms  struct array (dims, data): the summands of the stage cost (g_D, :196-200)
  *   prob.terminal    optional terminal cost [nS] (default zeros, :83-84)
  *   opts             struct, all fields optional: keep_stages (false), monitor_period (0), monitor_tol (0), devices (0;
- *                    a vector partitions the last state axis over those GPUs: hjb_create_multi_from)
+ *                    a vector partitions the last state axis over those GPUs: hjb_create_multi_from), double_tables
+ *                    (false; true with prob.single: next_terms data stay double and the queries are located and weighted
+ *                    in double - the typing of pos-att/Solver_pos_att.m:299-327, hjbdp.h HJB_TAB_F64), monitor_single
+ *                    (false; true: the monitor's sum(F.Values(:)) is a single-precision sum, Solver_pos_att.m:274).
+ *                    The state axes are never relabelled here (hjbdp_solve.m's 'fast_axes' is off by default too).
  *   out              struct: J, idx (double, 1-based, as MATLAB's min returns), J_stages, idx_stages ([nS x n_stages],
  *                    stage k_s in column k_s, only with keep_stages), stages_done, stopped_early, sweep_ms
  *
@@ -81,17 +85,21 @@ static void *term_data(const mxArray *data, int use_single, int64_t *count) {
     }
 }
 
-static uint32_t dims_to_mask(const mxArray *dims) {
+static uint32_t dims_to_mask(const mxArray *dims, int n_grid_dims) {
     const size_t n = mxGetNumberOfElements(dims);
-    const double *d = mxGetPr(dims);
+    const double *d;
     uint32_t m = 0;
     size_t i;
     if (!mxIsDouble(dims)) fail("hjbdp:arg", "term dims", "must be double");
-    for (i = 0; i < n; ++i) m |= 1u << ((int)d[i] - 1);          /* MATLAB dims are 1-based */
+    d = mxGetPr(dims);
+    for (i = 0; i < n; ++i) {                                  /* MATLAB dims are 1-based: 1 .. D + C */
+        if (!(d[i] >= 1 && d[i] <= n_grid_dims) || d[i] != (double)(int)d[i]) fail("hjbdp:arg", "term dims", "must be integers in 1..D+C");
+        m |= 1u << ((int)d[i] - 1);
+    }
     return m;
 }
 
-static void add_terms(const mxArray *terms, int axis /* -1: the stage cost */, int use_single) {
+static void add_terms(const mxArray *terms, int axis /* -1: the stage cost */, int use_single, int n_grid_dims) {
     const size_t nt = mxGetNumberOfElements(terms);
     size_t k;
     if (!mxIsStruct(terms)) fail("hjbdp:arg", "terms", "must be a struct array with fields dims, data");
@@ -102,8 +110,8 @@ static void add_terms(const mxArray *terms, int axis /* -1: the stage cost */, i
         int st;
         if (!dims || !data) fail("hjbdp:arg", "terms", "need fields dims and data");
         v = term_data(data, use_single, &count);
-        st = axis < 0 ? hjb_problem_add_cost_term(g_builder, dims_to_mask(dims), v, count)
-                      : hjb_problem_add_next_term(g_builder, axis, dims_to_mask(dims), v, count);
+        st = axis < 0 ? hjb_problem_add_cost_term(g_builder, dims_to_mask(dims, n_grid_dims), v, count)
+                      : hjb_problem_add_next_term(g_builder, axis, dims_to_mask(dims, n_grid_dims), v, count);
         mxFree(v);                                            /* the builder copied it */
         if (st) fail("hjbdp:problem", hjb_status_string(st), hjb_problem_last_error(g_builder));
     }
@@ -112,7 +120,7 @@ static void add_terms(const mxArray *terms, int axis /* -1: the stage cost */, i
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     const mxArray *prob, *opts, *knots, *mfield, *nterms, *terminal;
     int32_t n[HJB_MAX_D] = {0}, m[HJB_MAX_C] = {0}, devices[64];
-    int D, C, a, c, use_single, n_stages, keep_stages, monitor_period, n_dev = 1, st;
+    int D, C, a, c, use_single, n_stages, keep_stages, monitor_period, n_dev = 1, st, double_tables, monitor_single;
     double monitor_tol;
     size_t nS = 1, esz;
     mxClassID cls;
@@ -127,6 +135,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs < 2) mexErrMsgIdAndTxt("hjbdp:arg", "usage: out = hjbdp_mex(prob, n_stages [, opts])");
     prob = prhs[0];
     opts = nrhs > 2 ? prhs[2] : NULL;
+    if (mxGetNumberOfElements(prhs[1]) != 1 || !(mxGetScalar(prhs[1]) >= 1) || mxGetScalar(prhs[1]) > 2147483647.0)
+        mexErrMsgIdAndTxt("hjbdp:arg", "n_stages must be a scalar >= 1");       /* before it sizes any allocation */
     n_stages = (int)mxGetScalar(prhs[1]);
     knots = need_field(prob, "knots");
     mfield = need_field(prob, "m");
@@ -138,15 +148,19 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if ((int)mxGetNumberOfElements(nterms) != D) fail("hjbdp:arg", "prob", "next_terms needs one entry per state axis");
     use_single = mxIsLogicalScalarTrue(need_field(prob, "single")) ? 1 : 0;
     for (a = 0; a < D; ++a) { n[a] = (int32_t)mxGetNumberOfElements(mxGetCell(knots, a)); nS *= (size_t)n[a]; }
+    if (!mxIsDouble(mfield)) fail("hjbdp:arg", "prob.m", "must be a double vector");       /* mxGetPr is for double arrays only */
     for (c = 0; c < C; ++c) m[c] = (int32_t)mxGetPr(mfield)[c];
     keep_stages = opt_scalar(opts, "keep_stages", 0) != 0;
     monitor_period = (int)opt_scalar(opts, "monitor_period", 0);
     monitor_tol = opt_scalar(opts, "monitor_tol", 0);
+    double_tables = opt_scalar(opts, "double_tables", 0) != 0;
+    monitor_single = opt_scalar(opts, "monitor_single", 0) != 0;
+    if (double_tables && !use_single) fail("hjbdp:arg", "opts.double_tables", "is for prob.single = true");
     devices[0] = 0;
     if (opts && mxIsStruct(opts) && mxGetField(opts, 0, "devices")) {
         const mxArray *dv = mxGetField(opts, 0, "devices");
         n_dev = (int)mxGetNumberOfElements(dv);
-        if (n_dev < 1 || n_dev > 64) fail("hjbdp:arg", "opts.devices", "1..64 devices");
+        if (n_dev < 1 || n_dev > 64 || !mxIsDouble(dv)) fail("hjbdp:arg", "opts.devices", "1..64 devices (double)");
         for (a = 0; a < n_dev; ++a) devices[a] = (int32_t)mxGetPr(dv)[a];
     }
     if (n_dev > 1 && keep_stages) fail("hjbdp:arg", "opts", "keep_stages needs a single device");
@@ -154,14 +168,18 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     release_all();                                            /* leftovers of an interrupted call */
     st = hjb_problem_new(D, C, n, m, use_single ? HJB_F32 : HJB_F64, 1 /* MATLAB's 1-based argmin labels */, &g_builder);
     if (st) fail("hjbdp:problem", hjb_status_string(st), hjb_problem_last_error(NULL));
+    if (double_tables) {
+        st = hjb_problem_set_types(g_builder, HJB_IDX_I32, HJB_TAB_F64);
+        if (st) fail("hjbdp:problem", hjb_status_string(st), hjb_problem_last_error(g_builder));
+    }
     for (a = 0; a < D; ++a) {
         const mxArray *k = mxGetCell(knots, a);
         if (!mxIsDouble(k)) fail("hjbdp:arg", "knots", "must be double vectors");
         st = hjb_problem_set_knots(g_builder, a, mxGetPr(k), n[a]);
         if (st) fail("hjbdp:problem", hjb_status_string(st), hjb_problem_last_error(g_builder));
-        add_terms(mxGetCell(nterms, a), a, use_single);
+        add_terms(mxGetCell(nterms, a), a, use_single && !double_tables, D + C);
     }
-    add_terms(need_field(prob, "cost_terms"), -1, use_single);
+    add_terms(need_field(prob, "cost_terms"), -1, use_single, D + C);
 
     cls = use_single ? mxSINGLE_CLASS : mxDOUBLE_CLASS;
     esz = use_single ? sizeof(float) : sizeof(double);
@@ -183,12 +201,14 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (n_dev == 1) {
         st = hjb_create_from(g_builder, devices[0], &g_handle);
         if (st) fail("hjbdp:create", hjb_status_string(st), hjb_problem_last_error(g_builder));
+        if (monitor_single) (void)hjb_set_option(g_handle, "monitor_single", 1);
         st = hjb_solve_flat(g_handle, n_stages, monitor_period, monitor_tol, term, mxGetData(J), idx32,
                             Js ? mxGetData(Js) : NULL, idxs32, &done, &early, &ms);
         if (st) fail("hjbdp:solve", hjb_status_string(st), hjb_last_error(g_handle));
     } else {
         st = hjb_create_multi_from(g_builder, n_dev, devices, &g_multi);
         if (st) fail("hjbdp:create", hjb_status_string(st), hjb_problem_last_error(g_builder));
+        if (monitor_single) fail("hjbdp:arg", "opts.monitor_single", "needs a single device");
         st = hjb_solve_multi_flat(g_multi, n_stages, monitor_period, monitor_tol, term, mxGetData(J), idx32, &done, &early, &ms);
         if (st) fail("hjbdp:solve", hjb_status_string(st), hjb_multi_last_error(g_multi));
     }

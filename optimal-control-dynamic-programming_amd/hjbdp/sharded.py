@@ -103,7 +103,9 @@ class ShardedSweep:
                np.dtype(np.float64): torch.float64}[np.dtype(spec.j_dtype)]
         # haloed J layout [plane, inner] (row-major torch view of column-major [inner, plane])
         self.J = [torch.zeros((self.nplanes, self.inner), dtype=tdt, device=self.device) for _ in range(2)]
-        self.idx = torch.zeros((self.owned, self.inner), dtype=torch.int32, device=self.device)
+        # argmin labels in the width the problem asks for (hjb_problem.idx_dtype): int32, uint8 or uint16
+        idt = {4: torch.int32, 1: torch.uint8, 2: torch.uint16}[spec.idx_np_dtype.itemsize]
+        self.idx = torch.zeros((self.owned, self.inner), dtype=idt, device=self.device)
         self.cur = 0
         self.slab = (self.begin, self.end, self.halo_lo, self.halo_hi)
         self._handle = None
@@ -258,7 +260,7 @@ class ShardedSweep:
         """(sum J, sum idx) over the whole grid: the pos-att monitor's fsum50/idsum50."""
         t = self.torch
         J = self.J[self.cur][self.halo_lo:self.halo_lo + self.owned]
-        v = t.stack([J.double().sum(), self.idx.double().sum()])
+        v = t.stack([J.double().sum(), self.idx.to(t.int32).double().sum()])
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(v, group=self.group)

@@ -24,6 +24,10 @@ function out = hjbdp_solve(prob, n_stages, varargin)
 %   CAVEAT: relabelling changes the order in which the 1-D lerps are taken, so J agrees with the reference order only to
 %   a few ulp per stage and an argmin label can differ where two controls tie to rounding.  out.axis_order reports the
 %   labelling that ran (1-based: entry i = the caller's axis the library ran as its axis i).
+%   'double_tables' (default false; with prob.single): next_terms data go to the library as double and every query is
+%   formed, located and weighted in double, the weight rounded to single once - the typing of Solver_pos_att.m:299-327
+%   (double x_next .. w_next, single F_gI.Values); costs nothing per stage (hjbdp.h HJB_TAB_F64).
+%   'monitor_single' (default false): the monitor's sum(F.Values(:)) as a single-precision sum (Solver_pos_att.m:274).
 %   out: J (final values), idx (1-based argmin labels), and with keep_stages J_stages / idx_stages
 %        [nS x n_stages] with stage k_s in column k_s, stages_done, stopped_early, sweep_ms.
 %
@@ -35,6 +39,8 @@ function out = hjbdp_solve(prob, n_stages, varargin)
     addParameter(p, 'monitor_tol', 0);
     addParameter(p, 'devices', 0);
     addParameter(p, 'fast_axes', false);
+    addParameter(p, 'double_tables', false);
+    addParameter(p, 'monitor_single', false);
     parse(p, varargin{:});
     o = p.Results;
     L = 'libhjbdp';
@@ -49,12 +55,18 @@ function out = hjbdp_solve(prob, n_stages, varargin)
     check(calllib(L, 'hjb_problem_new', int32(D), int32(C), int32(n), int32(prob.m), int32(dt), int32(1), b), [], 'builder');
     bv = b.Value;
     freeb = onCleanup(@() calllib(L, 'hjb_problem_free', bv));
+    ncls = cls;                                   % class of the next-state operands as handed to the library
+    if o.double_tables
+        if ~prob.single, error('hjbdp:arg', 'double_tables is for prob.single = true'); end
+        check(calllib(L, 'hjb_problem_set_types', bv, int32(0), int32(1)), bv, 'builder');   % HJB_IDX_I32, HJB_TAB_F64
+        ncls = 'double';
+    end
     mask = @(dims) uint32(sum(bitshift(1, dims - 1)));
     for a = 1:D
         check(calllib(L, 'hjb_problem_set_knots', bv, int32(a - 1), double(prob.knots{a}(:)), int32(n(a))), bv, 'builder');
         T = prob.next_terms{a};
         for k = 1:numel(T)           % MATLAB's left-to-right order of the sum, e.g. A(1)*X1 + A(3)*X2 + B(1)*U (:186)
-            v = cast(T(k).data(:), cls);
+            v = cast(T(k).data(:), ncls);
             check(calllib(L, 'hjb_problem_add_next_term', bv, int32(a - 1), mask(T(k).dims), v, int64(numel(v))), bv, 'builder');
         end
     end
@@ -85,6 +97,7 @@ function out = hjbdp_solve(prob, n_stages, varargin)
         check(calllib(L, 'hjb_create_from', bv, int32(o.devices), h), bv, 'builder');
         hv = h.Value;
         freeh = onCleanup(@() calllib(L, 'hjb_destroy', hv));
+        if o.monitor_single, check(calllib(L, 'hjb_set_option', hv, 'monitor_single', int64(1)), hv, 'handle'); end
         Js = [];  Is = [];
         if o.keep_stages
             Js = libpointer(ptr, zeros(nS * n_stages, 1, cls));  Is = libpointer('int32Ptr', zeros(nS * n_stages, 1, 'int32'));

@@ -278,10 +278,14 @@ def test_rollout_kinematics_invariants():
     assert np.allclose(U_M, [0.0, 0.13 * pa.T_dist, 0.0])
 
 
+def pspec_n(spec, order):
+    return tuple(spec.n[a] for a in order)
+
+
 def test_suggest_axis_order_matches_the_mirrors(built):
     """hjbdp.suggest_axis_order (hjb_problem_suggest_order through the flat builder, no GPU): the labelling the library
-    proposes equals the one the mirrors apply by hand - Solver_pos_att.FAST_AXIS_ORDER up to the choice of the last axis
-    (the bench's (x, theta, w, v)), Solver_attitude.AXIS_ORDER - and nothing is proposed for Kirk's 2-D problem."""
+    proposes equals the one the mirrors apply by hand - Solver_pos_att.FAST_AXIS_ORDER (the bench's (x, theta, w, v)),
+    Solver_attitude.AXIS_ORDER - and nothing is proposed for Kirk's 2-D problem."""
     import numpy as np
     import hjbdp
     pa = hjbdp.Solver_pos_att()
@@ -290,7 +294,9 @@ def test_suggest_axis_order_matches_the_mirrors(built):
     spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1,
                                     pa.Qw1, pa.R1, pa.J2)
     order = hjbdp.suggest_axis_order(spec)
-    assert order == (0, 2, 3, 1) and set(order[:2]) == set(hjbdp.Solver_pos_att.FAST_AXIS_ORDER[:2])
+    assert order == (0, 2, 3, 1) == hjbdp.Solver_pos_att.FAST_AXIS_ORDER          # the constant IS the library's proposal
+    pa.axis_order = "auto"
+    assert pa._relabel(spec)[0].n == pspec_n(spec, order)
     pspec, _ = hjbdp.permute_state_axes(spec, order)
     assert hjbdp.suggest_axis_order(pspec) is None
     sa = hjbdp.Solver_attitude()

@@ -247,3 +247,101 @@ def test_pos_att_controller_artefact_roundtrip(tmp_path):
     assert pols[1](*x) == f[1][ids[i] - 1]
     with pytest.raises(ValueError):
         pa.set_controller(path, "q")
+
+
+def test_oracle_float64_query_mode_against_numpy(orc):
+    """hjb_problem.table_dtype = HJB_TAB_F64 in the C twin (Solver_pos_att.m:299-327: double query tables, single
+    Values) against an independent numpy evaluation of the same typing: queries summed in float64, located on the
+    float64 knots, weight (q - k[c]) / dx in float64 rounded to float32 once, float32 blend (axis 0 first), float32
+    cost, first minimum.  Non-uniform knots, 3-D and 4-D, two control dims; also: the mode is not a no-op."""
+    import hjbdp
+    _abi, orc, _ = orc
+    for seed, n, m in ((3, (9, 8, 7), (3, 4)), (4, (7, 6, 5, 6), (5,))):
+        s64 = random_problem(seed, n, m, dtype=np.float64, nonuniform=True)
+        spec = hjbdp.ProblemSpec(s64.knots, s64.m, s64.next_terms, s64.cost_terms, dtype=np.float32, table_dtype=np.float64)
+        term = random_terminal(spec, seed)
+        Jc, ic = orc.backup_stage(_abi, spec, term)
+        D, G = spec.D, spec.D + spec.C
+        full = spec.n + spec.m
+
+        def expand(t, dtype):
+            shape = [1] * G
+            for ax, d in enumerate(t.dims):
+                shape[d] = t.data.shape[ax]
+            return np.asarray(t.data, dtype=dtype).reshape(shape)
+        J = term.reshape(spec.n, order="F")
+        cells, ts = [], []
+        for a in range(D):
+            q = None
+            for t in spec.next_terms[a]:
+                e = expand(t, np.float64)
+                q = e if q is None else q + e
+            q = np.broadcast_to(q, full)
+            k = spec.knots[a]
+            c = np.clip(np.searchsorted(k, q, side="right") - 1, 0, len(k) - 2)
+            w = ((q - k[c]) * (1.0 / (k[c + 1] - k[c]))).astype(np.float32)
+            cells.append(c); ts.append(w)
+        vals = [J[tuple(cells[a] + ((corner >> a) & 1) for a in range(D))] for corner in range(1 << D)]
+        for a in range(D):
+            vals = [(vals[j] + (ts[a] * (vals[j + 1] - vals[j])).astype(np.float32)) for j in range(0, len(vals), 2)]
+        # the twin's lerp is fmaf(t, v1 - v0, v0): redo the last rounding exactly in float64 (products of two float32
+        # are exact in float64, so fma = round(t * d + v0) computed in float64 then rounded once)
+        vals = [J[tuple(cells[a] + ((corner >> a) & 1) for a in range(D))] for corner in range(1 << D)]
+        for a in range(D):
+            nxt = []
+            for j in range(0, len(vals), 2):
+                d = (vals[j + 1] - vals[j]).astype(np.float32)
+                nxt.append((ts[a].astype(np.float64) * d.astype(np.float64) + vals[j].astype(np.float64)).astype(np.float32))
+            vals = nxt
+        g = None
+        for t in spec.cost_terms:
+            e = expand(t, np.float32)
+            g = e if g is None else (g + e).astype(np.float32)
+        tot = (np.broadcast_to(g, full) + vals[0]).astype(np.float32)
+        tot = tot.reshape(spec.n + (spec.nU,), order="F") if spec.C == 1 else None
+        if tot is None:                                       # two control dims: control dim 0 slowest in the visit order
+            t2 = (np.broadcast_to(g, full) + vals[0]).astype(np.float32)
+            t2 = np.moveaxis(t2, (D, D + 1), (-2, -1)).reshape(spec.n + (spec.nU,))        # (i1 slow, i2 fast)
+            k = np.argmin(t2, axis=-1)
+            lab = (k // spec.m[1]) + spec.m[0] * (k % spec.m[1])                          # column-major label
+            Jn = np.take_along_axis(t2, k[..., None], axis=-1)[..., 0]
+        else:
+            k = np.argmin(tot, axis=-1)
+            lab = k
+            Jn = np.take_along_axis(tot, k[..., None], axis=-1)[..., 0]
+        assert np.array_equal(Jn.reshape(-1, order="F"), Jc)
+        assert np.array_equal(lab.reshape(-1, order="F").astype(np.int32), ic)
+        s32 = hjbdp.ProblemSpec(s64.knots, s64.m, s64.next_terms, s64.cost_terms, dtype=np.float32)
+        J32, _ = orc.backup_stage(_abi, s32, term)
+        assert not np.array_equal(J32, Jc) and np.allclose(J32, Jc, rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_single_precision_monitor_sum_is_the_stated_tree(orc):
+    """hjb_solve_opts.monitor_single: the oracle's float32 sum follows the order csrc/kernels_reduce.h states (131072
+    strided accumulators, pairwise halving per block of 256, 512 block sums folded the same way) - checked against a
+    numpy restatement of that order, and against the float64 sum to float32 accuracy."""
+    _abi, orc, _ = orc
+    spec = random_problem(1, (90, 80, 41), (3,), dtype=np.float32)         # 295200 states: more than one pass of the tree
+    out = orc.sweep(_abi, spec, 1, monitor_period=1, monitor_tol=0.0, monitor_single=True)
+    out64 = orc.sweep(_abi, spec, 1, monitor_period=1, monitor_tol=0.0)
+    J = out["J"]
+    NB, NT = 512, 256
+    pad = np.zeros(((J.size + NB * NT - 1) // (NB * NT)) * NB * NT, dtype=np.float32)
+    pad[:J.size] = J
+    acc = np.zeros(NB * NT, dtype=np.float32)
+    for row in pad.reshape(-1, NB * NT):
+        acc = (acc + row).astype(np.float32)               # adding 0.0f to a float32 is exact: padding changes nothing
+    v = acc.reshape(NB, NT).copy()
+    s = NT // 2
+    while s:
+        v[:, :s] = (v[:, :s] + v[:, s:2 * s]).astype(np.float32)
+        s //= 2
+    part = v[:, 0]
+    fin = (part[:NT] + part[NT:]).astype(np.float32)        # block sums t, t + 256 in that order (0 + a + b)
+    s = NT // 2
+    while s:
+        fin[:s] = (fin[:s] + fin[s:2 * s]).astype(np.float32)
+        s //= 2
+    assert out["last_e"] == float(fin[0])
+    assert out64["last_e"] == float(J.astype(np.float64).sum()) or abs(out64["last_e"] - J.astype(np.float64).sum()) < 1e-6
+    assert abs(out["last_e"] - out64["last_e"]) <= 1e-5 * abs(out64["last_e"])
