@@ -23,14 +23,20 @@ INST(float, 2, 5) INST(float, 3, 5) INST(_Float16, 2, 5) INST(float, 3, 4)
 """
 
 
-def test_column_sweep_kernels_fit_five_waves_without_spills(tmp_path):
-    src = tmp_path / "cs_budget.hip"
+@pytest.fixture(scope="module")
+def cs_asm(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cs_budget")
+    src = d / "cs_budget.hip"
     src.write_text(SRC % ROOT)
-    asm = tmp_path / "cs_budget.s"
+    asm = d / "cs_budget.s"
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
                         "-o", str(asm), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    text = asm.read_text()
+    return asm.read_text()
+
+
+def test_column_sweep_kernels_fit_five_waves_without_spills(cs_asm):
+    text = cs_asm
     kernels = re.findall(r"\.name:\s+(\S*k_backup_colsweep\S*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
     assert len(kernels) == 4, [k[0] for k in kernels]
     for name, vgprs, spills in kernels:
@@ -39,3 +45,108 @@ def test_column_sweep_kernels_fit_five_waves_without_spills(tmp_path):
     # scalar registers may overflow into lanes of a vector register (v_writelane / v_readlane: no memory involved) - a few
     assert all(int(x) <= 8 for x in re.findall(r"\.sgpr_spill_count:\s+(\d+)", text))
     assert "scratch_" not in text
+
+
+def _kernel_bodies(text):
+    """{mangled name: [lines]} of every column-sweep kernel in the assembly."""
+    out, cur = {}, None
+    for ln in text.splitlines():
+        m = re.match(r"^(_ZN3hjb17k_backup_colsweep\S*):", ln)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        if cur is not None:
+            if ln.startswith("\t.end_amdhsa_kernel") or ln.startswith(".Lfunc_end"):
+                cur = None
+            else:
+                cur.append(ln)
+    return out
+
+
+def _mentions(line, reg):
+    """Does the instruction on `line` name VGPR number `reg` (alone or inside a v[a:b] range)?"""
+    code = line.split(";")[0]
+    if re.search(r"\bv%d\b" % reg, code):
+        return True
+    return any(int(a) <= reg <= int(b) for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code))
+
+
+def test_gathers_in_flight_are_never_touched(cs_asm):
+    """The structure K10's hand-issued gathers rely on, read off the code object (kernels_colsweep.h: gather_async /
+    wait_gathers_n).  The corner-row gathers of the column loop are inline asm the compiler does not track: between a
+    gather and the counted wait that retires it the destination register holds nothing yet, and the compiler - which
+    believes it is already written - must not read, copy or reuse it.  The schedule: gathers are issued in batches
+    separated by the hand-written waits (H1 of this step | wait | H0 of the next step | wait | ...), and a wait retires
+    the batch issued BEFORE the previous wait; the full drain behind the stores of a write-out retires everything.  So:
+    walking the loop body from a gather (cyclically - a batch crosses the back-edge), no instruction may name its
+    destination before the second hand-written wait (or a full drain).  Also pinned: gathers per step of the headline
+    shape (5 groups x 3 window knots x 2 rows, one load each)."""
+    bodies = _kernel_bodies(cs_asm)
+    assert len(bodies) == 4, list(bodies)
+    for name, lines in bodies.items():
+        _check_gathers(name, lines)
+    # the checker itself: a copy of a gather's destination planted right behind the gather must be caught
+    name, lines = next(iter(bodies.items()))
+    at = next(i for i, ln in enumerate(lines) if i > next(j for j, l in enumerate(lines) if "s_barrier" in l)
+              and re.search(r"global_load_dword\s+v\d+,", ln) and ";;#ASMSTART" in lines[i - 1])
+    reg = re.search(r"global_load_dword\s+v(\d+),", lines[at]).group(1)
+    end = next(i for i in range(at, len(lines)) if ";;#ASMEND" in lines[i])
+    planted = lines[:end + 1] + ["\tv_mov_b32_e32 v200, v%s" % reg] + lines[end + 1:]
+    with pytest.raises(AssertionError, match="in flight"):
+        _check_gathers(name, planted)
+
+
+def _check_gathers(name, lines):
+    if True:
+        # the column loop = the depth-1 loop that holds the s_barrier: its header block, then every block the assembler
+        # annotates as inside it, in file order, the blocks laid out before the header (the latch) last
+        bar = next(i for i, ln in enumerate(lines) if "s_barrier" in ln)
+        hdr = max(i for i in range(bar) if re.match(r"^\.LBB\d+_\d+:.*Loop Header: Depth=1", lines[i]))
+        tag = "BB" + lines[hdr].split(":")[0][len(".LBB"):]
+        member, inside = [], False
+        for i, ln in enumerate(lines):
+            if re.match(r"^\.LBB\d+_\d+:", ln) or re.match(r"^; %bb\.\d+:", ln):
+                inside = i == hdr or ("Header=%s " % tag) in ln + " " or ("Parent Loop %s " % tag) in ln + " "
+            member.append(inside)
+        after = [lines[i] for i in range(hdr, len(lines)) if member[i]]
+        before = [lines[i] for i in range(hdr) if member[i]]
+        body = after + before
+        assert any("s_barrier" in ln for ln in body) and len(body) > 500
+        in_asm, tagged = False, []
+        for ln in body:
+            if ";;#ASMSTART" in ln:
+                in_asm = True
+                continue
+            if ";;#ASMEND" in ln:
+                in_asm = False
+                continue
+            tagged.append((in_asm, ln))
+        gathers = [(i, int(re.search(r"global_load_(?:dword|ushort)\s+v(\d+),", ln).group(1)))
+                   for i, (a, ln) in enumerate(tagged) if a and re.search(r"global_load_(?:dword|ushort)\s+v\d+,", ln)]
+        n_groups = 5 if "Li5E" in name else 4
+        assert len(gathers) == n_groups * 3 * 2, (name, len(gathers))      # rows of one step, each gathered by ONE load
+        n = len(tagged)
+
+        def is_wait(i):
+            a, ln = tagged[i]
+            if a and "s_setpc_b64" in ln:                 # the computed jump into the table of counted waits: one wait
+                return True
+            return (not a) and re.search(r"s_waitcnt\s+vmcnt\(0\)", ln) is not None and False
+        drains = {i for i, (a, ln) in enumerate(tagged) if not a and re.search(r"s_waitcnt\s+vmcnt\(0\)\s*$", ln.split(";")[0].rstrip())}
+        for pos, reg in gathers:
+            waits = 0
+            for k in range(1, n + 1):
+                i = (pos + k) % n
+                if i in drains:
+                    break                                   # a full drain: everything has landed
+                if is_wait(i):
+                    waits += 1
+                    if waits == 2:
+                        break
+                    continue
+                a, ln = tagged[i]
+                if a and re.search(r"s_waitcnt\s+vmcnt", ln):
+                    continue                                # an entry of the wait table
+                assert not _mentions(ln, reg), "%s: v%d is named while its gather is in flight: %s" % (name, reg, ln.strip())
+            else:
+                raise AssertionError("%s: no retiring wait found after the gather into v%d" % (name, reg))
