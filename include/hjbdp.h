@@ -362,6 +362,29 @@ int32_t hjb_multi_set_option(hjb_multi m, const char *key, int64_t value);   /* 
 int32_t hjb_destroy_multi(hjb_multi m);
 const char *hjb_multi_last_error(hjb_multi m);
 
+/* ---- one process per GPU: a rank's share of the sweep ----------------------------------------------------------------
+ * For hosts that run one process per GPU and move the halo planes themselves (MPI; RCCL through torch.distributed:
+ * hjbdp/sharded.py, bench.py --gpus N).  hjb_rank_create partitions the LAST state axis over `world` ranks exactly as
+ * hjb_create_multi does over devices and builds this rank's handles: the slab, and - with `overlap` and an interior -
+ * the interior and the two boundary strips over the same buffers.  The caller owns two J buffers of
+ * (end - begin + halo_lo + halo_hi) planes and a label buffer of (end - begin) planes on `device`, and per stage
+ *   1. makes its transfer stream wait for the compute stream, enqueues the halo exchange of dJ_in on it
+ *      (send my boundary planes, receive into planes [0, halo_lo) and [halo_lo + owned, ...)),
+ *   2. calls hjb_rank_stage(r, dJ_in, dJ_out, d_idx, compute_stream, halo_stream): ONE call enqueues the interior on
+ *      compute_stream, the strips on the library's own streams behind an event recorded on halo_stream at this point,
+ *      and joins them into compute_stream (halo_stream NULL: nothing to wait for).
+ * hjb_rank_info: out10 = begin, end, halo_lo, halo_hi, split (1: interior + strips), kernel variant, halo_needed_lo,
+ * halo_needed_hi, bytes per label, planes of the last axis. */
+typedef struct hjb_rank_s *hjb_rank;
+int32_t hjb_rank_create(const hjb_problem *problem, int32_t device, int32_t rank, int32_t world, int32_t overlap, hjb_rank *out);
+int32_t hjb_rank_info(hjb_rank r, int32_t *out10);
+int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream);
+int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value);
+int32_t hjb_rank_get_option(hjb_rank r, const char *key, int64_t *value);
+int32_t hjb_rank_check_status(hjb_rank r, void *stream);
+int32_t hjb_rank_destroy(hjb_rank r);
+const char *hjb_rank_last_error(hjb_rank r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2927,6 +2927,213 @@ int32_t hjb_solve_multi_flat(hjb_multi m, int32_t n_stages, int32_t monitor_peri
     return st;
 }
 
+// ---- one process per GPU: a rank's slab as interior + boundary strips ------------------------------------------------
+// What hjb_solve_multi does per slab and stage, for a host that runs ONE PROCESS PER GPU and moves the halo planes itself
+// (MPI, RCCL through torch.distributed: hjbdp/sharded.py, bench.py --gpus N).  The library partitions the last state axis
+// exactly as hjb_create_multi does, creates this rank's slab handle and - when the slab has an interior - the interior
+// and strip handles over the same buffers, and enqueues a whole stage (fork, interior, strips behind the halos, join) in
+// ONE call: the per-stage host work of a rank is the exchange plus this call.
+struct hjb_rank_s {
+    int device = 0, rank = 0, world = 1, begin = 0, end = 0, hlo = 0, hhi = 0, need_lo = 0, need_hi = 0, nl = 0;
+    Handle *whole = nullptr;
+    Handle *part[3] = {nullptr, nullptr, nullptr};     // interior, low strip, high strip (null: no split)
+    int64_t part_row0[3] = {0, 0, 0}, part_own0[3] = {0, 0, 0};
+    hipStream_t ss[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, halo = nullptr, sdone[2] = {nullptr, nullptr};
+    int64_t inner = 0;
+    size_t esz = 4, isz = 4;
+    std::string err;
+};
+
+static int rfail(hjb_rank r, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (r) r->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+const char *hjb_rank_last_error(hjb_rank r) { return r ? r->err.c_str() : g_last_error.c_str(); }
+
+int32_t hjb_rank_destroy(hjb_rank r) {
+    if (!r) return HJB_OK;
+    (void)hipSetDevice(r->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) {
+        if (r->sdone[i]) (void)hipEventDestroy(r->sdone[i]);
+        if (r->ss[i]) (void)hipStreamDestroy(r->ss[i]);
+    }
+    if (r->fork) (void)hipEventDestroy(r->fork);
+    if (r->halo) (void)hipEventDestroy(r->halo);
+    for (int i = 0; i < 3; ++i) if (r->part[i]) (void)hjb_destroy((hjb_handle)r->part[i]);
+    if (r->whole) (void)hjb_destroy((hjb_handle)r->whole);
+    delete r;
+    return HJB_OK;
+}
+
+int32_t hjb_rank_create(const hjb_problem *p, int32_t device, int32_t rank, int32_t world, int32_t overlap, hjb_rank *out) {
+    if (!p || !out) return rfail(nullptr, HJB_E_INVALID, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return rfail(nullptr, HJB_E_INVALID, "rank %d of %d", rank, world);
+    if (p->slab_begin || p->slab_end || p->halo_lo || p->halo_hi) return rfail(nullptr, HJB_E_INVALID, "hjb_rank_create partitions the grid itself: pass the whole problem");
+    if (p->D < 1 || p->D > HJB_MAX_D) return rfail(nullptr, HJB_E_UNSUPPORTED, "D=%d", p->D);
+    const int nl = p->n[p->D - 1];
+    if (world > nl) return rfail(nullptr, HJB_E_INVALID, "more ranks (%d) than planes of the last axis (%d)", world, nl);
+    hjb_handle probe = nullptr;                  // the halo the tables imply: host arithmetic on the last axis' terms
+    int st = hjb_create(p, device, &probe);
+    if (st) return st;
+    hjb_info pin{};
+    (void)hjb_get_info(probe, &pin);
+    (void)hjb_destroy(probe);
+    hjb_rank r = new hjb_rank_s();
+    r->device = device; r->rank = rank; r->world = world; r->nl = nl;
+    r->need_lo = pin.halo_needed_lo; r->need_hi = pin.halo_needed_hi;
+    r->esz = p->dtype == HJB_F16S ? 2 : (p->dtype == HJB_F32 ? 4 : 8);
+    r->isz = (size_t)pin.idx_bytes;
+    r->inner = pin.n_states / nl;
+    const int base = nl / world, rem = nl % world;
+    auto range = [&](int k, int *b, int *e) { *b = k * base + std::min(k, rem); *e = *b + base + (k < rem ? 1 : 0); };
+    range(rank, &r->begin, &r->end);
+    r->hlo = std::min(r->need_lo, r->begin);
+    r->hhi = std::min(r->need_hi, nl - r->end);
+    for (int k = 0; k < world; ++k) {            // a halo must come from the immediate neighbour only
+        int b, e;
+        range(k, &b, &e);
+        int pb = 0, pe = 0, nb = 0, ne = 0;
+        if (k > 0) range(k - 1, &pb, &pe);
+        if (k + 1 < world) range(k + 1, &nb, &ne);
+        if ((k > 0 && std::min(r->need_lo, b) > pe - pb) || (k + 1 < world && std::min(r->need_hi, nl - e) > ne - nb)) {
+            (void)hjb_rank_destroy(r);
+            return rfail(nullptr, HJB_E_INVALID, "halo (%d/%d planes) wider than a neighbouring slab: use fewer ranks or relabel the "
+                         "state axes so that the last axis moves less", pin.halo_needed_lo, pin.halo_needed_hi);
+        }
+    }
+    auto make = [&](int sb, int se, int hl, int hh, Handle **hout) {
+        hjb_problem q = *p;
+        if (world > 1) { q.slab_begin = sb; q.slab_end = se; q.halo_lo = hl; q.halo_hi = hh; }
+        hjb_handle h = nullptr;
+        const int s2 = hjb_create(&q, device, &h);
+        *hout = (Handle *)h;
+        return s2;
+    };
+    st = make(r->begin, r->end, r->hlo, r->hhi, &r->whole);
+    const int lo_w = r->hlo ? r->need_lo : 0, hi_w = r->hhi ? r->need_hi : 0, owned = r->end - r->begin;
+    if (!st && overlap && world > 1 && owned - lo_w - hi_w >= 1 && (lo_w || hi_w)) {
+        const int view0 = r->begin - r->hlo;
+        auto sub = [&](int k, int sb, int se, int hl, int hh) {
+            r->part_row0[k] = (sb - hl) - view0;
+            r->part_own0[k] = sb - r->begin;
+            return make(sb, se, hl, hh, &r->part[k]);
+        };
+        st = sub(0, r->begin + lo_w, r->end - hi_w, std::min(r->need_lo, lo_w), std::min(r->need_hi, hi_w));
+        if (!st && lo_w) st = sub(1, r->begin, r->begin + lo_w, r->hlo, std::min(r->need_hi, r->end - (r->begin + lo_w)));
+        if (!st && hi_w) st = sub(2, r->end - hi_w, r->end, std::min(r->need_lo, (r->end - hi_w) - r->begin), r->hhi);
+    }
+    if (!st) {
+        bool ok = hipSetDevice(device) == hipSuccess && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&r->halo, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = hipEventCreateWithFlags(&r->sdone[k], hipEventDisableTiming) == hipSuccess &&
+                 hipStreamCreateWithFlags(&r->ss[k], hipStreamNonBlocking) == hipSuccess;
+        if (!ok) st = rfail(nullptr, HJB_E_DEVICE, "stream / event creation failed on device %d", device);
+    }
+    if (st) {
+        const std::string keep = g_last_error;
+        (void)hjb_rank_destroy(r);
+        g_last_error = keep;
+        return st;
+    }
+    *out = r;
+    return HJB_OK;
+}
+
+int32_t hjb_rank_info(hjb_rank r, int32_t *out10) {
+    if (!r || !out10) return rfail(r, HJB_E_INVALID, "null argument");
+    out10[0] = r->begin; out10[1] = r->end; out10[2] = r->hlo; out10[3] = r->hhi;
+    out10[4] = r->part[0] ? 1 : 0;
+    out10[5] = (r->part[0] ? r->part[0] : r->whole)->variant;
+    out10[6] = r->need_lo; out10[7] = r->need_hi;
+    out10[8] = (int32_t)r->isz; out10[9] = r->nl;
+    return HJB_OK;
+}
+
+int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value) {
+    if (!r || !key) return rfail(r, HJB_E_INVALID, "null argument");
+    Handle *hs[4] = {r->whole, r->part[0], r->part[1], r->part[2]};
+    for (Handle *h : hs)
+        if (h) {
+            const int st = hjb_set_option((hjb_handle)h, key, value);
+            if (st) return rfail(r, st, "%s", hjb_last_error((hjb_handle)h));
+        }
+    return HJB_OK;
+}
+
+int32_t hjb_rank_get_option(hjb_rank r, const char *key, int64_t *value) {
+    if (!r) return rfail(r, HJB_E_INVALID, "null argument");
+    return hjb_get_option((hjb_handle)(r->part[0] ? r->part[0] : r->whole), key, value);
+}
+
+int32_t hjb_rank_check_status(hjb_rank r, void *stream) {
+    if (!r) return rfail(r, HJB_E_INVALID, "null argument");
+    if (hipSetDevice(r->device) != hipSuccess) return rfail(r, HJB_E_DEVICE, "hipSetDevice failed");
+    Handle *hs[4] = {r->whole, r->part[0], r->part[1], r->part[2]};
+    for (Handle *h : hs)
+        if (h) {
+            const int st = check_status(h, (hipStream_t)stream);
+            if (st) return rfail(r, st, "%s", h->err.c_str());
+        }
+    return HJB_OK;
+}
+
+int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream) {
+    if (!r || !dJ_in || !dJ_out) return rfail(r, HJB_E_INVALID, "null argument");
+    hipStream_t cs = (hipStream_t)compute_stream, hs = (hipStream_t)halo_stream;
+    const size_t plane_b = (size_t)r->inner * r->esz;
+#define RANK_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return rfail(r, HJB_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+    RANK_TRY(hipSetDevice(r->device));
+    auto stage_part = [&](int k, hipStream_t stream) -> int {
+        Handle *h = k < 0 ? r->whole : r->part[k];
+        const int64_t row0 = k < 0 ? 0 : r->part_row0[k], own0 = k < 0 ? 0 : r->part_own0[k];
+        const int st = launch_stage(h, (const char *)dJ_in + plane_b * row0, (char *)dJ_out + plane_b * row0,
+                                    d_idx ? (char *)d_idx + (size_t)(r->inner * own0) * r->isz : nullptr, stream);
+        if (st) r->err = h->err;
+        return st;
+    };
+    const bool halos = hs != nullptr && (r->hlo || r->hhi);
+    if (!r->part[0]) {                       // no interior to overlap with: the halos first, then one kernel
+        if (halos) {
+            RANK_TRY(hipEventRecord(r->halo, hs));
+            RANK_TRY(hipStreamWaitEvent(cs, r->halo, 0));
+        }
+        return stage_part(-1, cs);
+    }
+    // the strips run on streams of their own, beside the interior (see hjb_solve_multi): a strip stream waits for what the
+    // compute stream holds so far (J_in complete) and for the halos; the compute stream joins them at the end
+    RANK_TRY(hipEventRecord(r->fork, cs));
+    for (int k = 1; k <= 2; ++k)
+        if (r->part[k]) RANK_TRY(hipStreamWaitEvent(r->ss[k - 1], r->fork, 0));
+    int st = stage_part(0, cs);
+    if (st) return st;
+    if (halos) RANK_TRY(hipEventRecord(r->halo, hs));
+    for (int k = 1; k <= 2; ++k)
+        if (r->part[k]) {
+            if (halos) RANK_TRY(hipStreamWaitEvent(r->ss[k - 1], r->halo, 0));
+            st = stage_part(k, r->ss[k - 1]);
+            if (st) return st;
+            RANK_TRY(hipEventRecord(r->sdone[k - 1], r->ss[k - 1]));
+            RANK_TRY(hipStreamWaitEvent(cs, r->sdone[k - 1], 0));
+        }
+    return HJB_OK;
+#undef RANK_TRY
+}
+
 // ---- device-buffer helpers -------------------------------------------------------------------------------------------
 // hjb_backup_stage_device runs on buffers the caller owns.  A host without a HIP binding of its own (MATLAB, plain C)
 // gets them here: allocation, copies, free memory, a separable fill and a gather - enough to drive grids that never

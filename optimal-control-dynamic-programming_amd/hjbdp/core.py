@@ -400,6 +400,67 @@ class MultiBackup:
                 "sweep_ms": res.sweep_ms, "last_e": res.last_e, "last_e2": res.last_e2}
 
 
+class RankSlab:
+    """One rank's share of a sweep partitioned over `world` processes, one per GPU (hjb_rank_create / hjb_rank_stage):
+    the library builds the slab handle and - with overlap and an interior - the interior and strip handles, and enqueues
+    a whole stage (interior on the compute stream, strips behind the halos on streams of their own) in one call."""
+
+    def __init__(self, spec: ProblemSpec, device, rank, world, overlap=True):
+        self.lib = load_library()
+        self.spec = spec
+        self._cprob, self._keep = spec.to_c()
+        self._r = C.c_void_p()
+        st = self.lib.hjb_rank_create(C.byref(self._cprob), int(device), int(rank), int(world), 1 if overlap else 0, C.byref(self._r))
+        if st != _abi.HJB_OK:
+            self._r = C.c_void_p()
+            msg = self.lib.hjb_rank_last_error(None)
+            raise HjbError(st, (msg or b"").decode() or self.lib.hjb_status_string(st).decode())
+        self.refresh()
+
+    def refresh(self):
+        """Re-read what the library reports for this rank (the kernel variant changes with set_option)."""
+        v = (C.c_int32 * 10)()
+        self._check(self.lib.hjb_rank_info(self._r, v))
+        (self.begin, self.end, self.halo_lo, self.halo_hi, self.split, self.kernel_variant, self.need_lo, self.need_hi,
+         self.idx_bytes, self.n_planes) = (int(x) for x in v)
+
+    def _check(self, st):
+        if st != _abi.HJB_OK:
+            msg = self.lib.hjb_rank_last_error(self._r)
+            raise HjbError(st, (msg or b"").decode() or self.lib.hjb_status_string(st).decode())
+
+    def stage(self, dJ_in, dJ_out, d_idx, compute_stream=0, halo_stream=0):
+        def ptr(x):
+            if x is None:
+                return None
+            return int(x.data_ptr()) if hasattr(x, "data_ptr") else int(x)
+        self._check(self.lib.hjb_rank_stage(self._r, ptr(dJ_in), ptr(dJ_out), ptr(d_idx), int(compute_stream) or None,
+                                            int(halo_stream) or None))
+
+    def set_option(self, key, value):
+        self._check(self.lib.hjb_rank_set_option(self._r, key.encode(), int(value)))
+        self.refresh()
+
+    def get_option(self, key):
+        v = C.c_int64()
+        self._check(self.lib.hjb_rank_get_option(self._r, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    def check_device_status(self, stream=0):
+        self._check(self.lib.hjb_rank_check_status(self._r, int(stream) or None))
+
+    def close(self):
+        if getattr(self, "_r", None) and self._r.value:
+            self.lib.hjb_rank_destroy(self._r)
+            self._r = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def suggest_axis_order(spec):
     """The labelling of the state axes under which the library runs its fastest stage kernel on `spec`
     (hjb_problem_suggest_order, the call a MATLAB host makes through matlab/hjbdp_solve.m): a tuple for

@@ -14,6 +14,9 @@ the spacecraft models lies within a few cells of x, so each rank needs only
 Interior and strips are three libhjbdp slab handles over the SAME J buffers (a slab
 handle sees the planes [begin - halo_lo, end + halo_hi) of the last axis; sub-slabs of
 a rank's slab are pointer offsets into its buffers), so the split costs no copies.
+They live inside the library (hjb_rank_create), and a whole stage - fork, interior,
+strips behind the halos on streams of their own, join - is ONE call (hjb_rank_stage):
+per stage this module issues the exchange and that call, nothing else.
 overlap=False (and every CPU test) exchanges first and runs one kernel on all owned planes.
 
 The reference has no distributed code at all; this is new design
@@ -108,32 +111,17 @@ class ShardedSweep:
         self.idx = torch.zeros((self.owned, self.inner), dtype=idt, device=self.device)
         self.cur = 0
         self.slab = (self.begin, self.end, self.halo_lo, self.halo_hi)
-        self._handle = None
-        self._parts = None            # overlap: [(handle, first plane of its J view, first owned plane rel. to begin, planes)]
+        self._rank = None             # the HIP path: the library's view of this rank (hjb_rank_create)
         if stage_fn is None:
-            from .core import Backup  # raises loudly without the library / a GPU
+            from .core import RankSlab    # raises loudly without the library / a GPU
             dev_index = self.device.index if self.device.index is not None else 0
-            self._handle = Backup(spec, device=dev_index, slab=self.slab if world > 1 else None)
+            self._rank = RankSlab(spec, dev_index, self.rank, world, overlap=overlap)
+            rk = self._rank
+            if (rk.begin, rk.end, rk.halo_lo, rk.halo_hi) != self.slab:
+                raise RuntimeError("library partition %r differs from the host's %r" % ((rk.begin, rk.end, rk.halo_lo, rk.halo_hi), self.slab))
             stage_fn = self._hip_stage
-            # interior / boundary split: only when both strips and a non-empty interior exist
-            lo_w = need_lo if self.halo_lo else 0          # owned planes whose queries reach below `begin`
-            hi_w = need_hi if self.halo_hi else 0
-            if overlap and world > 1 and self.owned - lo_w - hi_w >= 1 and (lo_w or hi_w):
-                b, e = self.begin, self.end
-                view0 = b - self.halo_lo                   # global plane of row 0 of self.J[*]
-                self._parts = []
-
-                def sub(sb, se, hl, hh):
-                    h = Backup(spec, device=dev_index, slab=(sb, se, hl, hh))
-                    self._parts.append((h, (sb - hl) - view0, sb - b, se - sb, hl, hh))
-                sub(b + lo_w, e - hi_w, min(need_lo, lo_w), min(need_hi, hi_w))          # interior: reads owned planes only
-                if lo_w:
-                    sub(b, b + lo_w, self.halo_lo, min(need_hi, e - (b + lo_w)))
-                if hi_w:
-                    sub(e - hi_w, e, min(need_lo, (e - hi_w) - b), self.halo_hi)
+            if rk.split:
                 self._comm_stream = torch.cuda.Stream(device=self.device)
-                self._strip_streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
-                self._halo_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self.stage_fn = stage_fn
         self._halo_ops = {}
         # what my neighbours need from me
@@ -142,28 +130,19 @@ class ShardedSweep:
 
     def _hip_stage(self, J_in, J_out, idx):
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        self._handle.backup_stage_device(J_in, J_out, idx, stream=stream)
-
-    def _hip_part(self, i, J_in, J_out, idx):
-        h, row0, own0, planes, hl, hh = self._parts[i]
-        stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        n = planes + hl + hh
-        h.backup_stage_device(J_in[row0:row0 + n], J_out[row0:row0 + n], idx[own0:own0 + planes], stream=stream)
+        self._rank.stage(J_in, J_out, idx, compute_stream=stream)
 
     # -- the handle(s) behind this rank ------------------------------------------------------------------
     def info(self):
-        return self._handle.info()
+        rk = self._rank
+        return {"kernel_variant": rk.kernel_variant, "halo_needed_lo": rk.need_lo, "halo_needed_hi": rk.need_hi,
+                "idx_bytes": rk.idx_bytes, "split": rk.split}
 
     def set_option(self, key, value):
-        self._handle.set_option(key, value)
-        for p in self._parts or ():
-            p[0].set_option(key, value)
+        self._rank.set_option(key, value)
 
     def check_device_status(self):
-        stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        self._handle.check_device_status(stream)
-        for p in self._parts or ():
-            p[0].check_device_status(stream)
+        self._rank.check_device_status(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_terminal(self, J_global=None):
         """J_N: None = zeros (Dynamic_Solver.m:83-84); else global [nS] column-major."""
@@ -228,7 +207,7 @@ class ShardedSweep:
         """One backup of the owned planes.  Without overlap: halo exchange, then the fused kernel.  With
         overlap: start the exchange, run the interior planes, wait for the halos, run the boundary strips."""
         J_in, J_out = self.J[self.cur], self.J[1 - self.cur]
-        if self._parts is None:
+        if self._rank is None or not self._rank.split:
             self.exchange_halos()
             self.stage_fn(J_in, J_out, self.idx)
         else:
@@ -236,24 +215,11 @@ class ShardedSweep:
             main = t.cuda.current_stream(self.device)
             self._comm_stream.wait_stream(main)            # the previous stage's output is the data to send
             with t.cuda.stream(self._comm_stream):
-                works = self.exchange_halos(wait=False)
-                for w in works:
-                    w.wait()                               # the copy stream waits for the transfers ...
-                halo_ev = self._halo_ev[self.cur]
-                halo_ev.record(self._comm_stream)          # ... and one event tells the strip streams
-            # the boundary strips run on streams of their own, beside the interior: a strip is a few hundred waves, but
-            # every launch of the column-sweep kernel lasts at least one column (~0.2 ms) - in line behind the interior
-            # two strips would cost more than the exchange they hide
-            strips = list(zip(range(1, len(self._parts)), self._strip_streams))
-            for _, s in strips:
-                s.wait_stream(main)                        # J_in complete (recorded BEFORE the interior is enqueued)
-            self._hip_part(0, J_in, J_out, self.idx)       # interior: independent of the halos
-            for i, s in strips:
-                with t.cuda.stream(s):
-                    s.wait_event(halo_ev)                  # the halos have landed
-                    self._hip_part(i, J_in, J_out, self.idx)
-            for _, s in strips:
-                main.wait_stream(s)
+                for w in self.exchange_halos(wait=False):
+                    w.wait()                               # the transfer stream waits for the transfers
+            # interior on the compute stream now, the strips behind an event the library records on the transfer stream
+            # at this point (= the halos have landed), on streams of their own; joined into the compute stream
+            self._rank.stage(J_in, J_out, self.idx, compute_stream=main.cuda_stream, halo_stream=self._comm_stream.cuda_stream)
         self.cur = 1 - self.cur
 
     def monitor_sums(self):
@@ -277,7 +243,7 @@ class ShardedSweep:
                 e, fprev = fsum - fprev, fsum
                 if abs(e) < monitor_tol:
                     break
-        if self._handle is not None:
+        if self._rank is not None:
             self.check_device_status()
         return done
 
@@ -302,9 +268,6 @@ class ShardedSweep:
         return np.concatenate(outJ), np.concatenate(outI)
 
     def close(self):
-        for p in self._parts or ():
-            p[0].close()
-        self._parts = None
-        if self._handle is not None:
-            self._handle.close()
-            self._handle = None
+        if self._rank is not None:
+            self._rank.close()
+            self._rank = None

@@ -233,3 +233,61 @@ def test_solve_multi_refuses_what_it_cannot_do(env):
         hjbdp.MultiBackup(spec, [0] * 8)                      # halo wider than a 2-plane slab
     with pytest.raises(hjbdp.HjbError):
         hjbdp.MultiBackup(spec, [0] * 17)                     # more slabs than planes
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rank_api_three_ranks_in_one_process(env, overlap):
+    """hjb_rank_create / hjb_rank_stage (one process per GPU; here three ranks driven from one process, all on this box's
+    GPU): library-owned buffers, the halo planes moved by the caller with device-to-device copies between the ranks'
+    buffers before each stage - the role MPI / RCCL play in a real run - and every stage one hjb_rank_stage call per rank
+    (interior + strips with overlap).  All planes of every stage equal the oracle's whole-grid sweep."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, random_terminal
+    spec0 = colsweep_problem(15, (36, 7, 9, 14), gax=2)
+    spec = hjbdp.ProblemSpec(spec0.knots, spec0.m, spec0.next_terms, spec0.cost_terms, dtype=np.float32, index_base=1, idx_dtype="auto")
+    term = random_terminal(spec, 8)
+    stages, world = 4, 3
+    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, keep_J=True, keep_idx=True)
+    inner = spec.nS // spec.n[-1]
+    ranks = [hjbdp.RankSlab(spec, 0, r, world, overlap=overlap) for r in range(world)]
+    assert ranks[0].begin == 0 and ranks[-1].end == spec.n[-1] and all(a.end == b.begin for a, b in zip(ranks, ranks[1:]))
+    assert any(r.split for r in ranks) == overlap
+    lib = ranks[0].lib
+    T = term.reshape(inner, -1, order="F")
+    bufs = []
+    for r in ranks:
+        planes = r.end - r.begin + r.halo_lo + r.halo_hi
+        J = [hjbdp.DeviceBuffer(inner * planes * 4), hjbdp.DeviceBuffer(inner * planes * 4)]
+        init = np.zeros((inner, planes), dtype=np.float32, order="F")
+        init[:, r.halo_lo:r.halo_lo + r.end - r.begin] = T[:, r.begin:r.end]
+        J[0].upload(init.reshape(-1, order="F"))
+        bufs.append((J, hjbdp.DeviceBuffer(inner * (r.end - r.begin) * r.idx_bytes)))
+    pb = inner * 4
+
+    def d2d(dst, dst_plane, src, src_plane, n):
+        st = lib.hjb_device_copy(0, dst.ptr + pb * dst_plane, src.ptr + pb * src_plane, pb * n, _abi.HJB_COPY_D2D)
+        assert st == 0
+    cur = 0
+    for k_s in range(stages, 0, -1):
+        for i, r in enumerate(ranks):                     # the exchange: my halo planes from my neighbours' owned planes
+            if r.halo_lo:
+                lo = ranks[i - 1]
+                d2d(bufs[i][0][cur], 0, bufs[i - 1][0][cur], lo.halo_lo + (lo.end - lo.begin) - r.halo_lo, r.halo_lo)
+            if r.halo_hi:
+                hi = ranks[i + 1]
+                d2d(bufs[i][0][cur], r.halo_lo + r.end - r.begin, bufs[i + 1][0][cur], hi.halo_lo, r.halo_hi)
+        for i, r in enumerate(ranks):
+            r.stage(bufs[i][0][cur], bufs[i][0][cur ^ 1], bufs[i][1])
+        for i, r in enumerate(ranks):
+            r.check_device_status()
+            planes = r.end - r.begin + r.halo_lo + r.halo_hi
+            Jr = bufs[i][0][cur ^ 1].download(np.float32).reshape(inner, planes, order="F")[:, r.halo_lo:r.halo_lo + r.end - r.begin]
+            Ir = bufs[i][1].download(spec.idx_np_dtype).reshape(inner, r.end - r.begin, order="F")
+            want_J = ref["J_stages"][:, k_s - 1].reshape(inner, -1, order="F")[:, r.begin:r.end]
+            want_I = ref["idx_stages"][:, k_s - 1].reshape(inner, -1, order="F")[:, r.begin:r.end]
+            assert np.array_equal(Jr, want_J) and np.array_equal(Ir, want_I), (k_s, i)
+        cur ^= 1
+    for r in ranks:
+        r.close()
+    with pytest.raises(hjbdp.HjbError):
+        hjbdp.RankSlab(spec, 0, 3, 3)                     # rank out of range

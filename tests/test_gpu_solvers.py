@@ -205,6 +205,46 @@ def test_6d_24_pow_6_sampled_states(env, form):
         dO.free(); dI.free()
 
 
+@pytest.mark.order(5)
+def test_6d_24_pow_6_as_slabs_of_the_last_axis(env):
+    """C3's kernel mode (K3 mode 3: on-the-fly quaternion model, 64-bit state indexing) in its SLAB form at a real size:
+    the attitude model of Solver_attitude.run (attitude-control/Solver_attitude.m:280-287) on 24^6 = 1.9e8 states x 11^3
+    torques, swept by hjb_solve_multi as 2 and as 4 slabs of the last axis (w3) - every slab on this box's one GPU, halo
+    planes copied device to device per stage - must equal the whole-grid launch on EVERY state, two stages deep (the
+    second stage reads what the exchange delivered), and a sample of first-stage states must equal the oracle."""
+    hjbdp, _abi, c_oracle = env
+    sa = hjbdp.Solver_attitude(n_mesh_w=24, n_mesh_q=24)
+    sa.U_vector = np.linspace(-0.11, 0.11, 11)
+    spec0 = sa.build_spec_model()
+    spec = hjbdp.ProblemSpec(spec0.knots, spec0.m, spec0.next_terms, spec0.cost_terms, dtype=np.float32, index_base=spec0.index_base,
+                             model=spec0.model, idx_dtype="auto")
+    assert spec.nS == 24 ** 6 and spec.nU == 1331 and spec.idx_np_dtype == np.uint16
+    rng = np.random.default_rng(246)
+    vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
+    term = vecs[0].reshape(-1, 1, 1, 1, 1, 1)
+    for a in range(1, 6):                                   # ((v0 + v1) + v2) + ...: one float32 add per axis, like the checker
+        shape = [1] * 6
+        shape[a] = -1
+        term = term + vecs[a].reshape(shape)
+    term = np.asfortranarray(term.astype(np.float32)).reshape(-1, order="F")
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 4
+        whole = bk.solve(2, terminal=term, keep_J=True)
+    first = whole["J_stages"][:, 1]                         # the stage computed first (k_s = 2)
+    sel = np.unique(np.concatenate([rng.integers(0, spec.nS, 300), [0, spec.nS - 1, 24 ** 5 * 11 + 7, 24 ** 5 * 12 - 1]]))
+    Jr, ir = c_oracle.backup_states(_abi, spec, vecs, sel)
+    assert np.array_equal(first[sel], Jr)
+    del first
+    for n_slabs in (2, 4):
+        with hjbdp.MultiBackup(spec, [0] * n_slabs) as mb:
+            infos = [mb.slab_info(i) for i in range(n_slabs)]
+            assert all(i["kernel_variant"] == 4 for i in infos) and infos[-1]["end"] == 24
+            assert any(i["halo_lo"] or i["halo_hi"] for i in infos)
+            out = mb.solve(2, terminal=term)
+        assert np.array_equal(out["J"], whole["J"]), n_slabs
+        assert np.array_equal(out["idx"], whole["idx"]), n_slabs
+
+
 @pytest.mark.order(7)
 def test_solver_attitude_full_6d(env):
     """Solver_attitude.run semantics (6-D x 3-D, single) at a reduced size."""

@@ -47,7 +47,12 @@ def beside():
     for p, s in zip(parts[1:], side):
         launch(p, s)
     for s in side: main.wait_stream(s)
-for name, fn in (("fused", fused), ("interior + strips in line", inline), ("strips beside the interior", beside)):
+rk = hjbdp.RankSlab(spec, 0, N // 2, N, overlap=True)      # the same rank through hjb_rank_create: one call per stage
+assert (rk.begin, rk.end, rk.halo_lo, rk.halo_hi) == (b, e, hl, hh) and rk.split
+def one_call():
+    rk.stage(J_in, J_out, idx, compute_stream=main.cuda_stream)
+for name, fn in (("fused", fused), ("interior + strips in line", inline), ("strips beside the interior", beside),
+                 ("strips beside, hjb_rank_stage", one_call)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
