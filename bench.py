@@ -48,7 +48,7 @@ KERNEL_OF_VARIANT = {7: "k_backup_colsweep", 6: "k_backup_row", 5: "k_backup_tab
                      2: "k_backup_packed", 1: "k_backup_nested", 3: "k_backup_ctrlsplit", 0: "k_backup_generic"}
 # how the stage kernel of each workload is told apart in one rocprofv3 pass over all of them (demangled names)
 # (substring the name must hold, substring it must not hold): the binary16 type is spelt differently by demanglers
-KERNEL_FILTER = {"c4": ("k_backup_colsweep<float, float", None), "c5": ("k_backup_colsweep<float, ", "k_backup_colsweep<float, float"),
+KERNEL_FILTER = {"c4": ("k_backup_colsweep<float, float", None), "c5": ("k_backup_colsweep", "k_backup_colsweep<float, float"),   # rocprofv3 leaves the binary16 name mangled
                  "c2": ("k_backup_packed2<float, 3", None), "6d": ("k_backup_packed2<float, 6", None)}
 EXTRA_STEPS = {"c5": 20, "c2": 20, "6d": 4}
 
