@@ -159,7 +159,15 @@ def test_c3_full_size_51_pow_6(env):
     rng = np.random.default_rng(51)
     vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
     dO, dI, secs = _separable_backup_on_device(hjbdp, spec, vecs, timed=True)
-    print("C3 51^6 x 11^3: %.1f s per stage, %.3e backups/s" % (secs, spec.nS * spec.nU / secs))
+    line = "C3 51^6 x 11^3, uint16 labels, 176 GB resident: %.2f s per stage, %.3e backups/s" % (secs, spec.nS * spec.nU / secs)
+    print(line)
+    try:
+        from conftest import ROOT
+        (ROOT / "gpurun_out").mkdir(exist_ok=True)
+        with open(ROOT / "gpurun_out" / "c3_stage_time.log", "a") as fh:
+            fh.write(line + "\n")
+    except OSError:
+        pass
     n = np.array(spec.n, dtype=np.int64)
     sel = rng.integers(0, spec.nS, 300)
     # plus grid corners / edges and the very last state (64-bit indexing)
@@ -289,7 +297,8 @@ def test_solver_pos_att_all_channels_with_monitor(env):
     sx, sv, st, sw = pa.grids()
     spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, [0.0], pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
                                     pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
-    ref = c_oracle.sweep(_abi, spec, 120, monitor_period=10, monitor_tol=5.0)
+    assert pa.monitor_single and spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8     # the mirror's defaults: the reference's typing
+    ref = c_oracle.sweep(_abi, spec, 120, monitor_period=10, monitor_tol=5.0, monitor_single=True)
     c = pa.controllers["channel_x_controller_1_failure"]
     assert len(c["f0_allcomb"]) == 6
     assert c["stages_done"] == ref["stages_done"] and c["stopped_early"] == ref["stopped_early"]
