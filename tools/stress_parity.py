@@ -1,5 +1,6 @@
 """Randomised GPU-vs-oracle parity stress: random shapes (D, C, grid sizes, dtype, knot spacing, displacement
-spread, J storage), every applicable stage-kernel variant plus hjb_solve's multi-stage paths, whole grids and slabs.
+spread, J storage, argmin label width, float64-built query tables, the monitor in float32 or float64), every applicable
+stage-kernel variant plus hjb_solve's multi-stage paths, whole grids and slabs.
 Every result must equal the C oracle's bit for bit.  usage: python tools/stress_parity.py [seconds=120] [seed=0]"""
 import os, sys, time
 import numpy as np
@@ -73,13 +74,27 @@ while time.time() < t_end:
     if dtype == np.float32 and rng.random() < 0.25:
         spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=1,
                                  j_storage=np.float16)
-    term = random_terminal(spec, seed + 1)
+    # the typing options of round 3: label width, float64-built tables (float32 problems; the float64 copy of the terms
+    # is what the generators produced before the spec rounded them), the monitor's summation type
+    idx_dtype = [None, None, "auto", np.uint8, np.uint16][int(rng.integers(0, 5))]
+    if idx_dtype is np.uint8 and spec.nU - 1 + spec.index_base > 255:
+        idx_dtype = "auto"
+    tab64 = bool(spec.dtype == np.float32 and rng.random() < 0.3)
+    if idx_dtype is not None or tab64:
+        spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=spec.dtype, index_base=spec.index_base,
+                                 j_storage=None if spec.j_dtype == spec.dtype else spec.j_dtype, idx_dtype=idx_dtype,
+                                 table_dtype=np.float64 if tab64 else None)
+    mon = {}
+    if rng.random() < 0.3:
+        mon = dict(monitor_period=int(rng.integers(1, 4)), monitor_tol=float(rng.choice([0.0, 1e-3, 1e30])),
+                   monitor_single=bool(rng.random() < 0.5))
+    term = random_terminal(spec, seed + 1).astype(spec.j_dtype)
     stages = int(rng.choice([1, 2, 5, 17, 40, 70]))
     if kind == "local2d":
         stages = int(rng.choice([16, 23, 40, 70, 129]))
     if spec.nS * spec.nU * stages > 4e7:
         stages = 2
-    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, nthreads=16)
+    ref = c_oracle.sweep(_abi, spec, stages, terminal=term, nthreads=16, **mon)
     if not np.all(np.isfinite(ref["J"].astype(np.float64))):
         continue      # random dynamics with strong extrapolation can blow J up to inf/NaN: outside the contract
                       # (SURVEY 8a note 3: "NaNs ... none arise"; min/argmin of NaNs is not defined alike everywhere)
@@ -90,6 +105,8 @@ while time.time() < t_end:
         except hjbdp.HjbError as e:
             assert e.status == _abi.HJB_E_UNSUPPORTED, (v, str(e))
             continue
+        if mon and kind == "local2d":
+            pass
         with bk:
             if v == "7 two loads":
                 bk.set_option("cs_dpp", 0)
@@ -98,13 +115,19 @@ while time.time() < t_end:
                 if not bk.get_option("cs_coop"):
                     continue
             kv = bk.info()["kernel_variant"]
-            out = bk.solve(stages, terminal=term)
-        ok = np.array_equal(out["J"], ref["J"], equal_nan=True) and np.array_equal(out["idx"], ref["idx"])   # (f16 J may overflow to inf/NaN over many stages - on both sides alike)
+            out = bk.solve(stages, terminal=term, **mon)
+            assert out["idx"].dtype == spec.idx_np_dtype
+        ok = np.array_equal(out["J"], ref["J"], equal_nan=True) and np.array_equal(out["idx"], ref["idx"])
+        if mon:
+            # float32 sums: the library's stated order, bit for bit; float64 sums: order-free to rounding
+            exact = mon["monitor_single"] and spec.dtype == np.float32
+            close = (out["last_e"] == ref["last_e"]) if exact else (abs(out["last_e"] - ref["last_e"]) <= 1e-9 * max(abs(ref["last_e"]), 1e-300) + 1e-9)
+            ok = ok and out["stages_done"] == ref["stages_done"] and (close or not np.isfinite(ref["last_e"])) and out["last_e2"] == ref["last_e2"]   # (f16 J may overflow to inf/NaN over many stages - on both sides alike)
         seen[(v, kv)] = seen.get((v, kv), 0) + 1
         n_runs += 1
         if not ok:
             print("MISMATCH", dict(D=D, C=C, n=n, m=m, dtype=str(np.dtype(dtype)), j=str(spec.j_dtype), nonuniform=nonuniform,
-                                   spread=spread, seed=seed, kind=str(kind), stages=stages, forced=v, ran=kv), flush=True)
+                                   spread=spread, seed=seed, kind=str(kind), stages=stages, forced=v, ran=kv, idx=str(idx_dtype), tab64=tab64, mon=mon), flush=True)
             sys.exit(1)
     # a random slab of the last axis with the halos the library asks for, one stage
     nl = spec.n[-1]
