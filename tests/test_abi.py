@@ -106,13 +106,18 @@ def _builder_from_spec(lib, spec):
     for a in range(spec.D):
         k = np.ascontiguousarray(spec.knots[a], dtype=np.float64)
         assert lib.hjb_problem_set_knots(b, a, k.ctypes.data_as(C.POINTER(C.c_double)), k.size) == _abi.HJB_OK
-    def flat(t):
+    idx_code = {None: _abi.HJB_IDX_I32, "auto": _abi.HJB_IDX_AUTO}.get(spec.idx_dtype if not hasattr(spec.idx_dtype, "itemsize") else None,
+                                                                    {1: _abi.HJB_IDX_U8, 2: _abi.HJB_IDX_U16, 4: _abi.HJB_IDX_I32}[spec.idx_np_dtype.itemsize])
+    if spec.table_dtype is not None or spec.idx_dtype is not None:
+        assert lib.hjb_problem_set_types(b, idx_code, _abi.HJB_TAB_F64 if spec.table_dtype is not None else _abi.HJB_TAB_DEFAULT) == _abi.HJB_OK
+
+    def flat(t, dtype=None):
         mask = sum(1 << d for d in t.dims)
-        v = np.ascontiguousarray(np.asarray(t.data, dtype=spec.dtype).reshape(-1, order="F"))
+        v = np.ascontiguousarray(np.asarray(t.data, dtype=dtype or spec.dtype).reshape(-1, order="F"))
         return mask, v
     for a in range(spec.D):
         for t in spec.next_terms[a]:
-            mask, v = flat(t)
+            mask, v = flat(t, spec.table_dtype)
             assert lib.hjb_problem_add_next_term(b, a, mask, v.ctypes.data, v.size) == _abi.HJB_OK
     for t in spec.cost_terms:
         mask, v = flat(t)
@@ -239,3 +244,26 @@ def test_problem_spec_validation():
         hjbdp.ProblemSpec([k], [3], [[hjbdp.Term((0,), np.zeros(4))]], [hjbdp.Term((0,), k)])
     with pytest.raises(ValueError):
         hjbdp.ProblemSpec([k], [3], [[hjbdp.Term((0,), k)]], [hjbdp.Term((0,), k)], dtype=np.float16)
+
+
+def test_flat_builder_types_are_validated(lib):
+    """hjb_problem_set_types: label storage and the table dtype of a problem under construction - the table dtype is the
+    element type of the next-state terms, so it cannot change once one was added; float64 tables are for float32 problems."""
+    from hjbdp import _abi
+    n = (C.c_int32 * 2)(5, 4)
+    m = (C.c_int32 * 1)(3)
+    b = C.c_void_p()
+    assert lib.hjb_problem_new(2, 1, n, m, _abi.HJB_F32, 1, C.byref(b)) == _abi.HJB_OK
+    assert lib.hjb_problem_set_types(b, 7, 0) == _abi.HJB_E_INVALID and b"idx_dtype" in lib.hjb_problem_last_error(b)
+    assert lib.hjb_problem_set_types(b, _abi.HJB_IDX_AUTO, 5) == _abi.HJB_E_INVALID
+    assert lib.hjb_problem_set_types(b, _abi.HJB_IDX_U8, _abi.HJB_TAB_F64) == _abi.HJB_OK
+    v = np.arange(5, dtype=np.float64)                    # float64 data now: 5 doubles
+    assert lib.hjb_problem_add_next_term(b, 0, 1, v.ctypes.data, 5) == _abi.HJB_OK
+    assert lib.hjb_problem_set_types(b, _abi.HJB_IDX_U8, _abi.HJB_TAB_DEFAULT) == _abi.HJB_E_INVALID      # terms already typed
+    assert b"before adding" in lib.hjb_problem_last_error(b)
+    assert lib.hjb_problem_set_types(b, _abi.HJB_IDX_U16, _abi.HJB_TAB_F64) == _abi.HJB_OK                # the label type may still change
+    assert lib.hjb_problem_free(b) == _abi.HJB_OK
+    b = C.c_void_p()
+    assert lib.hjb_problem_new(2, 1, n, m, _abi.HJB_F64, 1, C.byref(b)) == _abi.HJB_OK
+    assert lib.hjb_problem_set_types(b, _abi.HJB_IDX_I32, _abi.HJB_TAB_F64) == _abi.HJB_E_INVALID         # a float64 problem is float64 throughout
+    assert lib.hjb_problem_free(b) == _abi.HJB_OK

@@ -291,3 +291,44 @@ def test_rank_api_three_ranks_in_one_process(env, overlap):
         r.close()
     with pytest.raises(hjbdp.HjbError):
         hjbdp.RankSlab(spec, 0, 3, 3)                     # rank out of range
+
+
+def test_flat_api_reference_typing_of_pos_att(env):
+    """The flat call sequence a MATLAB host makes for Solver_pos_att in the reference's typing (hjbdp_solve.m with
+    'double_tables'): hjb_problem_set_types(AUTO, HJB_TAB_F64), next-state operands handed over as doubles, labels back as
+    one byte per state, the monitor in single precision through the handle option - equal to the oracle bit for bit."""
+    hjbdp, _abi, c_oracle = env
+    lib = hjbdp.load_library()
+    pa = hjbdp.Solver_pos_att()
+    pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 14, 9, 8, 7
+    sx, sv, st, sw = pa.grids()
+    spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    assert spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8
+    b = C.c_void_p()
+    n = (C.c_int32 * 4)(*spec.n)
+    m = (C.c_int32 * 1)(*spec.m)
+    assert lib.hjb_problem_new(4, 1, n, m, _abi.HJB_F32, 1, C.byref(b)) == 0
+    assert lib.hjb_problem_set_types(b, _abi.HJB_IDX_AUTO, _abi.HJB_TAB_F64) == 0
+    for a in range(4):
+        k = np.ascontiguousarray(spec.knots[a])
+        assert lib.hjb_problem_set_knots(b, a, k.ctypes.data_as(C.POINTER(C.c_double)), k.size) == 0
+        for t in spec.next_terms[a]:
+            v = np.ascontiguousarray(np.asarray(t.data, dtype=np.float64).reshape(-1, order="F"))       # doubles
+            assert lib.hjb_problem_add_next_term(b, a, sum(1 << d for d in t.dims), v.ctypes.data, v.size) == 0
+    for t in spec.cost_terms:
+        v = np.ascontiguousarray(np.asarray(t.data, dtype=np.float32).reshape(-1, order="F"))           # singles
+        assert lib.hjb_problem_add_cost_term(b, sum(1 << d for d in t.dims), v.ctypes.data, v.size) == 0
+    h = C.c_void_p()
+    assert lib.hjb_create_from(b, 0, C.byref(h)) == 0, lib.hjb_problem_last_error(b)
+    lib.hjb_problem_free(b)
+    assert lib.hjb_set_option(h, b"monitor_single", 1) == 0
+    stages = 30
+    J = np.empty(spec.nS, dtype=np.float32)
+    idx = np.empty(spec.nS, dtype=np.uint8)
+    done, early, ms = C.c_int32(), C.c_int32(), C.c_double()
+    st_ = lib.hjb_solve_flat(h, stages, 10, 1e-2, None, J.ctypes.data, idx.ctypes.data, None, None, C.byref(done), C.byref(early), C.byref(ms))
+    assert st_ == 0, lib.hjb_last_error(h)
+    lib.hjb_destroy(h)
+    ref = c_oracle.sweep(_abi, spec, stages, monitor_period=10, monitor_tol=1e-2, monitor_single=True)
+    assert done.value == ref["stages_done"] and bool(early.value) == ref["stopped_early"]
+    assert np.array_equal(J, ref["J"]) and np.array_equal(idx, ref["idx"])
