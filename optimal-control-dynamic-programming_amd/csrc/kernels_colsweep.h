@@ -118,7 +118,9 @@ __device__ __forceinline__ void take_tie(float best, int &best_u, float tot, int
     unsigned long long m;
     asm volatile("v_cmp_eq_f32 %1, %2, %4\n\tv_cmp_lt_i32 vcc, %3, %0\n\ts_and_b64 vcc, vcc, %1\n\t"
                  "v_cndmask_b32 %0, %0, %3, vcc"
-                 : "+v"(best_u), "=&s"(m) : "v"(tot), "v"(u), "v"(best) : "vcc");
+                 : "+v"(best_u), "=&s"(m) : "v"(tot), "v"(u), "v"(best) : "vcc", "scc");     // s_and_b64 writes SCC: without
+                 // the clobber a flush test (s_cmp ... s_cselect) scheduled around this block reads a stale SCC - found in round 3
+                 // when a restructured build moved one there (wrong write-out timing, garbage labels)
 }
 // The corner-row gathers of the column loop are issued by hand and waited for by hand.  hipcc's wait insertion is
 // path-insensitive: a load that sits behind a wave-uniform guard (a column has ng <= NG groups), or any store that may
@@ -417,6 +419,11 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         const int n = LPK * (1 + ((used[g] & pairmask) != 0) + ((used[g] & (pairmask << (MM / 2))) != 0));
         if (g < NGH) nH0 += n; else nH1 += n;
     }
+    // operands of a scalar jump (wait_gathers_n): pinned to scalar registers whatever pipe the compiler summed them on (under
+    // scalar-register pressure it moves uniform arithmetic to the vector pipe, and an "s" asm operand then receives a VGPR -
+    // which only the assembler rejects: tests/test_kernel_budget.py assembles the code object for that reason)
+    nH0 = __builtin_amdgcn_readfirstlane(nH0);
+    nH1 = __builtin_amdgcn_readfirstlane(nH1);
     auto load_groups = [&](int g0, int g1, uint32_t vrow) __attribute__((always_inline)) {
         uint32_t vb[NW];
 #pragma unroll

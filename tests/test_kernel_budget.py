@@ -32,6 +32,11 @@ def cs_asm(tmp_path_factory):
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
                         "-o", str(asm), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+    # ... and ASSEMBLED: -S prints inline asm operands without checking them (a VGPR handed to an "s" operand of the
+    # counted-wait jump passes -S and fails here)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only",
+                        "-o", str(d / "cs_budget.o"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
     return asm.read_text()
 
 
