@@ -101,6 +101,10 @@ struct Handle {
     // every stage-invariant (cell, weight) table of this handle: rebuilt by option "prep_mfma" (timing / equality tests)
     struct PrepRec { int axis; int kind; const int32_t *dsz_d; std::vector<int32_t> dsz; int64_t n; void *tab; };
     std::vector<PrepRec> preps;
+    bool inline_axis0 = true;     // allow mode 1's axis 0 without a table (see build)
+    bool axis0_inline = false;    // ... in effect: N.at[0].tab is null
+    uint32_t axis0_dom = 0;       // its broadcast domain and entry count, should the table be wanted after all
+    int64_t axis0_nent = 0;
     int prep_mfma = 0;            // 1: tables were built with v_mfma_f32_32x32x2_f32 where the axis' terms allow it
     int prep_mfma_axes = 0;       // ... number of tables the MFMA form applied to in the last rebuild
     double prep_us = 0;           // device time of the last rebuild of all tables
@@ -245,6 +249,44 @@ void launch_prep_t(int D, int grid, const DParams *dp, int a, const int32_t *dsz
         case 5: hipLaunchKernelGGL((k_prep_axis_table_t<T, 5>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
         default: hipLaunchKernelGGL((k_prep_axis_table_t<T, 6>), g, b, 0, nullptr, dp, a, dsz, n, tab); break;
     }
+}
+
+// one outer axis' (cell, t) table over its broadcast domain `dom` (variant 2 / 4), registered for rebuilds
+template <typename T>
+int build_axis_table(Handle *h, const hjb_problem *p, int a, uint32_t dom, int64_t nent) {
+    const int D = p->D, C = p->C;
+    const int owned_last = h->hp.n[D - 1];
+    DNested::DAxisTable &A = h->hn.at[a];
+    std::vector<int32_t> dsz(HJB_MAX_G, 1);
+    for (int d = 0; d < D + C; ++d) {
+        if (!(dom & (1u << d))) continue;
+        dsz[d] = (d < D) ? (d == D - 1 ? owned_last : p->n[d]) : p->m[d - D];
+    }
+    void *dsz_d = nullptr, *tab = nullptr;
+    int st3 = upload(h, dsz, &dsz_d);
+    if (st3) return st3;
+    st3 = dev_alloc(h, (size_t)nent * sizeof(int2), &tab);
+    if (st3) return st3;
+    const int grid = (int)std::min<int64_t>((nent + 255) / 256, 65536);
+    launch_prep<T>(D, grid, h->dp, a, (const int32_t *)dsz_d, nent, (int2 *)tab);
+    h->preps.push_back({a, 0, (const int32_t *)dsz_d, dsz, nent, tab});
+    A.tab = tab;
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipDeviceSynchronize());
+    return HJB_OK;
+}
+
+// The axis-0 table of a mode-1 problem that runs without one (axis0_inline): built on demand for the kernels that read
+// tables only (forced variant 2, option "axis0_table").
+int ensure_axis0_table(Handle *h) {
+    if (!h->axis0_inline) return HJB_OK;
+    const int st = build_axis_table<float>(h, &h->prob, 0, h->axis0_dom, h->axis0_nent);
+    if (st) return st;
+    h->axis0_inline = false;
+    if (h->packed_pre == 4) h->packed_pre = 1;
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }      // captured launches are the other instantiation
+    if (h->dn) HIP_TRY(h, hipMemcpy(h->dn, &h->hn, sizeof(DNested), hipMemcpyHostToDevice));
+    return HJB_OK;
 }
 
 template <typename T>
@@ -570,6 +612,21 @@ int build(Handle *h, const hjb_problem *p) {
                 const bool has_o0 = (C == 3) && (dom[a] & (1u << D));
                 A.level = has_o1 ? 1 : (has_o0 ? 0 : -1);
                 if (p->n_next_terms[a] == 0) continue;     // model axis: evaluated in the stage kernel
+                // The C2 shape (mode 1 below: D = 3, three control dims, axis 0 moves with control dim 0, axis 1 with
+                // control dim 1): when axis 0's next value is (state-only terms) + ONE term over control dim 0 alone, the
+                // stage kernel forms its (cell, t) from q in registers - same ordered sum, same exact search - and the
+                // table (8 bytes per state and o0 step: 173 MB on C2, streamed every stage) is not built at all
+                if (a == 0 && D == 3 && C == 3 && has_o0 && !has_o1 && h->inline_axis0 &&
+                    p->n_next_terms[0] == P.axis[0].n_prefix + 1 && p->next_terms[0][p->n_next_terms[0] - 1].mask == (1u << D)) {
+                    uint32_t m1 = 0;
+                    for (int k = 0; k < p->n_next_terms[1]; ++k) m1 |= p->next_terms[1][k].mask;
+                    if ((m1 & (1u << (D + 1))) && !(m1 & (1u << D))) {       // A.tab stays null
+                        h->axis0_inline = true;
+                        h->axis0_dom = dom[0];
+                        h->axis0_nent = nent[0];
+                        continue;
+                    }
+                }
                 void *dsz_d = nullptr, *tab = nullptr;
                 int st3 = upload(h, dsz, &dsz_d);
                 if (st3) return st3;
@@ -587,6 +644,12 @@ int build(Handle *h, const hjb_problem *p) {
             const bool cl_lds = (!N.ot[HJB_MAX_D].present || N.ot[HJB_MAX_D].lds_off >= 0) &&
                                 (!N.ot[HJB_MAX_D + 1].present || N.ot[HJB_MAX_D + 1].lds_off >= 0);
             if (cl_lds && C == 3 && D == 3 && N.at[0].level == 0 && N.at[1].level == 1) h->packed_pre = 1;
+            if (h->axis0_inline && h->packed_pre != 1) {     // mode 1 did not come about after all: the table is needed
+                const int st4 = build_axis_table<T>(h, p, 0, dom[0], nent[0]);
+                if (st4) return st4;
+                h->axis0_inline = false;
+            }
+            if (h->axis0_inline) h->packed_pre = 4;          // mode 1 without the axis-0 table (kernels_packed2.h MODE 4)
             if (cl_lds && C == 3 && D >= 4 && N.at[D - 3].level == 0 && N.at[D - 2].level == 1) {
                 bool pre = true;
                 for (int a = 0; a < D - 3; ++a) pre = pre && N.at[a].level < 0;
@@ -1730,6 +1793,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             return fail(h, HJB_E_UNSUPPORTED, "variant 4 (packed, control pairs) needs float32 and the canonical spacecraft structure");
         if (value == 2 && h->packed_mode != 1)
             return fail(h, HJB_E_UNSUPPORTED, "variant 2 (packed) needs float32 and the canonical spacecraft structure (see kernels_packed.h)");
+        if (value == 2) { const int ast = ensure_axis0_table(h); if (ast) return ast; }     // variant 2 reads every axis from its table
         if (value == 1 && !h->nested_ok)
             return fail(h, HJB_E_UNSUPPORTED, "variant 1 (control-nested) needs: only the last state axis depends on the innermost control dim");
         h->forced_variant = (int)value;
@@ -1830,6 +1894,10 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         h->use_graph = value != 0;
         return HJB_OK;
     }
+    if (!strcmp(key, "axis0_table")) {      // 1: build the axis-0 (cell, t) table a mode-1 problem runs without (A/B timing, tests)
+        if (value) { const int ast = ensure_axis0_table(h); if (ast) return ast; }
+        return HJB_OK;
+    }
     if (!strcmp(key, "monitor_single")) {   // hjb_solve_opts.monitor_single for callers of the flat API (hjb_solve_flat)
         h->monitor_single = value != 0;
         return HJB_OK;
@@ -1842,6 +1910,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     if (!h || !key || !value) return fail(h, HJB_E_INVALID, "null argument");
     if (!strcmp(key, "variant")) *value = h->variant;
     else if (!strcmp(key, "graph")) *value = h->use_graph ? 1 : 0;
+    else if (!strcmp(key, "axis0_table")) *value = h->axis0_inline ? 0 : 1;       // 0: mode 1 forms axis 0's (cell, t) in the kernel
     else if (!strcmp(key, "monitor_single")) *value = h->monitor_single ? 1 : 0;
     else if (!strcmp(key, "idx_bytes")) *value = h->idx_bytes;
     else if (!strcmp(key, "temporal")) *value = h->use_temporal;

@@ -145,6 +145,8 @@ __device__ __forceinline__ float contract_df(const TJ *__restrict__ Jn, int off,
 // MODE (chosen on the host from the axis levels; "level" = the outermost control loop an axis' cell depends on):
 //   0  plain: 2 x 2^D corner gathers + full contraction per (o0,o1) step
 //   1  D == 3, axis 0 level 0, axis 1 level 1 (the C2 shape): axis 0 contracted once per o0 step
+//   4  mode 1 with axis 0's (cell, t) formed per o0 step from q in registers instead of read from a table (the host picks it
+//      when axis 0's next value is state-only terms + ONE term over control dim 0: no 8-byte-per-(state, o0) table at all)
 //   2  D >= 4, axes 0..D-4 state-only, axis D-3 level 0, axis D-2 level 1 (the attitude model with the angle axes
 //      first): the state-only axes are contracted ONCE PER STATE over the 3 x 3 x 4 window of (axis D-3 rows,
 //      axis D-2 rows, last-axis planes) the whole control sweep can touch; an o0 step is then 24 selects + 12
@@ -157,9 +159,11 @@ __global__ void __launch_bounds__(256)
 k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
                  TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
+    constexpr bool INL0 = MODE == 4;          // mode 1 with axis 0's (cell, t) formed in the kernel (no table: see below)
+    constexpr bool M1 = MODE == 1 || MODE == 4;
     constexpr bool HIER = MODE != 0;
     constexpr int AX_A = D >= 3 ? D - 3 : 0, AX_B = D >= 2 ? D - 2 : 0;   // the level-0 / level-1 axes of modes 1, 2
-    constexpr bool PRE = MODE >= 2, QMODEL = MODE == 3;
+    constexpr bool PRE = MODE == 2 || MODE == 3, QMODEL = MODE == 3;
     constexpr int NP = PRE ? D - 3 : 0;
     using sidx_t = typename std::conditional<QMODEL, int64_t, int>::type;   // linear state index
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -230,6 +234,22 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     const int cl_off[2] = {N->ot[CL0].lds_off, N->ot[CL1].lds_off};
     const int cl_c0[2] = {N->ot[CL0].c0, N->ot[CL1].c0}, cl_c1[2] = {N->ot[CL0].c1, N->ot[CL1].c1};
     // last axis' inner term: control-only (LDS) or state-dependent (global, offset boff + j * stride)
+    // Mode 1 (the C2 shape): when axis 0's next value is (state-only terms) + ONE term over control dim 0, its (cell, t) is
+    // formed per o0 step from q in registers - the same ordered sum, the same exact search, the same weight as the table
+    // entry would hold - and no table is built: C2's 173 MB of axis-0 entries (8 bytes per state and o0 step, re-read every
+    // stage: 9x the algorithmic HBM bytes) disappear.  N->at[0].tab == nullptr says so.
+    // axis 0's (cell, t) at control o0 from the state part qs of its next value: read from P where it is needed (once per o0
+    // step), not hoisted - the kernel sits at the register budget of four waves per SIMD
+    auto axis0_entry = [&](float qs, int o0, int &c_out, float &t_out) __attribute__((always_inline)) {
+        const DAxis &a0 = P->axis[0];
+        const int npre0 = a0.n_prefix;
+        const float bq = as_global<float>(a0.t[npre0].data)[o0];
+        const float q0 = npre0 == 0 ? bq : qs + bq;
+        gptr<float> kk0 = as_global<float>(a0.knots);
+        const int c0 = find_cell_g(kk0, a0.n, q0, a0.uniform, (float)a0.x0, (float)a0.inv_h);
+        c_out = c0;
+        t_out = (q0 - kk0[c0]) * as_global<float>(a0.rdx)[c0];
+    };
     const bool b_pure = N->in[0].lds_slot >= 0;
     gptr<float> b_data = as_global<float>(N->in[0].data);
     const int b_stride = N->in[0].stride_in;
@@ -239,7 +259,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         const bool valid = ls < n_owned;
         if (!valid) ls = n_owned - 1;         // harmless duplicate work, store skipped
 
-        float ql, gpre;
+        float ql, gpre, qs0 = 0.f;            // qs0: state-only part of axis 0's next value (inl0)
         int boff = 0;                         // state part of the inner term's table offset
         int aoff[DM], coff[2], cell[DM];
         float tw[DM];
@@ -273,6 +293,14 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 g = (k == 0) ? x : g + x;
             }
             gpre = g;
+            if constexpr (INL0) {
+                float q0 = 0.f;
+                for (int k = 0; k < P->axis[0].n_prefix; ++k) {
+                    const float x = term_value32<D>(P->axis[0].t[k], si);
+                    q0 = (k == 0) ? x : q0 + x;
+                }
+                qs0 = q0;
+            }
 #pragma unroll
             for (int a = 0; a < D - 1; ++a) {
                 int off = 0;
@@ -430,9 +458,13 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
             for (int a = 0; a < D - 1; ++a) {
                 if (a_lvl[a] == 0) {
-                    const i2v e = atab[a][aoff[a] + o0 * a_c0[a]];
-                    cell[a] = e.x;
-                    tw[a] = __int_as_float(e.y);
+                    if (INL0 && a == 0) {
+                        axis0_entry(qs0, o0, cell[a], tw[a]);
+                    } else {
+                        const i2v e = atab[a][aoff[a] + o0 * a_c0[a]];
+                        cell[a] = e.x;
+                        tw[a] = __int_as_float(e.y);
+                    }
                 }
             }
             float go0 = gpre;
@@ -485,7 +517,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         const float f1 = w0[(12 + rb * 4 + q) * 256];
                         F[rb][q] = __builtin_fmaf(ta, f1 - f0, f0);
                     }
-            } else if constexpr (MODE == 1) {
+            } else if constexpr (M1) {
                 const int cmin = b_o0dep ? min_cell(atab[1] + aoff[1] + o0 * a_c0[1], m_o1, a_c1[1]) : cBmin;
                 c1min = cmin;
                 const int n1 = P->axis[1].n;
@@ -751,9 +783,13 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
             for (int a = 0; a < D - 1; ++a) {
                 if (a_lvl[a] >= 0) {
-                    const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + (a_lvl[a] == 1 ? o1 * a_c1[a] : 0)];
-                    cell[a] = e.x;
-                    tw[a] = __int_as_float(e.y);
+                    if (INL0 && a == 0) {
+                        axis0_entry(qs0, o0, cell[a], tw[a]);
+                    } else {
+                        const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + (a_lvl[a] == 1 ? o1 * a_c1[a] : 0)];
+                        cell[a] = e.x;
+                        tw[a] = __int_as_float(e.y);
+                    }
                 }
                 ob += js[a] * cell[a];
             }

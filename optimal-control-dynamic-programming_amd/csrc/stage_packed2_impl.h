@@ -14,6 +14,8 @@ static int packed2_go(const StageArgs &a, int mode) {
     case DD:                                                                                                         \
         if (DD == 3 && mode == 1)                                                                                    \
             hipLaunchKernelGGL((k_backup_packed2<TJ, 3, 1>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
+        else if (DD == 3 && mode == 4)                                                                               \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, 3, 4>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
         else if (DD == 6 && mode == 3)                                                                               \
             hipLaunchKernelGGL((k_backup_packed2<TJ, 6, 3>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
         else if (DD >= 4 && mode == 2)                                                                               \

@@ -515,12 +515,37 @@ def test_c2_workload_small_bit_exact(env):
     hjbdp, _abi, c_oracle = env
     from hjbdp.synthetic import position3d_spec
     spec = position3d_spec(n=15, mu=7)
-    with hjbdp.Backup(spec) as bk:
-        assert bk.info()["kernel_variant"] in (2, 4)
-        out = bk.solve(6, keep_J=True, keep_idx=True)
     ref = c_oracle.sweep(_abi, spec, 6, keep_J=True, keep_idx=True)
-    assert np.array_equal(out["J_stages"], ref["J_stages"])
-    assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 4
+        # the C2 shape runs WITHOUT an axis-0 (cell, t) table: the kernel forms the entry from q in registers (K3 mode 4) ...
+        assert bk.get_option("axis0_table") == 0
+        out = bk.solve(6, keep_J=True, keep_idx=True)
+        assert np.array_equal(out["J_stages"], ref["J_stages"])
+        assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+        # ... and with the table built after all (mode 1): the same bits
+        bk.set_option("axis0_table", 1)
+        assert bk.get_option("axis0_table") == 1
+        out = bk.solve(6, keep_J=True, keep_idx=True)
+        assert np.array_equal(out["J_stages"], ref["J_stages"])
+        assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+        bk.set_option("variant", 2)                       # the two-states-per-lane kernel reads every axis from its table
+        out = bk.solve(6)
+        assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+    with hjbdp.Backup(spec, variant=2) as bk:             # forced straight away: the table is built on demand
+        assert bk.get_option("axis0_table") == 1
+        out = bk.solve(6)
+        assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+    for n_last, mu in ((9, 5), (12, 4)):                  # other sizes of the last axis and of the control grid
+        sp = position3d_spec(n=11, mu=mu, n_last=n_last)
+        r2 = c_oracle.sweep(_abi, sp, 3)
+        with hjbdp.Backup(sp) as bk:
+            assert bk.get_option("axis0_table") == 0
+            o2 = bk.solve(3)
+        assert np.array_equal(o2["J"], r2["J"]) and np.array_equal(o2["idx"], r2["idx"])
+    with hjbdp.MultiBackup(spec, [0, 0, 0]) as mb:       # slabs: every slab handle runs the table-less mode
+        om = mb.solve(6)
+    assert np.array_equal(om["J"], ref["J"]) and np.array_equal(om["idx"], ref["idx"])
 
 
 def test_variant_1_refused_when_not_applicable(env):

@@ -13,9 +13,12 @@ spec = position3d_spec(n, mu)
 pad = int(sys.argv[5]) if len(sys.argv)>5 else 0
 with hjbdp.Backup(spec, variant=var) as bk:
     if pad: bk.set_option('lds_pad', pad)
-    print(bk.info())
+    import os
+    if os.environ.get("AXIS0_TABLE"): bk.set_option('axis0_table', int(os.environ["AXIS0_TABLE"]))
+    print(bk.info(), 'axis0_table', bk.get_option('axis0_table'))
     out = bk.solve(2)
     out = bk.solve(st)
     ms = out['sweep_ms']/st
     print('n=%d mu=%d: %.3f ms/stage, %.3e backups/s' % (n, mu, ms, spec.nS*spec.nU/ (ms*1e-3)))
+    print('sum J %.12e' % float(out['J'].astype(np.float64).sum()))
     print('J range', out['J'].min(), out['J'].max(), 'idx range', out['idx'].min(), out['idx'].max())
