@@ -1,5 +1,6 @@
 """Time the 6-D attitude model (Solver_attitude.run semantics) on an n^6 grid x nu^3 torques.
-usage: python tools/time_6d.py [n=24] [nu=11] [stages=2] [variant=-1]"""
+usage: python tools/time_6d.py [n=24] [nu=11] [stages=2] [variant=-1]     env MODEL=1: next angles computed in the kernel
+(HJB_MODEL_QUAT_EULER321, K3 mode 3 - what C3 runs) instead of tabulated as the reference does (mode 2)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
@@ -12,8 +13,11 @@ variant = int(sys.argv[4]) if len(sys.argv) > 4 else -1
 sa = hjbdp.Solver_attitude(n_mesh_w=n, n_mesh_q=n)
 sa.U_vector = np.linspace(-0.11, 0.11, nu)
 t0 = time.time()
-spec = sa.build_spec_full()
-pspec, _ = hjbdp.permute_state_axes(spec, sa.AXIS_ORDER)
+if os.environ.get("MODEL") == "1":
+    pspec = sa.build_spec_model()
+else:
+    spec = sa.build_spec_full()
+    pspec, _ = hjbdp.permute_state_axes(spec, sa.AXIS_ORDER)
 print("host table build %.1f s" % (time.time() - t0), flush=True)
 with hjbdp.Backup(pspec) as bk:
     if variant >= 0:
