@@ -228,14 +228,21 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     const int inner_sz = (int)P->inner;
     f2 *my_t = s_t + threadIdx.x;
     gptr<i2v> atab[DM];
-    int a_c0[DM], a_c1[DM], a_lvl[DM];
+    int a_c0[DM], a_c1[DM], a_lvl_rt[DM];
 #pragma unroll
     for (int a = 0; a < D - 1; ++a) {
         atab[a] = as_global<i2v>(N->at[a].tab);
         a_c0[a] = N->at[a].c0;
         a_c1[a] = N->at[a].c1;
-        a_lvl[a] = N->at[a].level;
+        a_lvl_rt[a] = N->at[a].level;
     }
+    // the level of axis a's table: in modes 2 and 3 the host has checked the pattern (axis D-3 level 0, axis D-2 level 1, every
+    // axis before them state-only), so it is a compile-time constant of the unrolled axis loops (24^6: 166 -> 118 scalar
+    // registers spilled to vector lanes, 70 fewer lane reads per o0 step); the other modes read it
+    auto a_lvl = [&](int a) __attribute__((always_inline)) -> int {
+        if constexpr (PRE) return a == AX_A ? 0 : (a == AX_B ? 1 : -1);
+        else return a_lvl_rt[a];
+    };
     const bool cl0_present = N->ot[CL0].present, cl1_present = N->ot[CL1].present;
     const bool cl0_first = N->ot[CL0].first, cl1_first = N->ot[CL1].first;
     const int cl_off[2] = {N->ot[CL0].lds_off, N->ot[CL1].lds_off};
@@ -314,7 +321,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
                 for (int d = 0; d < D; ++d) off += N->at[a].sstride[d] * (d == D - 1 ? last_local : si[d]);
                 aoff[a] = off;
-                if (a_lvl[a] < 0 && !(QMODEL && a < 3)) {
+                if (a_lvl(a) < 0 && !(QMODEL && a < 3)) {
                     const i2v e = atab[a][off];
                     cell[a] = e.x;
                     tw[a] = __int_as_float(e.y);
@@ -379,6 +386,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     if (__ballot((cm_first >> j) & 1u) == all) UA |= 1u << j;
         }
         const unsigned int UX = U & ~UA;
+        // UX == 0: every lane's cm is the same single bit (or 0) - the control at which the wave enters the second cell
+        const int jc = U ? __builtin_ctz(U) : 2 * npairs;
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
         // smallest cell over `cnt` table entries `step` apart: four independent loads in flight per trip
@@ -464,7 +473,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             // ---- level 0 ------------------------------------------------------------
 #pragma unroll
             for (int a = 0; a < D - 1; ++a) {
-                if (a_lvl[a] == 0) {
+                if (a_lvl(a) == 0) {
                     if (INL0 && a == 0) {
                         axis0_entry(qs0, o0, cell[a], tw[a]);
                     } else {
@@ -483,7 +492,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 int b = 0;
 #pragma unroll
                 for (int a = 0; a < D - 1; ++a) {
-                    if (a_lvl[a] == 1) {
+                    if (a_lvl(a) == 1) {
                         const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + o1 * a_c1[a]];
                         cell[a] = e.x;
                         tw[a] = __int_as_float(e.y);
@@ -577,6 +586,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             // same first-minimum.  Anything else falls through to the one-step loop below.
             if constexpr (HIER) {
                 if (UX == 0u && !slow_a) {
+                    int r_rows = -1;                                             // the r the kept rows were selected for
+                    float R0[4], RD[4];
                     while (o1 + 1 < m_o1) {
                         const i2v eA = e_nx, eB = e_nx2;
                         const int rA = eA.x - c1min, rB = eB.x - c1min;
@@ -587,55 +598,60 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                             g_nx = level1_cost(o1 + 2);
                         }
                         if (o1 + 3 < m_o1) e_nx2 = tb1[(o1 + 3) * tb1_step];
-                        float a0[2], ad[2], b0[2], bd[2];                        // (E0, dE) first / second cell, per step
+                        // (E0, dE) of the first / second last-axis cell, as {step A, step B} pairs.  The two prepared rows a step
+                        // lerps between, R0 = F[r] and RD = F[r+1] - F[r], are kept from trip to trip (r moves 0 -> 1 at most
+                        // once over an o1 sweep when the axis' next value grows with the control): while every lane's r of both
+                        // steps is the one the rows were selected for, the lerps are 4 packed fmas instead of 16 selects +
+                        // 4 packed subtractions + 4 packed fmas.  Same f1 - f0, same fma: same bits.
+                        const f2 t2 = {__int_as_float(eA.y), __int_as_float(eB.y)};
+                        f2 X2[4];
+                        if (!__any(rA != r_rows || rB != r_rows)) {
 #pragma unroll
-                        for (int sI = 0; sI < 2; ++sI) {
-                            const bool up = (sI == 0 ? rA : rB) != 0;
-                            const float t1 = __int_as_float(sI == 0 ? eA.y : eB.y);
-                            float X[4];
+                            for (int q = 0; q < 4; ++q)
+                                X2[q] = __builtin_elementwise_fma(t2, (f2){RD[q], RD[q]}, (f2){R0[q], R0[q]});
+                        } else {
+                            const bool upA = rA != 0, upB = rB != 0;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const float f0 = up ? F[1][q] : F[0][q];
-                                const float f1 = up ? F[2][q] : F[1][q];
-                                X[q] = __builtin_fmaf(t1, f1 - f0, f0);
+                                const f2 f0 = {upA ? F[1][q] : F[0][q], upB ? F[1][q] : F[0][q]};
+                                const f2 f1 = {upA ? F[2][q] : F[1][q], upB ? F[2][q] : F[1][q]};
+                                const f2 d = f1 - f0;
+                                X2[q] = __builtin_elementwise_fma(t2, d, f0);
+                                R0[q] = f0.y;
+                                RD[q] = d.y;
                             }
-                            a0[sI] = X[0]; ad[sI] = X[1] - X[0];
-                            b0[sI] = X[2]; bd[sI] = X[3] - X[2];
+                            r_rows = rB;
                         }
-                        float cA0 = a0[0], cAd = ad[0], cB0 = a0[1], cBd = ad[1];   // current cell's (E0, dE) of step A / B
-                        const f2 gA2 = {gA, gA}, gB2 = {gB, gB};
+                        // The two halves of every packed instruction are the two STEPS (A, B) of one control: the per-step
+                        // quantities (cost so far, E0, dE) are register pairs as they come out of the lerps above, the
+                        // per-control ones (t_j, r_j) are broadcast by the instruction's operand selects, so nothing has to be
+                        // rearranged; a control pair is 6 packed instructions + 2 v_min3.  UX == 0 leaves at most ONE cell
+                        // change in the sweep, the whole wave's, at control jc: controls before it use the first cell, the
+                        // others the second - three straight loops, no per-pair tests.
+                        const f2 g2 = {gA, gB};
+                        const f2 Ea = X2[0], Da = X2[1] - X2[0], Eb = X2[2], Db = X2[3] - X2[2];
                         float mA = INFINITY, mB = INFINITY;
                         f2 t = my_t[0];
                         f2 r2 = s_r2[0];
+                        auto control_pair = [&](int p, const f2 &Ex, const f2 &Dx, const f2 &Ey, const f2 &Dy)
+                                                __attribute__((always_inline)) {
+                            const f2 totx = (g2 + (f2){r2.x, r2.x}) + __builtin_elementwise_fma((f2){t.x, t.x}, Dx, Ex);
+                            const f2 toty = (g2 + (f2){r2.y, r2.y}) + __builtin_elementwise_fma((f2){t.y, t.y}, Dy, Ey);
+                            t = lds_f2(my_t + (p + 1) * 256);                    // next pair (row npairs is padding)
+                            r2 = lds_f2(s_r2 + p + 1);
+                            mA = __builtin_fminf(mA, __builtin_fminf(totx.x, toty.x));      // v_min3_f32
+                            mB = __builtin_fminf(mB, __builtin_fminf(totx.y, toty.y));
+                        };
                         int p = 0;
-                        while (p < npairs) {
-                            const unsigned int rest = PU >> p;
-                            const int pstop = rest ? p + __builtin_ctz(rest) : npairs;
-                            const f2 eA0v = {cA0, cA0}, eAdv = {cAd, cAd}, eB0v = {cB0, cB0}, eBdv = {cBd, cBd};
+                        const int pa = jc >> 1;                                  // pairs wholly in the first cell
 #pragma unroll 2
-                            for (; p < pstop; ++p) {
-                                const f2 totA = (gA2 + r2) + __builtin_elementwise_fma(t, eAdv, eA0v);
-                                const f2 totB = (gB2 + r2) + __builtin_elementwise_fma(t, eBdv, eB0v);
-                                t = lds_f2(my_t + (p + 1) * 256);
-                                r2 = lds_f2(s_r2 + p + 1);
-                                mA = __builtin_fminf(mA, __builtin_fminf(totA.x, totA.y));      // v_min3_f32
-                                mB = __builtin_fminf(mB, __builtin_fminf(totB.x, totB.y));
-                            }
-                            if (p < npairs) {                                    // the wave changes cell inside this pair
-                                const int jb = 2 * p;
-                                if ((UA >> jb) & 1u) { cA0 = b0[0]; cAd = bd[0]; cB0 = b0[1]; cBd = bd[1]; }
-                                float yA0 = cA0, yAd = cAd, yB0 = cB0, yBd = cBd;
-                                if ((UA >> (jb + 1)) & 1u) { yA0 = b0[0]; yAd = bd[0]; yB0 = b0[1]; yBd = bd[1]; }
-                                const f2 totA = (gA2 + r2) + __builtin_elementwise_fma(t, (f2){cAd, yAd}, (f2){cA0, yA0});
-                                const f2 totB = (gB2 + r2) + __builtin_elementwise_fma(t, (f2){cBd, yBd}, (f2){cB0, yB0});
-                                cA0 = yA0; cAd = yAd; cB0 = yB0; cBd = yBd;
-                                t = lds_f2(my_t + (p + 1) * 256);
-                                r2 = lds_f2(s_r2 + p + 1);
-                                mA = __builtin_fminf(mA, __builtin_fminf(totA.x, totA.y));      // v_min3_f32
-                                mB = __builtin_fminf(mB, __builtin_fminf(totB.x, totB.y));
-                                ++p;
-                            }
+                        for (; p < pa; ++p) control_pair(p, Ea, Da, Ea, Da);
+                        if (jc & 1) {                                            // the change falls on a pair's second control
+                            control_pair(p, Ea, Da, Eb, Db);
+                            ++p;
                         }
+#pragma unroll 2
+                        for (; p < npairs; ++p) control_pair(p, Eb, Db, Eb, Db);
                         if (uo == 0 || mA < best) { best = mA; best_uo = uo; }
                         if (mB < best) { best = mB; best_uo = uo + 1; }
                         o1 += 2;
@@ -778,11 +794,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             int ob = 0;
 #pragma unroll
             for (int a = 0; a < D - 1; ++a) {
-                if (a_lvl[a] >= 0) {
+                if (a_lvl(a) >= 0) {
                     if (INL0 && a == 0) {
                         axis0_entry(qs0, o0, cell[a], tw[a]);
                     } else {
-                        const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + (a_lvl[a] == 1 ? o1 * a_c1[a] : 0)];
+                        const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + (a_lvl(a) == 1 ? o1 * a_c1[a] : 0)];
                         cell[a] = e.x;
                         tw[a] = __int_as_float(e.y);
                     }
