@@ -387,7 +387,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         }
         const unsigned int UX = U & ~UA;
         // UX == 0: every lane's cm is the same single bit (or 0) - the control at which the wave enters the second cell
-        const int jc = U ? __builtin_ctz(U) : 2 * npairs;
+        const int jc = U ? __builtin_ctz(U) : m_in;
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
         // smallest cell over `cnt` table entries `step` apart: four independent loads in flight per trip
@@ -559,10 +559,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             const int tb1_step = a_c1[AX_B];
             i2v e_nx = {0, 0};
             float g_nx = 0.f;
+            // cost so far + the level-1 term; when that term is the first of the sum, -0 + x == x bit for bit (no select per step)
+            const float go0_l1 = cl1_first ? -0.0f : go0;
             auto level1_cost = [&](int o1) -> float {
                 if (!cl1_present) return go0;
-                const float x = cterm(CL1, o0, o1);
-                return cl1_first ? x : go0 + x;
+                return go0_l1 + cterm(CL1, o0, o1);
             };
             i2v e_nx2 = {0, 0};                   // ... and the entry after it: a two-step trip consumes two
             if constexpr (HIER) {
@@ -591,7 +592,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     while (o1 + 1 < m_o1) {
                         const i2v eA = e_nx, eB = e_nx2;
                         const int rA = eA.x - c1min, rB = eB.x - c1min;
-                        if (__any(!((rA == 0 || rA == 1) && (rB == 0 || rB == 1)))) break;   // e_nx, g_nx still belong to o1
+                        if (__any(((unsigned int)rA | (unsigned int)rB) > 1u)) break;   // outside the window: e_nx, g_nx still belong to o1
                         const float gA = g_nx, gB = level1_cost(o1 + 1);
                         if (o1 + 2 < m_o1) {
                             e_nx = tb1[(o1 + 2) * tb1_step];
@@ -646,12 +647,20 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         const int pa = jc >> 1;                                  // pairs wholly in the first cell
 #pragma unroll 2
                         for (; p < pa; ++p) control_pair(p, Ea, Da, Ea, Da);
-                        if (jc & 1) {                                            // the change falls on a pair's second control
+                        if ((jc & 1) && jc < m_in) {                             // the change falls on a pair's second control
                             control_pair(p, Ea, Da, Eb, Db);
                             ++p;
                         }
+                        const int nfull = m_in >> 1;
 #pragma unroll 2
-                        for (; p < npairs; ++p) control_pair(p, Eb, Db, Eb, Db);
+                        for (; p < nfull; ++p) control_pair(p, Eb, Db, Eb, Db);
+                        if (m_in & 1) {                                          // the last control of an odd sweep, alone
+                            const bool second = jc < m_in;                       // (wave-uniform) it lies in the second cell
+                            const f2 El = second ? Eb : Ea, Dl = second ? Db : Da;
+                            const f2 totx = (g2 + (f2){r2.x, r2.x}) + __builtin_elementwise_fma((f2){t.x, t.x}, Dl, El);
+                            mA = __builtin_fminf(mA, totx.x);
+                            mB = __builtin_fminf(mB, totx.y);
+                        }
                         if (uo == 0 || mA < best) { best = mA; best_uo = uo; }
                         if (mB < best) { best = mB; best_uo = uo + 1; }
                         o1 += 2;
