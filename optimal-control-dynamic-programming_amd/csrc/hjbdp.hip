@@ -1912,6 +1912,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "graph")) *value = h->use_graph ? 1 : 0;
     else if (!strcmp(key, "axis0_table")) *value = h->axis0_inline ? 0 : 1;       // 0: mode 1 forms axis 0's (cell, t) in the kernel
     else if (!strcmp(key, "monitor_single")) *value = h->monitor_single ? 1 : 0;
+    else if (!strcmp(key, "packed2_mode")) *value = h->packed_mode ? h->packed_pre : -1;   // variant 4's contraction mode (kernels_packed2.h), -1: not eligible
     else if (!strcmp(key, "idx_bytes")) *value = h->idx_bytes;
     else if (!strcmp(key, "temporal")) *value = h->use_temporal;
     else if (!strcmp(key, "row_lean")) *value = h->row_lean ? 1 : 0;

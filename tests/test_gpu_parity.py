@@ -548,6 +548,81 @@ def test_c2_workload_small_bit_exact(env):
     assert np.array_equal(om["J"], ref["J"]) and np.array_equal(om["idx"], ref["idx"])
 
 
+def _chain_spec(n, m, gain, u_lo, u_hi, cost_order, h=0.2):
+    """D-axis chain x+ = (I + h N) x + gain_a * u_a on the last three axes (N strictly upper-triangular ones), float32:
+    the shape variant 4 contracts hierarchically (D = 3: kernels_packed2.h mode 4 / 1, D >= 4: the window mode 2).
+    gain / the control range place the last axis' cell change on any control of the sweep, on none, or on several;
+    cost_order picks the cost terms (without state terms a control term is the first of the canonical sum)."""
+    from hjbdp.problem import ProblemSpec, Term
+    D = len(n)
+    f = np.float32
+    knots = [np.linspace(-1.0, 1.0, k).astype(np.float32) for k in n]
+    A = np.eye(D) + h * np.triu(np.ones((D, D)), 1)
+    nxt = []
+    for a in range(D):
+        terms = [Term((j,), f(A[a, j]) * knots[j]) for j in range(D) if A[a, j] != 0.0]
+        c = a - (D - 3)
+        if c >= 0:
+            u = np.linspace(u_lo, u_hi, m[c]) if m[c] > 1 else np.array([0.5 * (u_lo + u_hi)])
+            terms.append(Term((D + c,), (gain[c] * u).astype(np.float32)))
+        nxt.append(terms)
+    cost = [Term((j,), f(1.5 + j) * knots[j] ** 2) for j in range(D)]
+    for c in range(3):
+        u = np.linspace(u_lo, u_hi, m[c]) if m[c] > 1 else np.array([0.5 * (u_lo + u_hi)])
+        cost.append(Term((D + c,), (f(0.3 + 0.1 * c) * u ** 2).astype(np.float32)))
+    cost = [cost[i] for i in cost_order(len(cost))]
+    return ProblemSpec(knots, list(m), nxt, cost, dtype=np.float32, index_base=1)
+
+
+K3_TRIPS = [
+    # n, m (o0, o1, inner), gain per control, control range, cost order
+    ((9, 8, 7), (3, 4, 6), (0.05, 0.05, 0.10), (-1.0, 1.0), "std"),        # even sweep, change inside
+    ((9, 8, 7), (3, 5, 7), (0.05, 0.05, 0.10), (-1.0, 1.0), "std"),        # odd sweep, odd step count (a single step at the end)
+    ((9, 8, 7), (2, 2, 5), (0.05, 0.05, 0.02), (0.2, 1.0), "std"),         # no cell change in the sweep
+    ((9, 8, 7), (4, 6, 5), (0.05, 0.05, 0.30), (-1.0, 1.0), "std"),        # change on the last control of an odd sweep / other parities by state
+    ((9, 8, 7), (3, 4, 8), (0.05, 0.05, 0.90), (-1.0, 1.0), "std"),        # several changes per sweep: the one-step path
+    ((9, 8, 7), (3, 4, 1), (0.05, 0.05, 0.10), (-1.0, 1.0), "std"),        # one inner control
+    ((9, 8, 7), (3, 1, 5), (0.05, 0.05, 0.10), (-1.0, 1.0), "std"),        # one level-1 step: no trip at all
+    ((9, 8, 7), (3, 6, 5), (0.05, 0.40, 0.10), (-1.0, 1.0), "std"),        # level-1 axis moves two cells: rows re-selected, window left
+    ((9, 8, 7), (3, 6, 5), (0.05, 0.05, 0.10), (-1.0, 1.0), "l1_first"),   # the level-1 cost term leads the sum
+    ((9, 8, 7), (3, 6, 4), (0.05, 0.05, 0.10), (-1.0, 1.0), "l0_first"),   # the level-0 cost term leads the sum
+    ((9, 8, 7), (3, 6, 5), (0.05, 0.05, 0.10), (-1.0, 1.0), "inner_first"),
+    ((5, 6, 7, 6), (3, 4, 5), (0.05, 0.05, 0.10), (-1.0, 1.0), "std"),     # D = 4: the window mode
+    ((5, 6, 7, 6), (2, 5, 6), (0.30, 0.40, 0.30), (-1.0, 1.0), "l1_first"),
+    ((3, 4, 5, 6, 5), (3, 3, 4), (0.05, 0.10, 0.20), (-0.5, 1.0), "std"),  # D = 5
+    ((70, 6, 5), (3, 5, 7), (0.05, 0.05, 0.10), (-1.0, 1.0), "std"),       # waves inside one axis-0 row: the wave-uniform trip
+    ((70, 6, 5), (3, 6, 6), (0.05, 0.05, 0.10), (-1.0, 0.6), "l1_first"),
+    ((66, 5, 4, 5), (3, 5, 5), (0.05, 0.05, 0.10), (-1.0, 1.0), "std"),
+    ((66, 5, 4, 5), (3, 4, 6), (0.05, 0.05, 0.12), (-0.7, 1.0), "inner_first"),
+]
+
+
+@pytest.mark.parametrize("n,m,gain,urange,order", K3_TRIPS)
+def test_packed2_trip_shapes_bit_exact(env, n, m, gain, urange, order):
+    """Variant 4's two-step trip (kernels_packed2.h): sweeps of odd and even length, the wave-wide cell change on either
+    control of a pair / on the last control / absent / repeated, kept lerp rows re-selected, a control cost term first in
+    the canonical sum - labels and values against the oracle, every stage."""
+    hjbdp, _abi, c_oracle = env
+    from problems import random_terminal
+    D = len(n)
+    orders = {                                   # which cost terms, in the canonical order (state terms, then one per control)
+        "std": lambda k: list(range(k)),
+        "l0_first": lambda k: [D, D + 1, D + 2],     # no state terms: the level-0 control term leads the sum
+        "l1_first": lambda k: [D + 1, D + 2],        # ... the level-1 term leads it
+        "inner_first": lambda k: [0, D + 2],         # no level terms at all
+    }
+    spec = _chain_spec(n, m, gain, urange[0], urange[1], orders[order])
+    term = random_terminal(spec, 5)
+    ref = c_oracle.sweep(_abi, spec, 3, terminal=term, keep_J=True, keep_idx=True)
+    with hjbdp.Backup(spec, variant=4) as bk:
+        assert bk.info()["kernel_variant"] == 4
+        mode = bk.get_option("packed2_mode")
+        assert mode == (4 if D == 3 else 2), mode         # the hierarchical modes, not the plain one
+        out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
+    assert np.array_equal(out["J_stages"], ref["J_stages"]), (n, m, order, mode)
+    assert np.array_equal(out["idx_stages"], ref["idx_stages"]), (n, m, order, mode)
+
+
 def test_variant_1_refused_when_not_applicable(env):
     hjbdp, _abi, c_oracle = env
     spec = _kirk(hjbdp, "double", 5, 8, 9).build_spec()   # both axes depend on u
