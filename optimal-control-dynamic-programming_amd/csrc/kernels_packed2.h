@@ -162,7 +162,9 @@ __device__ __forceinline__ float contract_df(const TJ *__restrict__ Jn, int off,
 //      computed per state instead of read from nS-sized tables) and 64-bit state indexing: C3, 51^6 states.
 // Same lerp order (axis 0 first ... last axis last) -> same bits in every mode.
 template <typename TJ, int D, int MODE>
-__global__ void __launch_bounds__(256)
+// The C2 modes are held to 96 VGPRs = five waves per SIMD (ten values spilled; 1.40 -> 1.35 ms per stage on C2; six waves
+// = 80 VGPRs spill 44 and run 1.7x slower); the window modes sit at three workgroups per CU by LDS whatever the registers.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 4 || MODE == 1) ? 5 : 1)))
 k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
                  TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
