@@ -270,7 +270,14 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     gptr<float> b_data = as_global<float>(N->in[0].data);
     const int b_stride = N->in[0].stride_in;
 
-    for (sidx_t blk = (sidx_t)blockIdx.x * 256; blk < n_owned; blk += (sidx_t)gridDim.x * 256) {
+    // Window modes: workgroups are handed to the eight XCDs round-robin, so neighbouring 256-state chunks would sit under
+    // eight different L2s although their windows overlap (the next roll / w1 / w2 row of a chunk is the current one of a
+    // chunk a few workgroups on).  Renumber: XCD x takes the x-th CONTIGUOUS eighth of every grid-sized span of chunks.
+    unsigned int first_chunk = blockIdx.x;
+    if constexpr (PRE) {
+        if ((gridDim.x & 7u) == 0u) first_chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    }
+    for (sidx_t blk = (sidx_t)first_chunk * 256; blk < n_owned; blk += (sidx_t)gridDim.x * 256) {
         sidx_t ls = blk + threadIdx.x;
         const bool valid = ls < n_owned;
         if (!valid) ls = n_owned - 1;         // harmless duplicate work, store skipped
