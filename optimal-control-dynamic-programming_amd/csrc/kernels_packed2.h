@@ -273,14 +273,34 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     gptr<float> b_data = as_global<float>(N->in[0].data);
     const int b_stride = N->in[0].stride_in;
 
-    // Window modes: workgroups are handed to the eight XCDs round-robin, so neighbouring 256-state chunks would sit under
-    // eight different L2s although their windows overlap (the next roll / w1 / w2 row of a chunk is the current one of a
-    // chunk a few workgroups on).  Renumber: XCD x takes the x-th CONTIGUOUS eighth of every grid-sized span of chunks.
-    unsigned int first_chunk = blockIdx.x;
+    // Window modes, the order in which the 256-state chunks are visited.  (1) Workgroups are handed to the eight XCDs
+    // round-robin, so neighbouring chunks would sit under eight different L2s: XCD x takes the x-th CONTIGUOUS eighth of every
+    // grid-sized span of the visiting order.  (2) In state order the chunks of one point of the level axes (all values of the
+    // state-only axes: `ac` chunks) come first, so the chunks whose windows overlap most - the neighbours along the level-0
+    // and level-1 axes - are ac, ac * n apart and never resident together.  The visiting order is the transpose: for one
+    // chunk of the state-only axes, all points of the other axes in turn (v -> chunk (v mod nw) * ac + v / nw over the
+    // ac x nw rectangle that covers the chunks; positions past the last chunk are skipped).
+    unsigned int first_v = blockIdx.x, n_v = 0, ac = 1, nw = 1;
+    const unsigned int n_chunks = (unsigned int)((n_owned + 255) / 256);
     if constexpr (PRE) {
-        if ((gridDim.x & 7u) == 0u) first_chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        if ((gridDim.x & 7u) == 0u) first_v = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        unsigned int inner = 1;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) inner *= (unsigned int)P->n[a];
+        ac = inner >= 256u ? inner / 256u : 1u;
+        nw = (n_chunks + ac - 1) / ac;
+        n_v = ac * nw;
+    } else {
+        n_v = n_chunks;
     }
-    for (sidx_t blk = (sidx_t)first_chunk * 256; blk < n_owned; blk += (sidx_t)gridDim.x * 256) {
+    for (unsigned int v = first_v; v < n_v; v += gridDim.x) {
+        unsigned int chunk = v;
+        if constexpr (PRE) {
+            const unsigned int va = v / nw;
+            chunk = (v - va * nw) * ac + va;
+            if (chunk >= n_chunks) continue;
+        }
+        const sidx_t blk = (sidx_t)chunk * 256;
         sidx_t ls = blk + threadIdx.x;
         const bool valid = ls < n_owned;
         if (!valid) ls = n_owned - 1;         // harmless duplicate work, store skipped
