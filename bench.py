@@ -340,6 +340,11 @@ def main():
               "traffic": traffic, "kernel": kname, "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(sp.D),
               "alg_bytes_per_launch": bytes_state * res["states_rank"], "valu_issue_util": valu_util, "pmc": pmc,
               "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "alg_bytes_per_state": bytes_state}}
+        if workload == "6d":
+            # this workload's next angles are TABULATED: one 8-byte (cell, weight) entry per state and angle axis, read once per
+            # stage beside J (the on-the-fly quaternion model of C3's kernel mode computes them instead) - part of `traffic`,
+            # not of the algorithmic bytes
+            rf["model_table_bytes_per_launch"] = 3 * 8 * res["states_rank"]
         if rf["frac"] > 1.0:
             # F_alg prices every backup at a full N-linear interpolation; this kernel contracts the axes the innermost
             # controls do not move once per outer control step, so it executes a fraction of those flops: the credit is
