@@ -228,7 +228,9 @@ int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
  * of every reference solver; csrc/kernels_prep_mfma.h), 0: with the vector kernels.  Bit-identical tables either way;
  * get: "prep_mfma", "prep_mfma_tables", "prep_tables", "prep_ns" (device time of the last rebuild), "table_hash",
  * "packed2_mode" (variant 4's contraction mode, csrc/kernels_packed2.h: 0 plain, 1 / 4 the C2 shape with / without the axis-0
- * table, 2 / 3 the per-state window of the attitude shapes; -1 when variant 4 does not apply).
+ * table, 2 / 3 the per-state window of the attitude shapes with four last-axis planes, 5 / 6 with three - chosen when the inner
+ * control moves the last axis by less than its narrowest cell per step; -1 when variant 4 does not apply).  Settable:
+ * "window_planes" (3 or 4: switch a handle that qualifies between modes 5 / 6 and 2 / 3; same results, tests and timing).
  * read a knob back, plus what the column-sweep kernel (variant 7) settled on: "cs_dpp" (1: one load per corner row, the
  * upper axis-0 neighbour taken from the next lane), "cs_groups", "cs_group_axis", "cs_rows" (corner rows per step of the
  * mid-grid column), "cs_coop" (1: the cooperative form is in effect), "cs_coop_why" (why it does not apply: 0 applies,

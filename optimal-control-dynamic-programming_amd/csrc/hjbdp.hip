@@ -91,6 +91,7 @@ struct Handle {
     bool row_lean_ok = false;     // variant 6: the lean form applies (kernels_rowwise.h)
     bool row_lean = true;         // option "row_lean"
     int packed_pre = 0;           // variant 4 contraction mode (kernels_packed2.h MODE): 0 plain, 1 C2 shape, 2 state-only axes first
+    bool window3_ok = false;      // modes 2 / 3 qualify for the three-plane window (modes 5 / 6); option "window_planes" switches
     size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
     bool tabled_ok = false;       // variant 5: per-axis (cell, t) tables for every axis (built on first use)
     uint32_t dom_mask[HJB_MAX_D] = {0};
@@ -655,7 +656,34 @@ int build(Handle *h, const hjb_problem *p) {
                 for (int a = 0; a < D - 3; ++a) pre = pre && N.at[a].level < 0;
                 if (pre && h->packed2_lds + 36 * 256 * 4 <= 64 * 1024) {
                     h->packed_pre = p->model ? 3 : 2;
-                    h->packed2_lds += 36 * 256 * 4;   // the per-state window
+                    // Three window planes instead of four (kernels_packed2.h W3P, D == 6): when the inner control moves the
+                    // last axis by less than its narrowest cell per control step, the second cell a sweep enters is a
+                    // neighbour of the first.  27 entries and no padding row in the weights: 40 KB per workgroup with 11
+                    // torque levels = four workgroups per CU instead of three.  (The kernel still checks every state.)
+                    bool near = D == 6 && N.n_ax_in == 1 && p->table_dtype == HJB_TAB_DEFAULT;
+                    if (near) {
+                        // the last axis' one inner term: (state dims of its mask) x the inner control, control slowest
+                        const hjb_term &bt = p->next_terms[D - 1][N.ax_kin];
+                        int64_t per_ctrl = 1;
+                        for (int d = 0; d < D; ++d)
+                            if (bt.mask & (1u << d)) per_ctrl *= p->n[d];
+                        const T *bj = (const T *)bt.data;
+                        double step = 0.0, width = 1e300;
+                        for (int j = 1; j < N.m_in; ++j)
+                            for (int64_t e = 0; e < per_ctrl; ++e)
+                                step = std::max(step, std::fabs((double)bj[e + j * per_ctrl] - (double)bj[e + (j - 1) * per_ctrl]));
+                        for (int i = 1; i < p->n[D - 1]; ++i)
+                            width = std::min(width, (double)(T)p->knots[D - 1][i] - (double)(T)p->knots[D - 1][i - 1]);
+                        near = step < 0.99 * width;
+                    }
+                    h->window3_ok = near;
+                    if (near) {
+                        h->packed_pre += 3;                                        // modes 5 / 6
+                        h->packed2_lds += 27 * 256 * 4;
+                        h->packed2_lds -= 256 * 8;                                 // no padding row in the weights
+                    } else {
+                        h->packed2_lds += 36 * 256 * 4;   // the per-state window
+                    }
                 }
             }
         }
@@ -695,7 +723,7 @@ int build(Handle *h, const hjb_problem *p) {
         h->row_auto = rw && lane_use >= 0.7 && h->n_owned >= ((int64_t)1 << 20);
     }
     if (p->model) {
-        if (!(h->packed_mode && h->packed_pre == 3))
+        if (!(h->packed_mode && (h->packed_pre == 3 || h->packed_pre == 6)))
             return fail(h, HJB_E_UNSUPPORTED,
                         "HJB_MODEL_QUAT_EULER321 needs the canonical attitude structure: axis 3 driven by control dim 0, "
                         "axis 4 by control dim 1, axis 5 by control dim 2 (kernels_packed2.h mode 3)");
@@ -1896,6 +1924,15 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     }
     if (!strcmp(key, "axis0_table")) {      // 1: build the axis-0 (cell, t) table a mode-1 problem runs without (A/B timing, tests)
         if (value) { const int ast = ensure_axis0_table(h); if (ast) return ast; }
+        return HJB_OK;
+    }
+    if (!strcmp(key, "window_planes")) {    // 4 / 3: variant 4's window modes with four planes (modes 2 / 3) or three (5 / 6)
+        const bool three = h->packed_pre == 5 || h->packed_pre == 6, four = h->packed_pre == 2 || h->packed_pre == 3;
+        if (!(three || four) || (value != 3 && value != 4)) return fail(h, HJB_E_UNSUPPORTED, "window_planes: 3 or 4, window modes only");
+        if (value == 3 && !h->window3_ok) return fail(h, HJB_E_UNSUPPORTED, "window_planes 3: the inner control can skip a cell");
+        if (value == 4 && three) { h->packed_pre -= 3; h->packed2_lds += 9 * 256 * 4 + 256 * 8; }
+        if (value == 3 && four) { h->packed_pre += 3; h->packed2_lds -= 9 * 256 * 4 + 256 * 8; }
+        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the captured launches are the other form
         return HJB_OK;
     }
     if (!strcmp(key, "monitor_single")) {   // hjb_solve_opts.monitor_single for callers of the flat API (hjb_solve_flat)

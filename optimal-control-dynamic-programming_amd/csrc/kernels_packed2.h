@@ -175,7 +175,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     constexpr bool M1 = MODE == 1 || MODE == 4;
     constexpr bool HIER = MODE != 0;
     constexpr int AX_A = D >= 3 ? D - 3 : 0, AX_B = D >= 2 ? D - 2 : 0;   // the level-0 / level-1 axes of modes 1, 2
-    constexpr bool PRE = MODE == 2 || MODE == 3, QMODEL = MODE == 3;
+    constexpr bool W3P = MODE == 5 || MODE == 6;            // modes 2 / 3 with the three-plane window (see kWin)
+    constexpr bool PRE = MODE == 2 || MODE == 3 || W3P, QMODEL = MODE == 3 || MODE == 6;
     constexpr int NP = PRE ? D - 3 : 0;
     using sidx_t = typename std::conditional<QMODEL, int64_t, int>::type;   // linear state index
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -186,10 +187,15 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     // LDS: {t_2p, t_2p+1} per lane [npairs+1][256] float2 | {r_2p, r_2p+1} [npairs+1] | b[m_in] |
     //      knots, rdx of the last axis | control-only cost tables
     // mode 2 only: the per-state window W[(ra*3+rb)*4+q][lane] in front of everything else
-    constexpr int kWin = PRE ? 36 : 0;
+    // W3P: the host has checked that the inner control moves the last axis by less than one cell per step, so the second cell
+    // a sweep enters is a neighbour of the first and the window needs 3 last-axis planes, not 4: 27 entries - with no padding
+    // row in the weights 40 KB of LDS per workgroup on the 11-torque attitude grids, i.e. FOUR workgroups per CU instead of three
+    constexpr int kWin = PRE ? (W3P ? 27 : 36) : 0;
+    constexpr int kWq = W3P ? 3 : 4;                        // window planes
     float *my_w = reinterpret_cast<float *>(smem_raw) + threadIdx.x;
     f2 *s_t = reinterpret_cast<f2 *>(smem_raw + (size_t)kWin * 256 * sizeof(float));
-    f2 *s_r2 = s_t + (size_t)(npairs + 1) * 256;
+    const int t_rows = W3P ? npairs : npairs + 1;           // W3P: no padding row (the read-ahead is clamped instead)
+    f2 *s_r2 = s_t + (size_t)t_rows * 256;
     float *s_b = reinterpret_cast<float *>(s_r2 + (npairs + 1));
     float *s_k = s_b + m_in;
     float *s_r = s_k + nl;
@@ -209,7 +215,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             if (2 * p + 1 < m_in) x.y = static_cast<const float *>(tr.data)[(2 * p + 1) * tr.stride_in];
             s_r2[p] = x;
         }
-        s_t[(size_t)npairs * 256 + threadIdx.x] = (f2){0.f, 0.f};
+        if constexpr (!W3P) s_t[(size_t)npairs * 256 + threadIdx.x] = (f2){0.f, 0.f};
     }
     constexpr int CL0 = HJB_MAX_D, CL1 = HJB_MAX_D + 1;
 #pragma unroll
@@ -232,6 +238,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     for (int a = 0; a < D; ++a) js[a] = (int)P->jstride[a];
     const int inner_sz = (int)P->inner;
     f2 *my_t = s_t + threadIdx.x;
+    // the weights row read ahead of pair p (beyond the last pair: the padding row, or - without one - the last row again)
+    auto t_ahead = [&](int p) __attribute__((always_inline)) -> int {
+        if constexpr (W3P) return p + 1 < npairs ? p + 1 : p;
+        else return p + 1;
+    };
     gptr<i2v> atab[DM];
     int a_c0[DM], a_c1[DM], a_lvl_rt[DM];
 #pragma unroll
@@ -422,6 +433,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         const int jc = U ? __builtin_ctz(U) : m_in;
         if (lc0 < 0 || lc0 + 1 >= nplanes) { *P->status = 1; lc0 = lc0 < 0 ? 0 : nplanes - 2; }
         if (lc1 < 0 || lc1 + 1 >= nplanes) { *P->status = 1; lc1 = lc1 < 0 ? 0 : nplanes - 2; }
+        // W3P: window plane of each cell's lower corner; a state whose second cell is NOT a neighbour of the first (the host's
+        // check makes that impossible) is served by the synchronous gathers like any step outside the window
+        const int pl0 = lc0 < lc1 ? lc0 : lc1;
+        const int qa = lc0 - pl0, qb = lc1 - pl0;
+        const bool far_cells = W3P && (qa > 1 || qb > 1);
         // smallest cell over `cnt` table entries `step` apart: four independent loads in flight per trip
         auto min_cell = [&](gptr<i2v> tb, int cnt, int step) {
             int cm = 0x7fffffff, o = 0;
@@ -456,7 +472,15 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             const int cb = cBmin;
             cAmin = ca;
             const int nA = P->axis[AX_A].n, nB = P->axis[AX_B].n;
-            const int planes[4] = {lc0, lc0 + 1, lc1, lc1 + 1};
+            // window planes: the two cells' four planes, or (W3P, neighbouring cells) the three planes from the lower cell up
+            int planes[kWq];
+            if constexpr (W3P) {
+                planes[0] = pl0;
+                planes[1] = pl0 + 1;
+                planes[2] = pl0 + 2 < nplanes ? pl0 + 2 : nplanes - 1;      // not read from when the sweep stays in one cell
+            } else {
+                planes[0] = lc0; planes[1] = lc0 + 1; planes[2] = lc1; planes[3] = lc1 + 1;
+            }
             int pbase = 0;
 #pragma unroll
             for (int a = 0; a < NP; ++a) pbase += js[a] * cell[a];
@@ -467,13 +491,13 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 for (int rb = 0; rb < 3; ++rb) {
                     const int rowB = cb + rb < nB ? cb + rb : nB - 1;
                     const int off = pbase + js[AX_A] * rowA + js[AX_B] * rowB;      // < one plane: fits 32 bits
-                    // the four planes' corners first (4 x 2^NP gathers in flight), then their lerps: one wait per (ra, rb)
+                    // the planes' corners first (4 x 2^NP gathers in flight), then their lerps: one wait per (ra, rb)
                     // instead of one per window entry (24^6: 36 -> 9 round trips to L2 / HBM per state)
-                    float v[4][1 << NP];
+                    float v[kWq][1 << NP];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) gather_corners<TJ, NP>(Jn + (int64_t)js[D - 1] * planes[q], off, js, v[q]);
+                    for (int q = 0; q < kWq; ++q) gather_corners<TJ, NP>(Jn + (int64_t)js[D - 1] * planes[q], off, js, v[q]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) my_w[((ra * 3 + rb) * 4 + q) * 256] = contract_corners<NP>(v[q], tw);
+                    for (int q = 0; q < kWq; ++q) my_w[((ra * 3 + rb) * kWq + q) * 256] = contract_corners<NP>(v[q], tw);
                 }
             }
         }
@@ -565,15 +589,17 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             if constexpr (PRE) {
                 c1min = cBmin;
                 const int r = cell[AX_A] - cAmin;
-                slow_a = !(r == 0 || r == 1);
-                const float *w0 = my_w + (r == 1 ? 12 * 256 : 0);          // rows {r, r+1} of the window
+                slow_a = !(r == 0 || r == 1) || far_cells;
+                const float *w0 = my_w + (r == 1 ? 3 * kWq * 256 : 0);     // rows {r, r+1} of the window
                 const float ta = tw[AX_A];
 #pragma unroll
                 for (int rb = 0; rb < 3; ++rb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float f0 = w0[(rb * 4 + q) * 256];
-                        const float f1 = w0[(12 + rb * 4 + q) * 256];
+                        // window plane of F's plane q = {cell 0 lower, upper, cell 1 lower, upper}
+                        const int wq = W3P ? (q < 2 ? qa : qb) + (q & 1) : q;
+                        const float f0 = w0[(rb * kWq + wq) * 256];
+                        const float f1 = w0[(3 * kWq + rb * kWq + wq) * 256];
                         F[rb][q] = __builtin_fmaf(ta, f1 - f0, f0);
                     }
             } else if constexpr (M1) {
@@ -681,7 +707,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                                                 __attribute__((always_inline)) {
                             const f2 totx = (g2 + (f2){r2.x, r2.x}) + __builtin_elementwise_fma((f2){t.x, t.x}, Dx, Ex);
                             const f2 toty = (g2 + (f2){r2.y, r2.y}) + __builtin_elementwise_fma((f2){t.y, t.y}, Dy, Ey);
-                            t = lds_f2(my_t + (p + 1) * 256);                    // next pair (row npairs is padding)
+                            t = lds_f2(my_t + t_ahead(p) * 256);                 // next pair
                             r2 = lds_f2(s_r2 + p + 1);
                             mA = __builtin_fminf(mA, __builtin_fminf(totx.x, toty.x));      // v_min3_f32
                             mB = __builtin_fminf(mB, __builtin_fminf(totx.y, toty.y));
@@ -797,7 +823,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll 2
                     for (; p < pstop; ++p) {
                         const f2 tot = (go2 + r2) + __builtin_elementwise_fma(t, dev, e0v);
-                        t = lds_f2(my_t + (p + 1) * 256);            // next pair's rows (row npairs is padding)
+                        t = lds_f2(my_t + t_ahead(p) * 256);         // next pair's rows
                         r2 = lds_f2(s_r2 + p + 1);
                         ibest = __builtin_fminf(ibest, __builtin_fminf(tot.x, tot.y));            // v_min3_f32
                     }
@@ -818,7 +844,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         const f2 tot = (go2 + r2) + __builtin_elementwise_fma(t, (f2){de, dey}, (f2){e0, e0y});
                         e0 = e0y;
                         de = dey;
-                        t = my_t[(p + 1) * 256];
+                        t = my_t[t_ahead(p) * 256];
                         r2 = s_r2[p + 1];
                         ibest = __builtin_fminf(ibest, __builtin_fminf(tot.x, tot.y));
                         ++p;
@@ -870,16 +896,16 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             auto step_cell = [&](int lc, float &xe0, float &xde) {
                 if constexpr (PRE) {
                     const int ra = cell[AX_A] - cAmin, rb = cell[AX_B] - cBmin;
-                    if ((ra == 0 || ra == 1) && (rb == 0 || rb == 1) && (lc == lc0 || lc == lc1)) {
-                        const int q0 = lc == lc0 ? 0 : 2;
+                    if ((ra == 0 || ra == 1) && (rb == 0 || rb == 1) && (lc == lc0 || lc == lc1) && !far_cells) {
+                        const int q0 = W3P ? lc - pl0 : (lc == lc0 ? 0 : 2);
                         float X[2];
 #pragma unroll
                         for (int dq = 0; dq < 2; ++dq) {
                             float Fr[2];
 #pragma unroll
                             for (int db = 0; db < 2; ++db) {
-                                const float w0 = my_w[((ra * 3 + rb + db) * 4 + q0 + dq) * 256];
-                                const float w1 = my_w[(((ra + 1) * 3 + rb + db) * 4 + q0 + dq) * 256];
+                                const float w0 = my_w[((ra * 3 + rb + db) * kWq + q0 + dq) * 256];
+                                const float w1 = my_w[(((ra + 1) * 3 + rb + db) * kWq + q0 + dq) * 256];
                                 Fr[db] = __builtin_fmaf(tw[AX_A], w1 - w0, w0);
                             }
                             X[dq] = __builtin_fmaf(tw[AX_B], Fr[1] - Fr[0], Fr[0]);

@@ -623,6 +623,31 @@ def test_packed2_trip_shapes_bit_exact(env, n, m, gain, urange, order):
     assert np.array_equal(out["idx_stages"], ref["idx_stages"]), (n, m, order, mode)
 
 
+@pytest.mark.parametrize("gain,near", [((0.05, 0.10, 0.12), True), ((0.30, 0.40, 0.90), False)])
+def test_packed2_window_planes(env, gain, near):
+    """D = 6: when the inner control moves the last axis by less than a cell per step the per-state window holds three
+    last-axis planes (modes 5 / 6: four workgroups per CU on the attitude grids), else four; option window_planes switches a
+    qualifying handle between the two forms - the same bits either way."""
+    hjbdp, _abi, c_oracle = env
+    from problems import random_terminal
+    spec = _chain_spec((20, 3, 4, 5, 4, 6), (3, 5, 5), gain, -1.0, 1.0, lambda k: list(range(k)))
+    term = random_terminal(spec, 9)
+    ref = c_oracle.sweep(_abi, spec, 2, terminal=term, keep_J=True, keep_idx=True)
+    with hjbdp.Backup(spec, variant=4) as bk:
+        assert bk.get_option("packed2_mode") == (5 if near else 2)
+        forms = (3, 4, 3) if near else (4,)
+        for planes in forms:
+            bk.set_option("window_planes", planes)
+            assert bk.get_option("packed2_mode") == (5 if planes == 3 else 2)
+            out = bk.solve(2, terminal=term, keep_J=True, keep_idx=True)
+            assert np.array_equal(out["J_stages"], ref["J_stages"]), planes
+            assert np.array_equal(out["idx_stages"], ref["idx_stages"]), planes
+        if not near:
+            with pytest.raises(hjbdp.HjbError) as ei:
+                bk.set_option("window_planes", 3)
+            assert ei.value.status == _abi.HJB_E_UNSUPPORTED
+
+
 def test_variant_1_refused_when_not_applicable(env):
     hjbdp, _abi, c_oracle = env
     spec = _kirk(hjbdp, "double", 5, 8, 9).build_spec()   # both axes depend on u

@@ -1,6 +1,7 @@
 """Time the 6-D attitude model (Solver_attitude.run semantics) on an n^6 grid x nu^3 torques.
 usage: python tools/time_6d.py [n=24] [nu=11] [stages=2] [variant=-1]     env MODEL=1: next angles computed in the kernel
-(HJB_MODEL_QUAT_EULER321, K3 mode 3 - what C3 runs) instead of tabulated as the reference does (mode 2)"""
+(HJB_MODEL_QUAT_EULER321, K3 mode 3 - what C3 runs) instead of tabulated as the reference does (mode 2); env WINDOW=3|4: planes of
+the per-state window (option window_planes)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
@@ -22,8 +23,10 @@ print("host table build %.1f s" % (time.time() - t0), flush=True)
 with hjbdp.Backup(pspec) as bk:
     if variant >= 0:
         bk.set_option("variant", variant)
-    print(bk.info(), flush=True)
+    if os.environ.get("WINDOW"):
+        bk.set_option("window_planes", int(os.environ["WINDOW"]))
+    print(bk.info(), "packed2_mode", bk.get_option("packed2_mode"), flush=True)
     bk.solve(1)
     out = bk.solve(stages)
 b = pspec.nS * pspec.nU * stages
-print("n=%d nu=%d: %.2f ms/stage, %.3e backups/s" % (n, nu, out["sweep_ms"] / stages, b / (out["sweep_ms"] * 1e-3)))
+print("n=%d nu=%d: %.2f ms/stage, %.3e backups/s sum J %.9e" % (n, nu, out["sweep_ms"] / stages, b / (out["sweep_ms"] * 1e-3), float(out["J"].astype(np.float64).sum())))
