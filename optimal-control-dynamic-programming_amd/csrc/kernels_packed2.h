@@ -1,12 +1,13 @@
-// kernels_packed2.h - variant 4: like variant 2 (kernels_packed.h) but the two halves
-// of every packed fp32 instruction are two CONSECUTIVE CONTROLS (j, j+1) of ONE state
-// per lane instead of two states.  Same packed-instruction count per backup, but the
-// per-lane state is half as large (more waves per SIMD) and the grid has twice as many
-// waves (C2: 16,100 waves over 4,096 resident slots = 3.93 rounds instead of 2.62 -> 3),
-// which removes most of the tail loss.  An inner-dim size that is odd is padded with a
-// control whose cost is +inf (never selected).  A cell crossing at an odd control
-// changes only the upper half of (E0, dE); the halves are re-synchronised after the
-// pair.  Arithmetic per backup is the canonical order: bit-identical results.
+// kernels_packed2.h - variant 4: the throughput kernel of the canonical spacecraft shape, one state per lane, packed fp32.
+// Like variant 2 (kernels_packed.h) it runs the innermost control loop with no cell test, no search and no load on the vector
+// pipe, but its per-lane state is half as large (more waves per SIMD; C2: 16,100 waves instead of 8,050).
+//   * the sweep keeps MINIMA only (3 packed operations + one v_min3 per control pair and step); the first (o0, o1) step that
+//     attains the state's minimum is tracked per step, and that step's controls are re-evaluated once per state, in order, to
+//     find the first one that reproduces it - the label (first-minimum rule, bit for bit);
+//   * in the hierarchical modes two (o0, o1) steps run per trip with the two STEPS in the halves of every packed instruction;
+//     the one-step loop (anything irregular, the last step of an odd count) puts two consecutive CONTROLS there instead;
+//   * the window modes (MODE 2, 3, 5, 6) contract the state-only axes once per state into an LDS window.
+// Arithmetic per backup is the canonical order throughout: results are bit-identical to the oracle and to every other variant.
 #pragma once
 #include <type_traits>
 #include "hjbdp_dev.h"
@@ -648,10 +649,10 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 return b;
             };
             int o1 = 0;
-            // ---- modes 1-3, TWO (o0, o1) steps per trip ---------------------------------------------------
+            // ---- hierarchical modes, TWO (o0, o1) steps per trip --------------------------------------------
             // When every cell change of the wave is a wave-uniform first crossing (UX == 0: the C2 and attitude
             // shapes) and both steps stay inside the prepared window, steps o1 and o1+1 share one pass over the
-            // control pairs: one read of (t, r2), one set of loop/segment bookkeeping, two running minima.  Per
+            // controls: one read of (t, r2) per control pair, one set of loop bookkeeping, two running minima.  Per
             // element the arithmetic is unchanged, and step o1 is compared with `best` before step o1+1: same bits,
             // same first-minimum.  Anything else falls through to the one-step loop below.
             if constexpr (HIER) {
@@ -810,7 +811,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     }
                 };
                 // ---- inner loop over control PAIRS: packed, no loads, no cell tests on the vector pipe.
-                // Per pair: 3 packed math (E0, dE broadcast to both halves), v_min3, one compare/select.
+                // Per pair: 3 packed math (E0, dE broadcast to both halves) and one v_min3 (minima only: the label is found
+                // after the sweep).
                 // The pair loop is cut at the (wave-uniform, scalar) pairs where some lane changes cell, so
                 // that inside a segment (E0, dE) are loop-invariant registers.
                 f2 t = my_t[0];
