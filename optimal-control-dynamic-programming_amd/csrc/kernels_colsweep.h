@@ -553,16 +553,15 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         }
         best = __builtin_inff();                 // (inf, control 0): what an all-infinite column of totals yields as well
         best_u = 0;
-        // the arithmetic of a half runs at raised wave priority: a wave that has its rows gets the vector pipe ahead of waves
-        // still forming addresses, and returns to issuing gathers sooner (C4: 1.760 -> 1.741 ms per stage; raised priority
-        // around the gather issue instead: no change)
+        // from the moment its first half has landed until its last member is done a wave runs at raised priority: a wave that
+        // has its rows gets the vector pipe ahead of waves still forming addresses or parking results, and returns to issuing
+        // gathers sooner (C4, one box: 1.760 ms per stage without, 1.741 raised around each half's arithmetic only, 1.734
+        // like this; raised from the barrier on: 1.755; raised around the gather issue only: no change)
         await_groups(0, NGH, nH1);                                        // H0 landed; H1 may still be in flight
         __builtin_amdgcn_s_setprio(3);
         compute_groups(0, NGH);
-        __builtin_amdgcn_s_setprio(0);
         load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // H0 of the next step
         await_groups(NGH, NG, nH0);                                       // H1 landed; the next H0 in flight
-        __builtin_amdgcn_s_setprio(3);
         compute_groups(NGH, NG);
         __builtin_amdgcn_s_setprio(0);
         // ---- results: parked in LDS, written out every kCsFlush steps ------------------------------------
