@@ -155,3 +155,24 @@ def _check_gathers(name, lines):
                 assert not _mentions(ln, reg), "%s: v%d is named while its gather is in flight: %s" % (name, reg, ln.strip())
             else:
                 raise AssertionError("%s: no retiring wait found after the gather into v%d" % (name, reg))
+
+
+def test_packed2_occupancy_budgets():
+    """K3's occupancy rests on register counts the compiler could quietly exceed: the C2 modes are held to 96 VGPRs (five
+    waves per SIMD, `amdgpu_waves_per_eu`), the three-plane window modes of the 6-D grids must stay within 128 (the LDS they
+    save buys a fourth workgroup per CU only then)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        asm = "%s/p2.s" % d
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+                            "-I%s/include" % ROOT, "-o", asm,
+                            "%s/optimal-control-dynamic-programming_amd/csrc/stage_packed2_f32.hip" % ROOT],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        text = open(asm).read()
+    got = dict((m[0], (int(m[1]), int(m[2]))) for m in re.findall(
+        r"\.name:\s+_ZN3hjb16k_backup_packed2IfLi(\d+ELi\d+)E\S*\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text))
+    assert got["3ELi4"][0] <= 96 and got["3ELi1"][0] <= 96, got          # C2 modes: five waves per SIMD
+    assert got["3ELi4"][1] <= 12, got                                      # ... at the price of a few values in scratch
+    for key in ("6ELi5", "6ELi6"):                                          # three-plane window: four waves per SIMD, no spill
+        assert got[key][0] <= 128 and got[key][1] == 0, got
