@@ -169,7 +169,8 @@ def collect_pmc(argv_child, kernel_filters, timeout_s=420):
     if not Path(rocprof).exists():
         return None, "rocprofv3 not found"
     sets = [["FETCH_SIZE"], ["WRITE_SIZE"],
-            ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]]
+            ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+            ["SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"]]
     out, notes = {w: {} for w in kernel_filters}, []
     tmp = tempfile.mkdtemp(prefix="hjb_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
@@ -336,9 +337,17 @@ def main():
             if "SQ_INSTS_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
                 cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                                   # summed over the 8 XCDs
                 valu_util = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_WAVE_INSTR / (1024.0 * cyc)
+        valu_busy = wait_frac = None
+        if pmc and pmc.get("GRBM_GUI_ACTIVE"):
+            cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0
+            if "SQ_ACTIVE_INST_VALU" in pmc:          # rocprof's derived VALUBusy: 4 cycles per counted unit, over SIMDs x cycles
+                valu_busy = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
+            if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES"):
+                wait_frac = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
         rf = {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
               "traffic": traffic, "kernel": kname, "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(sp.D),
-              "alg_bytes_per_launch": bytes_state * res["states_rank"], "valu_issue_util": valu_util, "pmc": pmc,
+              "alg_bytes_per_launch": bytes_state * res["states_rank"], "valu_issue_util": valu_util,
+              "valu_busy": valu_busy, "waves_waiting_frac": wait_frac, "pmc": pmc,
               "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "alg_bytes_per_state": bytes_state}}
         if workload == "6d":
             # this workload's next angles are TABULATED: one 8-byte (cell, weight) entry per state and angle axis, read once per
@@ -363,7 +372,11 @@ def main():
     rf["note"] = ("fp32 VALU binds (SURVEY 8d), not HBM and not MFMA (interpolation is a gather; K = D <= 6); peak = fp32 vector "
                   "peak = f32-input MFMA peak.  achieved = ALGORITHMIC flops (F_alg(D) per backup) / launch time; the "
                   "kernel shares the control-independent lerps between the controls, so it executes fewer.  "
-                  "valu_issue_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8): the executed-instruction view")
+                  "valu_issue_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8): the executed-instruction view at "
+                  "the cheapest instruction class; valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 x cycles) = rocprof's VALUBusy (4 "
+                  "cycles per instruction: packed fp32, v_min3, v_cndmask, DPP measure 4.1 - 4.3 on this part, plain add / mul "
+                  "2.1 - 2.8, profiles/r03_valu_rate.json - the pipe's real occupancy lies between the two); "
+                  "waves_waiting_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
     out = {
         "metric": "bellman_backups_per_s", "value": value, "unit": "backups/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["wall"] * 1e3 / args.steps,
