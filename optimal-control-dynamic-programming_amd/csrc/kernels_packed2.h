@@ -657,6 +657,9 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             // same first-minimum.  Anything else falls through to the one-step loop below.
             if constexpr (HIER) {
                 if (UX == 0u && !slow_a) {
+                    // (the window modes only: at the C2 modes' 96-register budget the eight kept values cost nine spills to
+                    // scratch - 40 MB of write-back per C2 stage - and buy nothing measurable there)
+                    constexpr bool KEEP_ROWS = PRE;
                     int r_rows = -1;                                             // the r the kept rows were selected for
                     float R0[4], RD[4];
                     while (o1 + 1 < m_o1) {
@@ -676,7 +679,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         // 4 packed subtractions + 4 packed fmas.  Same f1 - f0, same fma: same bits.
                         const f2 t2 = {__int_as_float(eA.y), __int_as_float(eB.y)};
                         f2 X2[4];
-                        if (!__any(rA != r_rows || rB != r_rows)) {
+                        if (KEEP_ROWS && !__any(rA != r_rows || rB != r_rows)) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
                                 X2[q] = __builtin_elementwise_fma(t2, (f2){RD[q], RD[q]}, (f2){R0[q], R0[q]});
