@@ -656,11 +656,11 @@ int build(Handle *h, const hjb_problem *p) {
                 for (int a = 0; a < D - 3; ++a) pre = pre && N.at[a].level < 0;
                 if (pre && h->packed2_lds + 36 * 256 * 4 <= 64 * 1024) {
                     h->packed_pre = p->model ? 3 : 2;
-                    // Three window planes instead of four (kernels_packed2.h W3P, D == 6): when the inner control moves the
+                    // Three window planes instead of four (kernels_packed2.h W3P): when the inner control moves the
                     // last axis by less than its narrowest cell per control step, the second cell a sweep enters is a
                     // neighbour of the first.  27 entries and no padding row in the weights: 40 KB per workgroup with 11
                     // torque levels = four workgroups per CU instead of three.  (The kernel still checks every state.)
-                    bool near = D == 6 && N.n_ax_in == 1 && p->table_dtype == HJB_TAB_DEFAULT;
+                    bool near = N.n_ax_in == 1 && p->table_dtype == HJB_TAB_DEFAULT;
                     if (near) {
                         // the last axis' one inner term: (state dims of its mask) x the inner control, control slowest
                         const hjb_term &bt = p->next_terms[D - 1][N.ax_kin];

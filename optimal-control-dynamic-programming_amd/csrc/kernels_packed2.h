@@ -188,7 +188,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     // LDS: {t_2p, t_2p+1} per lane [npairs+1][256] float2 | {r_2p, r_2p+1} [npairs+1] | b[m_in] |
     //      knots, rdx of the last axis | control-only cost tables
     // mode 2 only: the per-state window W[(ra*3+rb)*4+q][lane] in front of everything else
-    // W3P: the host has checked that the inner control moves the last axis by less than one cell per step, so the second cell
+    // W3P (any D >= 4): the host has checked that the inner control moves the last axis by less than one cell per step, so the second cell
     // a sweep enters is a neighbour of the first and the window needs 3 last-axis planes, not 4: 27 entries - with no padding
     // row in the weights 40 KB of LDS per workgroup on the 11-torque attitude grids, i.e. FOUR workgroups per CU instead of three
     constexpr int kWin = PRE ? (W3P ? 27 : 36) : 0;

@@ -18,8 +18,8 @@ static int packed2_go(const StageArgs &a, int mode) {
             hipLaunchKernelGGL((k_backup_packed2<TJ, 3, 4>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
         else if (DD == 6 && mode == 3)                                                                               \
             hipLaunchKernelGGL((k_backup_packed2<TJ, 6, 3>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
-        else if (DD == 6 && mode == 5)                                                                               \
-            hipLaunchKernelGGL((k_backup_packed2<TJ, 6, 5>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
+        else if (DD >= 4 && mode == 5)                                                                               \
+            hipLaunchKernelGGL((k_backup_packed2<TJ, (DD >= 4 ? DD : 4), 5>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx); \
         else if (DD == 6 && mode == 6)                                                                               \
             hipLaunchKernelGGL((k_backup_packed2<TJ, 6, 6>), g, b, a.lds, a.st, a.dp, a.dn, Jn, Jo, a.idx);           \
         else if (DD >= 4 && mode == 2)                                                                               \
