@@ -95,9 +95,12 @@ while time.time() < t_end:
     if spec.nS * spec.nU * stages > 4e7:
         stages = 2
     ref = c_oracle.sweep(_abi, spec, stages, terminal=term, nthreads=16, **mon)
-    if not np.all(np.isfinite(ref["J"].astype(np.float64))):
+    jabs = np.abs(ref["J"].astype(np.float64))
+    if not np.all(np.isfinite(jabs)) or jabs.max() > (1e30 if spec.j_dtype.itemsize <= 4 else 1e290):
         continue      # random dynamics with strong extrapolation can blow J up to inf/NaN: outside the contract
-                      # (SURVEY 8a note 3: "NaNs ... none arise"; min/argmin of NaNs is not defined alike everywhere)
+                      # (SURVEY 8a note 3: "NaNs ... none arise"; min/argmin of NaNs is not defined alike everywhere).
+                      # A finite final J of magnitude 1e36 has passed through -inf / NaN states on the way (found by
+                      # seed 11: variant 3's cross-lane reduction and the sequential `tot < best` treat NaN totals differently)
     n_prob += 1
     for v in (None, 0, 1, 2, 3, 4, 5, 6, 7, "7 two loads", "7 coop"):
         try:
@@ -126,6 +129,25 @@ while time.time() < t_end:
         seen[(v, kv)] = seen.get((v, kv), 0) + 1
         n_runs += 1
         if not ok:
+            dj = np.flatnonzero(~((out["J"] == ref["J"]) | (np.isnan(out["J"].astype(np.float64)) & np.isnan(ref["J"].astype(np.float64)))))
+            di = np.flatnonzero(out["idx"] != ref["idx"])
+            print("  J differs at %d of %d states (first %s), idx at %d (first %s)" % (dj.size, spec.nS, dj[:6], di.size, di[:6]), flush=True)
+            if dj.size:
+                print("  J gpu", out["J"][dj[:4]], "oracle", ref["J"][dj[:4]], flush=True)
+            if di.size:
+                print("  idx gpu", out["idx"][di[:4]], "oracle", ref["idx"][di[:4]], "J there", out["J"][di[:4]], ref["J"][di[:4]], flush=True)
+            print("  stages_done", out.get("stages_done"), ref.get("stages_done"), "info", bk.info() if False else kv, flush=True)
+            try:
+                import pickle
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "stress_fail.pkl"), "wb") as fh:
+                    pickle.dump(dict(knots=[np.asarray(k) for k in spec.knots], m=list(spec.m),
+                                     next_terms=[[(t.dims, np.asarray(t.data)) for t in ts] for ts in spec.next_terms],
+                                     cost_terms=[(t.dims, np.asarray(t.data)) for t in spec.cost_terms], dtype=str(spec.dtype),
+                                     j_dtype=str(spec.j_dtype), idx_dtype=str(idx_dtype), tab64=tab64, term=term, stages=stages,
+                                     mon=mon, forced=v), fh)
+            except Exception as e:
+                print("  (dump failed: %s)" % e)
             print("MISMATCH", dict(D=D, C=C, n=n, m=m, dtype=str(np.dtype(dtype)), j=str(spec.j_dtype), nonuniform=nonuniform,
                                    spread=spread, seed=seed, kind=str(kind), stages=stages, forced=v, ran=kv, idx=str(idx_dtype), tab64=tab64, mon=mon), flush=True)
             sys.exit(1)
