@@ -68,7 +68,7 @@ k_backup_ctrlsplit(const DParams *__restrict__ P, const T *__restrict__ Jn, T *_
         }
         T best = (T)INFINITY;
         int best_u = 0x7fffffff;
-        bool have = false;
+        bool have = false, first_nan = false;
         for (int u = lane; u < nU; u += 64) {
             // visiting index (control dim 0 slowest) -> per-dim control indices
             int cj[HJB_MAX_C] = {0, 0, 0};
@@ -126,7 +126,11 @@ k_backup_ctrlsplit(const DParams *__restrict__ P, const T *__restrict__ Jn, T *_
                 g = (k == 0) ? x : (T)(g + x);
             }
             const T tot = (T)(g + v[0]);
-            if (!have || tot < best) {
+            // A NaN total (inf - inf in a runaway sweep) is never a candidate - except that of control 0, which the
+            // sequential rule `first || tot < best` of the reference loop takes as the result (checked after the reduction):
+            // a lane that HELD a NaN would answer every comparison of the butterfly with "no" and hide its whole subtree.
+            if (u == 0 && tot != tot) first_nan = true;
+            if (tot == tot && (!have || tot < best)) {
                 best = tot;
                 best_u = u;
                 have = true;
@@ -141,6 +145,12 @@ k_backup_ctrlsplit(const DParams *__restrict__ P, const T *__restrict__ Jn, T *_
                 best = ov;
                 best_u = ou;
             }
+        }
+        if (__any(first_nan)) {                   // control 0 (lane 0's first) was NaN: the sequential rule keeps it
+            best = (T)NAN;
+            best_u = 0;
+        } else if (best_u == 0x7fffffff) {        // every other total NaN, none kept: control 0's own (non-NaN) total won
+            best_u = 0;
         }
         if (lane == 0) {
             int64_t label;

@@ -3,8 +3,12 @@
 Bars: J and argmin BIT-EXACT against the C twin (oracle/hjb_oracle.c, same
 canonical arithmetic); <= 1e-6 relative (north_star's tolerance; observed ~1e-13)
 against the MATLAB fixture test/obj_1.mat for the float64 Kirk problem."""
+from pathlib import Path
+
 import numpy as np
 import pytest
+
+ROOT_GOLDEN = Path(__file__).resolve().parent / "golden"
 
 pytestmark = pytest.mark.gpu
 
@@ -1088,3 +1092,22 @@ def test_mfma_table_build_is_bit_identical(env, case):
             assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
             orc = c_oracle.sweep(_abi, spec, 3, terminal=term)
             assert np.array_equal(out["J"], orc["J"]) and np.array_equal(out["idx"], orc["idx"])
+
+
+def test_runaway_sweep_nan_totals_follow_the_sequential_rule(env):
+    """A case tools/stress_parity.py found (seed 11): a random 60x9x9x8 x 10 float32 problem whose cost-to-go runs away to
+    -2.7e38 over 70 stages; states pass through -inf, totals become NaN (inf - inf).  Outside the contract, but the
+    control-split kernel must not let a NaN held by one lane hide that lane's subtree of the reduction: like the
+    sequential rule `first || tot < best` it skips NaN candidates (and keeps a NaN only when control 0's total is one)."""
+    hjbdp, _abi, c_oracle = env
+    import pickle
+    from hjbdp import Term
+    with open(ROOT_GOLDEN / "runaway_60x9x9x8.pkl", "rb") as fh:
+        d = pickle.load(fh)
+    spec = hjbdp.ProblemSpec(d["knots"], d["m"], [[Term(dims, data) for dims, data in ts] for ts in d["next_terms"]],
+                             [Term(dims, data) for dims, data in d["cost_terms"]], dtype=np.float32, index_base=1, idx_dtype=np.uint16)
+    ref = c_oracle.sweep(_abi, spec, d["stages"], terminal=d["term"], nthreads=8)
+    for v in (0, 3, 5):
+        with hjbdp.Backup(spec, variant=v) as bk:
+            out = bk.solve(d["stages"], terminal=d["term"])
+        assert np.array_equal(out["J"], ref["J"], equal_nan=True) and np.array_equal(out["idx"], ref["idx"]), v
