@@ -1,4 +1,5 @@
 #!/bin/bash
+# Quick look at the pos-att stage kernel on the GPU box: both axis orders timed, then the column-sweep / multi-GPU parity tests.
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/quick; mkdir -p $O; rm -f $O/quick.log
 ORDER=0,2,3,1 timeout 300 python3 tools/time_posatt.py 120 50 7 2>&1 | tail -2 | sed "s/^/xtwv: /" | tee -a $O/quick.log

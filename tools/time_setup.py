@@ -1,3 +1,4 @@
+"""Host-side set-up time of a C4 handle (spec build, hjb_create with its tables and plans), for the INTEGRATION notes."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "optimal-control-dynamic-programming_amd"))
