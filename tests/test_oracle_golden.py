@@ -170,10 +170,11 @@ def test_avx2_twin_equals_scalar_twin(orc, golden, case):
             c_oracle.backup_stage(_abi, spec64, random_terminal(spec64, 3), impl="avx2")
 
 
-@pytest.mark.parametrize("n,m,nonuniform", [((9, 7, 6), (5,), True), ((6, 5, 4, 5), (3, 2), True), ((11, 8), (7,), False)])
+@pytest.mark.parametrize("n,m,nonuniform", [((9, 7, 6), (5,), True), ((6, 5, 4, 5), (3, 2), True), ((11, 8), (7,), False),
+                                            ((6, 5, 4), (3, 2, 4), False), ((3, 4, 3, 4, 3), (2, 3, 2), True), ((3, 3, 2, 3, 3, 4), (3, 2, 3), False)])
 def test_backup_oracle_against_scipy_interpolant(orc, n, m, nonuniform):
     """The backup itself against an independent implementation of griddedInterpolant's 'linear' semantics on what the
-    reference's golden vector does not cover (non-uniform knots, D = 3 and 4, two control dims): scipy's
+    reference's golden vector does not cover (non-uniform knots, D = 3 .. 6, two and three control dims): scipy's
     RegularGridInterpolator (multilinear, fill_value=None = linear extrapolation) evaluated at the oracle's own next
     states, plus numpy's first-minimum.  float64: 1e-11 relative on J; argmin equal wherever the minimum is not a
     near-tie."""
