@@ -178,7 +178,9 @@ typedef struct hjb_solve_opts {
                                 array F_gI.Values is (Solver_pos_att.m:274; dtype HJB_F32 / HJB_F16S, one device).
                                 MATLAB's own summation order is not documented; the order used here is the fixed
                                 tree stated in csrc/kernels_reduce.h, restated by the oracle.  The label sum stays
-                                exact (U_Optimal_id is a double array there).  0: float64 sums */
+                                exact (U_Optimal_id is a double array there).  The difference e = fsum50 - fsum50_prev
+                                and the test abs(e) < tol are then single-precision too (:276-282; MATLAB casts the
+                                double tol to single).  0: float64 sums, float64 difference and test */
 } hjb_solve_opts;
 
 typedef struct hjb_result {

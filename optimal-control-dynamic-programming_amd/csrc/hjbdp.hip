@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <climits>
 #include <cstring>
@@ -290,6 +291,35 @@ int ensure_axis0_table(Handle *h) {
     return HJB_OK;
 }
 
+// The halo (planes of the last axis a slab must see beyond the ones it owns) implied by the last axis' next-state terms:
+// host arithmetic only, conservative.  Shared by build() and by the partitioners (hjb_create_multi, hjb_rank_create),
+// which must not build a whole-grid handle just to learn two integers.
+template <typename T>
+void halo_from_terms(const hjb_problem *p, bool tab64, int *out_lo, int *out_hi) {
+    const int a = p->D - 1, n = p->n[a];
+    std::vector<double> lo(n, 0.0), hi(n, 0.0);
+    for (int k = 0; k < p->n_next_terms[a]; ++k) {
+        if (tab64) term_minmax_along<double>(p, p->next_terms[a][k], a, lo, hi);
+        else term_minmax_along<T>(p, p->next_terms[a][k], a, lo, hi);
+    }
+    std::vector<T> kk(n);
+    for (int i = 0; i < n; ++i) kk[i] = (T)p->knots[a][i];
+    auto cell_of = [&](double q) {
+        int c = (int)(std::upper_bound(kk.begin(), kk.end(), (T)q) - kk.begin()) - 1;
+        return std::min(std::max(c, 0), n - 2);
+    };
+    int need_lo = 0, need_hi = 0;
+    for (int i = 0; i < n; ++i) {
+        // small relative slack: the sum of per-term extrema is formed in double
+        double span = std::fabs(hi[i]) + std::fabs(lo[i]);
+        int clo = cell_of(lo[i] - 1e-6 * span), chi = cell_of(hi[i] + 1e-6 * span);
+        need_lo = std::max(need_lo, i - clo);
+        need_hi = std::max(need_hi, chi + 1 - i);
+    }
+    *out_lo = need_lo;
+    *out_hi = need_hi;
+}
+
 template <typename T>
 int build(Handle *h, const hjb_problem *p) {
     const int D = p->D, C = p->C;
@@ -384,30 +414,7 @@ int build(Handle *h, const hjb_problem *p) {
         }
     }
     // conservative halo implied by the tables of the last axis
-    {
-        const int a = D - 1, n = p->n[a];
-        std::vector<double> lo(n, 0.0), hi(n, 0.0);
-        for (int k = 0; k < p->n_next_terms[a]; ++k) {
-            if (h->tab64) term_minmax_along<double>(p, p->next_terms[a][k], a, lo, hi);
-            else term_minmax_along<T>(p, p->next_terms[a][k], a, lo, hi);
-        }
-        std::vector<T> kk(n);
-        for (int i = 0; i < n; ++i) kk[i] = (T)p->knots[a][i];
-        auto cell_of = [&](double q) {
-            int c = (int)(std::upper_bound(kk.begin(), kk.end(), (T)q) - kk.begin()) - 1;
-            return std::min(std::max(c, 0), n - 2);
-        };
-        int need_lo = 0, need_hi = 0;
-        for (int i = 0; i < n; ++i) {
-            // small relative slack: the sum of per-term extrema is formed in double
-            double span = std::fabs(hi[i]) + std::fabs(lo[i]);
-            int clo = cell_of(lo[i] - 1e-6 * span), chi = cell_of(hi[i] + 1e-6 * span);
-            need_lo = std::max(need_lo, i - clo);
-            need_hi = std::max(need_hi, chi + 1 - i);
-        }
-        h->halo_need_lo = need_lo;
-        h->halo_need_hi = need_hi;
-    }
+    halo_from_terms<T>(p, h->tab64, &h->halo_need_lo, &h->halo_need_hi);
     // ---- variant 1 (control-nested) eligibility --------------------------------
     {
         DNested &N = h->hn;
@@ -731,7 +738,8 @@ int build(Handle *h, const hjb_problem *p) {
         h->nested_fast = false;
     }
     if (h->tab64 && !h->tabled_ok)
-        return fail(h, HJB_E_UNSUPPORTED, "table_dtype HJB_TAB_F64 needs the per-axis (cell, weight) tables to fit (variants 5-7)");
+        return fail(h, HJB_E_UNSUPPORTED, "table_dtype HJB_TAB_F64 needs the per-axis (cell, weight) tables to fit (variants 5-7): this grid's tables do not - "
+                    "pass table_dtype = HJB_TAB_DEFAULT (Python mirrors: table_dtype=None) to run it on float32 queries");
     if (h->nested_ok) {
         void *dnn = nullptr;
         int st2 = dev_alloc(h, sizeof(DNested), &dnn);
@@ -759,7 +767,10 @@ int launch_prep_any(Handle *h, int D, int grid, int a, const int32_t *dsz, int64
     if constexpr (std::is_same<T, float>::value) {
         if (h->tab64) {
             void *tmp = nullptr;
-            if (hipMalloc(&tmp, (size_t)n * sizeof(TabEntry<double>)) != hipSuccess) return fail(h, HJB_E_NOMEM, "float64 table build: scratch of %lld entries", (long long)n);
+            // test hook: HJBDP_TEST_FAIL_TAB64_SCRATCH=1 makes this allocation fail (tests/test_gpu_types.py checks that
+            // hjb_create then fails instead of handing out a handle on float32 queries)
+            const char *tf = getenv("HJBDP_TEST_FAIL_TAB64_SCRATCH");
+            if ((tf && tf[0] == '1') || hipMalloc(&tmp, (size_t)n * sizeof(TabEntry<double>)) != hipSuccess) return fail(h, HJB_E_NOMEM, "float64 table build: scratch of %lld entries", (long long)n);
             launch_prep_t<double>(D, grid, h->dp64, a, dsz, n, (TabEntry<double> *)tmp);
             hipLaunchKernelGGL(k_tab_narrow, dim3(grid), dim3(256), 0, nullptr, (const TabEntry<double> *)tmp, tab, n);
             const hipError_t e1 = hipDeviceSynchronize();
@@ -1381,7 +1392,11 @@ void choose_launch(Handle *h) {
     if (h->tab64 && h->variant < 5) h->variant = 5;       // float64-built tables: the table-driven kernels only (tabled_ok holds)
     // build the variant 5/6 tables now (never inside a launch: launches may be under graph capture)
     h->launch_status = HJB_OK;
-    if ((h->variant == 5 || h->variant == 6) && (h->launch_status = ensure_tabled(h)) != HJB_OK) h->variant = 0;
+    if ((h->variant == 5 || h->variant == 6) && (h->launch_status = ensure_tabled(h)) != HJB_OK) {
+        // a float64-table handle never falls back to a kernel that evaluates the float32 copies of its terms:
+        // it keeps its variant and every launch reports the build's status (hjb_create fails on it)
+        if (!h->tab64) h->variant = 0;
+    }
     h->block = 256;
     h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
     const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass (variant 4: 256)
@@ -1432,6 +1447,9 @@ int launch_stage(Handle *h, const void *dJn, void *dJo, void *didx, hipStream_t 
     a.Jo = dJo;
     a.idx = didx;
     int miss = 0;
+    if (h->tab64 && (h->variant < 5 || h->launch_status != HJB_OK))
+        return fail(h, h->launch_status != HJB_OK ? h->launch_status : HJB_E_UNSUPPORTED,
+                    "table_dtype HJB_TAB_F64 is served by the table-driven kernels only (variant %d, table build status %d)", h->variant, h->launch_status);
     switch (h->variant) {
         case 7: {
             if (!h->dtb || !h->dcs) return fail(h, HJB_E_DEVICE, "variant 7 plan missing");
@@ -1660,9 +1678,10 @@ const char *hjb_last_error(hjb_handle hh) {
     return h ? h->err.c_str() : g_last_error.c_str();
 }
 
-int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
-    if (!p || !out) return fail(nullptr, HJB_E_INVALID, "null argument");
-    *out = nullptr;
+// Everything hjb_create checks or derives WITHOUT touching a device: argument validation, the label width, and (on
+// request) the halo the last axis' tables imply.  hjb_create_multi / hjb_rank_create partition on these numbers alone.
+static int analyse_problem(const hjb_problem *p, int *idx_bytes_out, int64_t *n_states_out, int *halo_lo, int *halo_hi) {
+    if (!p) return fail(nullptr, HJB_E_INVALID, "null argument");
     if (p->D < 1 || p->D > HJB_MAX_D) return fail(nullptr, HJB_E_UNSUPPORTED, "D=%d not in 1..%d", p->D, HJB_MAX_D);
     if (p->C < 1 || p->C > HJB_MAX_C) return fail(nullptr, HJB_E_UNSUPPORTED, "C=%d not in 1..%d", p->C, HJB_MAX_C);
     if (p->dtype != HJB_F32 && p->dtype != HJB_F64 && p->dtype != HJB_F16S) return fail(nullptr, HJB_E_UNSUPPORTED, "dtype %d", p->dtype);
@@ -1715,10 +1734,6 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
         if ((p->slab_end + p->halo_hi) - (p->slab_begin - p->halo_lo) < 2)
             return fail(nullptr, HJB_E_INVALID, "slab + halo must span at least 2 planes");
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return fail(nullptr, HJB_E_DEVICE, "no HIP device visible (libhjbdp has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(nullptr, HJB_E_INVALID, "device %d not in 0..%d", device, ndev - 1);
     int idx_bytes = 4;
     {
         const int64_t top = nU - 1 + p->index_base;                       // the largest label
@@ -1727,6 +1742,29 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
         if ((idx_bytes == 1 && top > 255) || (idx_bytes == 2 && top > 65535))
             return fail(nullptr, HJB_E_INVALID, "idx_dtype %d cannot hold the label %lld", p->idx_dtype, (long long)top);
     }
+    if (idx_bytes_out) *idx_bytes_out = idx_bytes;
+    if (n_states_out) *n_states_out = nS;
+    if (halo_lo && halo_hi) {
+        const bool tab64 = p->table_dtype == HJB_TAB_F64;
+        if (p->n_next_terms[p->D - 1] < 1) { *halo_lo = *halo_hi = 0; }
+        else if (p->dtype != HJB_F64) halo_from_terms<float>(p, tab64, halo_lo, halo_hi);
+        else halo_from_terms<double>(p, tab64, halo_lo, halo_hi);
+    }
+    return HJB_OK;
+}
+
+int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
+    if (!p || !out) return fail(nullptr, HJB_E_INVALID, "null argument");
+    *out = nullptr;
+    int idx_bytes = 4;
+    {
+        const int ast = analyse_problem(p, &idx_bytes, nullptr, nullptr, nullptr);
+        if (ast) return ast;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, HJB_E_DEVICE, "no HIP device visible (libhjbdp has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, HJB_E_INVALID, "device %d not in 0..%d", device, ndev - 1);
     Handle *h = new Handle();
     h->device = device;
     h->idx_bytes = idx_bytes;
@@ -1755,6 +1793,16 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
     }
     for (int k = 0; k < HJB_MAX_TERMS; ++k) h->prob.cost_terms[k].data = nullptr;
     choose_launch(h);
+    if (h->tab64 && (h->launch_status != HJB_OK || h->variant < 5)) {
+        // the caller asked for float64 queries: a handle that cannot serve them is not handed out
+        st = h->launch_status != HJB_OK ? h->launch_status : HJB_E_UNSUPPORTED;
+        if (h->err.empty()) (void)fail(h, st, "table_dtype HJB_TAB_F64: the (cell, t) tables could not be built; table_dtype = HJB_TAB_DEFAULT (Python: table_dtype=None) runs float32 queries");
+        g_last_error = h->err;
+        if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+        for (void *d : h->allocs) (void)hipFree(d);
+        delete h;
+        return st;
+    }
     *out = (hjb_handle)h;
     return HJB_OK;
 }
@@ -2210,7 +2258,10 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
             SOLVE_TRY(hipMemcpyAsync(sums, h->d_sums, sizeof sums, hipMemcpyDeviceToHost, stream));
             SOLVE_TRY(hipStreamSynchronize(stream));
             unsafe_lk.unlock();
-            e = sums[0] - fprev;
+            // Solver_pos_att.m:276-282: with a single fsum50, `e = fsum50 - fsum50_prev` is a single-precision subtraction
+            // and `abs(e) < tol` compares in single (MATLAB casts the double tol); otherwise everything is double
+            const bool msingle = (o->monitor_single != 0 || h->monitor_single) && h->dtype != HJB_F64;
+            e = msingle ? (double)((float)sums[0] - (float)fprev) : sums[0] - fprev;
             e2 = sums[1] - iprev;
             fprev = sums[0];
             iprev = sums[1];
@@ -2221,7 +2272,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
                 (void)hipEventElapsedTime(&ms, ev0, ev1);
                 o->progress(o->progress_user, stop, e, e2, ms * 1e-3);
             }
-            if (std::fabs(e) < o->monitor_tol) { early = 1; break; }
+            if (msingle ? (std::fabs((float)e) < (float)o->monitor_tol) : (std::fabs(e) < o->monitor_tol)) { early = 1; break; }
         }
     }
     SOLVE_TRY(hipEventRecord(ev1, stream));
@@ -2721,13 +2772,17 @@ int32_t hjb_create_multi(const hjb_problem *p, int32_t n_dev, const int32_t *dev
     if (p->D < 1 || p->D > HJB_MAX_D) return mfail(nullptr, HJB_E_UNSUPPORTED, "D=%d", p->D);
     const int nl = p->n[p->D - 1];
     if (n_dev > nl) return mfail(nullptr, HJB_E_INVALID, "more devices (%d) than planes of the last axis (%d)", n_dev, nl);
-    // the halo the tables imply: from a handle on the whole grid (host arithmetic on the last axis' terms)
-    hjb_handle probe = nullptr;
-    int st = hjb_create(p, devices[0], &probe);
-    if (st) return st;
+    // the halo the tables imply and the label width: host arithmetic on the last axis' terms - no whole-grid handle, no
+    // whole-grid tables (a problem whose slabs fit must not be refused because the whole grid would not)
     hjb_info pin{};
-    (void)hjb_get_info(probe, &pin);
-    (void)hjb_destroy(probe);
+    int st;
+    {
+        int ib = 4, hl = 0, hh = 0;
+        int64_t ns = 0;
+        st = analyse_problem(p, &ib, &ns, &hl, &hh);
+        if (st) return st;
+        pin.idx_bytes = ib; pin.n_states = ns; pin.halo_needed_lo = hl; pin.halo_needed_hi = hh;
+    }
     hjb_multi m = new hjb_multi_s();
     m->need_lo = pin.halo_needed_lo;
     m->need_hi = pin.halo_needed_hi;
@@ -3089,12 +3144,15 @@ int32_t hjb_rank_create(const hjb_problem *p, int32_t device, int32_t rank, int3
     if (p->D < 1 || p->D > HJB_MAX_D) return rfail(nullptr, HJB_E_UNSUPPORTED, "D=%d", p->D);
     const int nl = p->n[p->D - 1];
     if (world > nl) return rfail(nullptr, HJB_E_INVALID, "more ranks (%d) than planes of the last axis (%d)", world, nl);
-    hjb_handle probe = nullptr;                  // the halo the tables imply: host arithmetic on the last axis' terms
-    int st = hjb_create(p, device, &probe);
-    if (st) return st;
-    hjb_info pin{};
-    (void)hjb_get_info(probe, &pin);
-    (void)hjb_destroy(probe);
+    hjb_info pin{};                              // the halo the tables imply + the label width: host arithmetic only
+    int st;
+    {
+        int ib = 4, hl = 0, hh = 0;
+        int64_t ns = 0;
+        st = analyse_problem(p, &ib, &ns, &hl, &hh);
+        if (st) return st;
+        pin.idx_bytes = ib; pin.n_states = ns; pin.halo_needed_lo = hl; pin.halo_needed_hi = hh;
+    }
     hjb_rank r = new hjb_rank_s();
     r->device = device; r->rank = rank; r->world = world; r->nl = nl;
     r->need_lo = pin.halo_needed_lo; r->need_hi = pin.halo_needed_hi;

@@ -46,8 +46,21 @@ def lib(abi):
                                         C.c_void_p, C.c_void_p, C.c_int]
         l.orc_canon_eval.restype = None
         l.orc_canon_eval.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.orc_monitor_sums.restype = C.c_int
+        l.orc_monitor_sums.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]
         _lib = l
     return _lib
+
+
+def monitor_sums(abi, spec, J, idx, single=False):
+    """(sum of J, sum of labels) as orc_sweep's monitor forms them (single: the stated float32 tree) - for checking the
+    library's monitor on a J the GPU produced."""
+    l = lib(abi)
+    Jc = np.ascontiguousarray(np.asarray(J, dtype=spec.j_dtype).reshape(-1))
+    ic = np.ascontiguousarray(np.asarray(idx).reshape(-1), dtype=np.int32)
+    out = (C.c_double * 2)()
+    l.orc_monitor_sums(int(spec.to_c()[0].dtype), Jc.ctypes.data, ic.ctypes.data, Jc.size, 1 if single else 0, out)
+    return float(out[0]), float(out[1])
 
 
 def backup_states(abi, spec, jsep, states, nthreads=0):

@@ -545,6 +545,21 @@ static float single_sum(int dtype, const void *A, int64_t n) {
     return fin[0];
 }
 
+/* The monitor's two sums (Solver_pos_att.m:274-275) of a given J / label array, exactly as orc_sweep forms them:
+ * out[0] = sum(J) in float64 (single != 0 and a float32 / binary16 J: the stated float32 tree, widened), out[1] = the
+ * exact label sum.  For tests that check the library's monitor on a J the GPU produced (grids too big to sweep here). */
+int orc_monitor_sums(int dtype, const void *J, const int32_t *idx, int64_t n, int single, double *out2) {
+    double fs = 0, is = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        fs += dtype == HJB_F16S ? (double)h2f(((const uint16_t *)J)[i])
+                                : (dtype == HJB_F32 ? (double)((const float *)J)[i] : ((const double *)J)[i]);
+        if (idx) is += (double)idx[i];
+    }
+    if (single && dtype != HJB_F64) fs = (double)single_sum(dtype, J, n);
+    out2[0] = fs; out2[1] = is;
+    return 0;
+}
+
 /* whole-grid backward sweep with the same outputs as hjb_solve. */
 int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, int nthreads) {
     int st = validate(p);
@@ -574,11 +589,14 @@ int orc_sweep(const hjb_problem *p, const hjb_solve_opts *o, hjb_result *res, in
                                            : (p->dtype == HJB_F32 ? (double)((float *)A)[i] : ((double *)A)[i]);
                 is += (double)idx[i];
             }
-            if (o->monitor_single && p->dtype != HJB_F64) fs = (double)single_sum(p->dtype, A, nS);
-            e = fs - fprev; e2 = is - iprev;
+            const int msingle = o->monitor_single && p->dtype != HJB_F64;
+            if (msingle) fs = (double)single_sum(p->dtype, A, nS);
+            /* Solver_pos_att.m:276-282: single fsum50 => single subtraction, and abs(e) < tol compared in single */
+            e = msingle ? (double)((float)fs - (float)fprev) : fs - fprev;
+            e2 = is - iprev;
             fprev = fs; iprev = is;
             if (o->progress) o->progress(o->progress_user, k_s, e, e2, 0.0);
-            if (fabs(e) < o->monitor_tol) { early = 1; break; }
+            if (msingle ? (fabsf((float)e) < (float)o->monitor_tol) : (fabs(e) < o->monitor_tol)) { early = 1; break; }
         }
     }
     if (o->J_final) memcpy(o->J_final, A, nS * es);

@@ -369,8 +369,9 @@ def test_c4_c5_full_size_colsweep_plane_vs_oracle(env, j_storage):
     spec, _ = hjbdp.permute_state_axes(spec0, (0, 2, 1, 3))        # (x, theta, v, w): the w-last labelling, wide halo
     if j_storage is not None:
         spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=1,
-                                 j_storage=j_storage)
+                                 j_storage=j_storage, idx_dtype=spec.idx_dtype, table_dtype=spec.table_dtype)
     assert spec.nS == 120 ** 4 and spec.n == (120, 120, 120, 120)
+    assert spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8      # the mirror's (= the reference's) typing, both storages
     X, T, V = np.meshgrid(sx, st[0], sv, indexing="ij")
     inner = (np.sin(7 * X) + 3 * V ** 2 + np.cos(5 * T)).astype(np.float32).reshape(-1, order="F")
     term = (inner[:, None] * (1.0 + 10.0 * sw[None, :] ** 2).astype(np.float32)).astype(spec.j_dtype)   # [120^3, 120]

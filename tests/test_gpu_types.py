@@ -235,3 +235,21 @@ def test_device_buffer_helpers(env):
         term = random_terminal(spec, 1)
         dJ.upload(term)
         assert np.array_equal(dJ.download(np.float32), term)
+
+
+def test_tab64_table_build_failure_is_loud(env, monkeypatch):
+    """A float64-query handle whose (cell, t) table build fails (here: the float64 scratch allocation, forced by the
+    library's test hook) is NOT handed out on the float32 copies of its terms: hjb_create fails with the build's status
+    and a message that names the remedy.  (it used to fall back to the generic kernel silently.)"""
+    hjbdp, _abi, c_oracle = env
+    spec = _pos_att_spec(hjbdp, (30, 12, 10, 9), np.float64, idx_dtype="auto")
+    monkeypatch.setenv("HJBDP_TEST_FAIL_TAB64_SCRATCH", "1")
+    with pytest.raises(hjbdp.HjbError) as ei:
+        hjbdp.Backup(spec)
+    assert ei.value.status == _abi.HJB_E_NOMEM and "scratch" in str(ei.value)
+    # float32 queries are not affected by the hook, and without it the float64 build works
+    with hjbdp.Backup(_pos_att_spec(hjbdp, (30, 12, 10, 9), None, idx_dtype="auto")) as bk:
+        assert bk.info()["table_dtype"] == _abi.HJB_TAB_DEFAULT
+    monkeypatch.delenv("HJBDP_TEST_FAIL_TAB64_SCRATCH")
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["table_dtype"] == _abi.HJB_TAB_F64 and bk.info()["kernel_variant"] >= 5
