@@ -168,7 +168,7 @@ __device__ __forceinline__ float contract_df(const TJ *__restrict__ Jn, int off,
 template <typename TJ, int D, int MODE>
 // The C2 modes are held to 96 VGPRs = five waves per SIMD (ten values spilled; 1.40 -> 1.35 ms per stage on C2; six waves
 // = 80 VGPRs spill 44 and run 1.7x slower); the window modes sit at three workgroups per CU by LDS whatever the registers.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 4 || MODE == 1) ? 5 : 1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 4 || MODE == 1) ? 5 : ((MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1))))
 k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
                  TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
@@ -636,7 +636,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 return go0_l1 + cterm(CL1, o0, o1);
             };
             i2v e_nx2 = {0, 0};                   // ... and the entry after it: a two-step trip consumes two
-            if constexpr (HIER) {
+            if constexpr (HIER && !PRE) {         // (the window modes fetch per pass, and these only when they fall back)
                 e_nx = tb1[0];
                 if (m_o1 > 1) e_nx2 = tb1[tb1_step];
                 g_nx = level1_cost(0);
@@ -655,13 +655,142 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             // controls: one read of (t, r2) per control pair, one set of loop bookkeeping, two running minima.  Per
             // element the arithmetic is unchanged, and step o1 is compared with `best` before step o1+1: same bits,
             // same first-minimum.  Anything else falls through to the one-step loop below.
-            if constexpr (HIER) {
+            // ---- window modes: a PASS = up to six (o0, o1) steps swept together, the loop nest interchanged ------------------
+            // The two-steps-per-trip form below pays ~45 vector + ~60 scalar instructions of set-up per trip for 22 backups
+            // (24^6: 5.8k of the 10k vector instructions of a state, profiles/r03_k3_experiments.log).  Here the per-step
+            // values - (E0, dE) of both last-axis cells and the cost so far, as {step A, step B} register pairs for three step
+            // pairs - are formed once, and the CONTROLS run outside: a control pair reads its (t, r) once and serves all six
+            // steps (3 x (6 packed + 2 v_min3)), each step keeping its own running minimum.  Per element the arithmetic and
+            // its order are the trip's; a step's minimum meets `best` in step order afterwards: same bits, same first minimum.
+            // A padding step (odd counts) carries an infinite cost so far and never wins.  A pass whose steps leave the
+            // prepared 2-row window, or a wave whose cell changes are not one wave-uniform first crossing, takes the
+            // one-step loop below (which serves anything).
+            float RD0[PRE ? 4 : 1], RD1[PRE ? 4 : 1];                    // F[1] - F[0], F[2] - F[1]: what a step lerps along axis D-2
+            if constexpr (PRE) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    RD0[q] = F[1][q] - F[0][q];
+                    RD1[q] = F[2][q] - F[1][q];
+                }
                 if (UX == 0u && !slow_a) {
-                    // (the window modes only: at the C2 modes' 96-register budget the eight kept values cost nine spills to
-                    // scratch - 40 MB of write-back per C2 stage - and buy nothing measurable there)
-                    constexpr bool KEEP_ROWS = PRE;
-                    int r_rows = -1;                                             // the r the kept rows were selected for
-                    float R0[4], RD[4];
+                    constexpr int SP = 3;                                // packed step pairs per pass
+                    auto entry_at = [&](int o) __attribute__((always_inline)) -> i2v {
+                        return tb1[(o < m_o1 ? o : m_o1 - 1) * tb1_step];
+                    };
+                    i2v e[2 * SP];
+#pragma unroll
+                    for (int s = 0; s < 2 * SP; ++s) e[s] = entry_at(s);
+                    // control pairs wholly in the first cell / the pair the wave's one cell change splits / the rest
+                    const bool no_change = jc >= m_in;
+                    const int nfull = m_in >> 1;
+                    const int pa = no_change ? nfull : (jc >> 1);
+                    const bool straddle = !no_change && (jc & 1);
+                    while (o1 < m_o1) {
+                        f2 Ea[SP], Da[SP], Eb[SP], Db[SP], g2[SP];
+                        bool miss = false;
+#pragma unroll
+                        for (int sp = 0; sp < SP; ++sp) {
+                            const i2v eA = e[2 * sp], eB = e[2 * sp + 1];
+                            const int rA = eA.x - c1min, rB = eB.x - c1min;
+                            miss |= ((unsigned int)rA | (unsigned int)rB) > 1u;
+                            const f2 t2 = {__int_as_float(eA.y), __int_as_float(eB.y)};
+                            f2 X2[4];
+                            if (!__any((rA | rB) != 0)) {                // every lane lerps rows (0, 1) in both steps
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    X2[q] = __builtin_elementwise_fma(t2, (f2){RD0[q], RD0[q]}, (f2){F[0][q], F[0][q]});
+                            } else if (!__any((rA & rB) != 1)) {         // ... rows (1, 2)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    X2[q] = __builtin_elementwise_fma(t2, (f2){RD1[q], RD1[q]}, (f2){F[1][q], F[1][q]});
+                            } else {
+                                const bool upA = rA != 0, upB = rB != 0;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const f2 f0 = {upA ? F[1][q] : F[0][q], upB ? F[1][q] : F[0][q]};
+                                    const f2 d = {upA ? RD1[q] : RD0[q], upB ? RD1[q] : RD0[q]};
+                                    X2[q] = __builtin_elementwise_fma(t2, d, f0);
+                                }
+                            }
+                            Ea[sp] = X2[0]; Da[sp] = X2[1] - X2[0];
+                            Eb[sp] = X2[2]; Db[sp] = X2[3] - X2[2];
+                        }
+                        {                                                 // cost so far of each step; padding steps: infinite
+                            const int last = m_o1 - 1;
+                            float c[2 * SP];
+#pragma unroll
+                            for (int s = 0; s < 2 * SP; ++s) c[s] = cl1_present ? cterm(CL1, o0, o1 + s < last ? o1 + s : last) : 0.f;
+#pragma unroll
+                            for (int s = 0; s < 2 * SP; ++s) {
+                                const float g = cl1_present ? go0_l1 + c[s] : go0;
+                                const float gp = o1 + s < m_o1 ? g : INFINITY;
+                                if (s & 1) g2[s >> 1].y = gp; else g2[s >> 1].x = gp;
+                            }
+                        }
+                        if (__any(miss)) break;                           // outside the window: the one-step loop takes over at o1
+                        const int o1n = o1 + 2 * SP;
+                        if (o1n < m_o1) {                                 // the next pass' entries, in flight under this pass' sweep
+#pragma unroll
+                            for (int s = 0; s < 2 * SP; ++s) e[s] = entry_at(o1n + s);
+                        }
+                        f2 m2[SP];
+#pragma unroll
+                        for (int sp = 0; sp < SP; ++sp) m2[sp] = (f2){INFINITY, INFINITY};
+                        f2 t = my_t[0];
+                        f2 r2 = s_r2[0];
+                        // one control pair against all steps of the pass; BX / BY: the pair's first / second control lies in the
+                        // second last-axis cell
+                        auto control_pair = [&](int p, auto BX, auto BY) __attribute__((always_inline)) {
+                            const f2 tc = t, rc = r2;
+                            t = lds_f2(my_t + t_ahead(p) * 256);         // next pair
+                            r2 = lds_f2(s_r2 + p + 1);
+#pragma unroll
+                            for (int sp = 0; sp < SP; ++sp) {
+                                const f2 Ex = decltype(BX)::value ? Eb[sp] : Ea[sp], Dx = decltype(BX)::value ? Db[sp] : Da[sp];
+                                const f2 Ey = decltype(BY)::value ? Eb[sp] : Ea[sp], Dy = decltype(BY)::value ? Db[sp] : Da[sp];
+                                const f2 totx = (g2[sp] + (f2){rc.x, rc.x}) + __builtin_elementwise_fma((f2){tc.x, tc.x}, Dx, Ex);
+                                const f2 toty = (g2[sp] + (f2){rc.y, rc.y}) + __builtin_elementwise_fma((f2){tc.y, tc.y}, Dy, Ey);
+                                m2[sp].x = __builtin_fminf(m2[sp].x, __builtin_fminf(totx.x, toty.x));      // v_min3_f32
+                                m2[sp].y = __builtin_fminf(m2[sp].y, __builtin_fminf(totx.y, toty.y));
+                            }
+                        };
+                        int p = 0;
+                        for (; p < pa; ++p) control_pair(p, std::false_type{}, std::false_type{});
+                        if (straddle) {
+                            control_pair(p, std::false_type{}, std::true_type{});
+                            ++p;
+                        }
+                        for (; p < nfull; ++p) control_pair(p, std::true_type{}, std::true_type{});
+                        if (m_in & 1) {                                   // the last control of an odd sweep, alone
+#pragma unroll
+                            for (int sp = 0; sp < SP; ++sp) {
+                                const f2 El = no_change ? Ea[sp] : Eb[sp], Dl = no_change ? Da[sp] : Db[sp];
+                                const f2 totx = (g2[sp] + (f2){r2.x, r2.x}) + __builtin_elementwise_fma((f2){t.x, t.x}, Dl, El);
+                                m2[sp].x = __builtin_fminf(m2[sp].x, totx.x);
+                                m2[sp].y = __builtin_fminf(m2[sp].y, totx.y);
+                            }
+                        }
+#pragma unroll
+                        for (int sp = 0; sp < SP; ++sp) {                 // the steps meet `best` in step order
+                            if (o1 + 2 * sp < m_o1) {
+                                if (uo == 0 || m2[sp].x < best) { best = m2[sp].x; best_uo = uo; }
+                                ++uo;
+                            }
+                            if (o1 + 2 * sp + 1 < m_o1) {
+                                if (m2[sp].y < best) { best = m2[sp].y; best_uo = uo; }
+                                ++uo;
+                            }
+                        }
+                        o1 = o1n < m_o1 ? o1n : m_o1;
+                    }
+                }
+                if (o1 < m_o1) {                                          // fall back: what the one-step loop expects to find
+                    e_nx = tb1[o1 * tb1_step];
+                    g_nx = level1_cost(o1);
+                }
+            }
+            if constexpr (HIER && !PRE) {
+                if (UX == 0u && !slow_a) {
                     while (o1 + 1 < m_o1) {
                         const i2v eA = e_nx, eB = e_nx2;
                         const int rA = eA.x - c1min, rB = eB.x - c1min;
@@ -672,18 +801,10 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                             g_nx = level1_cost(o1 + 2);
                         }
                         if (o1 + 3 < m_o1) e_nx2 = tb1[(o1 + 3) * tb1_step];
-                        // (E0, dE) of the first / second last-axis cell, as {step A, step B} pairs.  The two prepared rows a step
-                        // lerps between, R0 = F[r] and RD = F[r+1] - F[r], are kept from trip to trip (r moves 0 -> 1 at most
-                        // once over an o1 sweep when the axis' next value grows with the control): while every lane's r of both
-                        // steps is the one the rows were selected for, the lerps are 4 packed fmas instead of 16 selects +
-                        // 4 packed subtractions + 4 packed fmas.  Same f1 - f0, same fma: same bits.
+                        // (E0, dE) of the first / second last-axis cell, as {step A, step B} pairs
                         const f2 t2 = {__int_as_float(eA.y), __int_as_float(eB.y)};
                         f2 X2[4];
-                        if (KEEP_ROWS && !__any(rA != r_rows || rB != r_rows)) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                X2[q] = __builtin_elementwise_fma(t2, (f2){RD[q], RD[q]}, (f2){R0[q], R0[q]});
-                        } else {
+                        {
                             const bool upA = rA != 0, upB = rB != 0;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -691,10 +812,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                                 const f2 f1 = {upA ? F[2][q] : F[1][q], upB ? F[2][q] : F[1][q]};
                                 const f2 d = f1 - f0;
                                 X2[q] = __builtin_elementwise_fma(t2, d, f0);
-                                R0[q] = f0.y;
-                                RD[q] = d.y;
                             }
-                            r_rows = rB;
                         }
                         // The two halves of every packed instruction are the two STEPS (A, B) of one control: the per-step
                         // quantities (cost so far, E0, dE) are register pairs as they come out of the lerps above, the
@@ -760,8 +878,12 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float f0 = up ? F[1][q] : F[0][q];
-                            const float f1 = up ? F[2][q] : F[1][q];
-                            X[q] = __builtin_fmaf(t1, f1 - f0, f0);
+                            if constexpr (PRE) {                         // the same f1 - f0, formed once per o0 step
+                                X[q] = __builtin_fmaf(t1, up ? RD1[q] : RD0[q], f0);
+                            } else {
+                                const float f1 = up ? F[2][q] : F[1][q];
+                                X[q] = __builtin_fmaf(t1, f1 - f0, f0);
+                            }
                         }
                         e0a = X[0]; dea = X[1] - X[0];
                         e0b = X[2]; deb = X[3] - X[2];

@@ -67,14 +67,14 @@ def test_c2_100_stages_deep(env):
     assert np.all(Js[:, :-1] >= Js[:, 1:] - 1e-5)               # J_k never decreases as the horizon grows
 
 
-def _c4_deep(env, workload):
+def _c4_deep(env, workload, N, period):
     hjbdp, _abi, c_oracle = env
     import bench
     spec, _ = bench.build_spec(workload)
     assert spec.n == (120,) * 4 and spec.nU == 9
     assert spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8           # the bench's exact typing
     assert spec.j_dtype == (np.float16 if workload == "c5" else np.float32)
-    N = 200
+    mid = N // 2 + 1
     sums = {}
 
     def oracle_sums(J, idx):
@@ -85,13 +85,14 @@ def _c4_deep(env, workload):
         assert inf["kernel_variant"] == 7 and inf["halo_needed_lo"] == 1 and inf["halo_needed_hi"] == 1
         # (1) the reference's sweep: 200 stages, monitor every 50 (Solver_pos_att.m:270-286), single-precision sum
         events = []
-        full = bk.solve(N, monitor_period=50, monitor_tol=1e-2, monitor_single=True,
+        full = bk.solve(N, monitor_period=period, monitor_tol=1e-2, monitor_single=True,
                         progress=lambda k_s, e, e2, sec: events.append((k_s, e, e2)))
         assert full["stages_done"] == N and not full["stopped_early"]
-        assert [ev[0] for ev in events] == [200, 150, 100, 50]
+        points = [(N - i * period, 1 + i * period) for i in range(4)]        # (k_s, stages computed when it is reached)
+        assert [ev[0] for ev in events] == [k for k, _ in points] and points[2][1] == mid
         # (2) stage pairs: the last two stages and a mid-sweep pair, from sweeps of their own (no monitor: one graph)
         last = full
-        for n_done, planes in ((N, (0, 63, 119)), (101, (17, 104))):
+        for n_done, planes in ((N, (0, 63, 119)), (mid, (17, 104))):
             cur = last if n_done == N else bk.solve(n_done)
             prev = bk.solve(n_done - 1)
             if n_done == N:
@@ -99,33 +100,33 @@ def _c4_deep(env, workload):
                 assert np.array_equal(plain["J"], cur["J"]) and np.array_equal(plain["idx"], cur["idx"])
                 del plain
             _plane_from_previous(c_oracle, _abi, spec, prev["J"], cur["J"], cur["idx"], planes, 1, 1)
-            if n_done == 101:
-                sums[101] = oracle_sums(cur["J"], cur["idx"])
+            if n_done == mid:
+                sums[mid] = oracle_sums(cur["J"], cur["idx"])
             del prev, cur
-        # (3) the monitor: its sums at k_s = 200, 150, 100, 50 are those of J after 1, 51, 101, 151 stages
-        for n_done in (1, 51, 151):
+        # (3) the monitor: its sums at the four monitor points are those of J after 1, 1 + period, ... stages
+        for n_done in (points[0][1], points[1][1], points[3][1]):
             o = bk.solve(n_done)
             sums[n_done] = oracle_sums(o["J"], o["idx"])
             del o
         f32 = np.float32
         fprev, iprev, expect = 0.0, 0.0, []
-        for k_s, n_done in ((200, 1), (150, 51), (100, 101), (50, 151)):
+        for k_s, n_done in points:
             fs, isum = sums[n_done]
             expect.append((k_s, float(f32(fs) - f32(fprev)), isum - iprev))           # single difference (:276)
             fprev, iprev = fs, isum
         assert events == expect, (events, expect)
         assert full["last_e"] == expect[-1][1] and full["last_e2"] == expect[-1][2]
-        # (4) the stop decision at the margin, compared in single (:279): a tolerance one float32 ulp above |e(100)|
-        # stops the sweep at the first monitor point whose |e| is below it; |e(100)| itself as the tolerance does not
-        # stop it there ('<')
-        e100 = abs(f32(expect[2][1]))
-        for tol in (float(np.nextafter(e100, f32(np.inf))), float(e100)):
+        # (4) the stop decision at the margin, compared in single (:279): a tolerance one float32 ulp above the third
+        # monitor point's |e| stops the sweep at the first monitor point whose |e| is below it; that |e| itself as the
+        # tolerance does not stop it there ('<')
+        e3 = abs(f32(expect[2][1]))
+        for tol in (float(np.nextafter(e3, f32(np.inf))), float(e3)):
             stop = next((k_s for k_s, e, _ in expect if abs(f32(e)) < f32(tol)), None)
-            o = bk.solve(N, monitor_period=50, monitor_tol=tol, monitor_single=True)
+            o = bk.solve(N, monitor_period=period, monitor_tol=tol, monitor_single=True)
             assert o["stopped_early"] == (stop is not None), tol
             assert o["stages_done"] == (N if stop is None else N - stop + 1), (tol, stop, o["stages_done"])
             del o
-    assert float(np.min(full["J"].astype(np.float32))) >= 0.0
+    return full
 
 
 @pytest.mark.order(3)
@@ -133,14 +134,22 @@ def _c4_deep(env, workload):
 def test_c4_200_stages_deep_bench_typing(env):
     """BASELINE configs[3] exactly as bench.py runs it (float64-built query tables, uint8 labels, axes (x, theta, w, v)),
     200 stages with the reference's monitor."""
-    _c4_deep(env, "c4")
+    full = _c4_deep(env, "c4", 200, 50)
+    assert float(np.min(full["J"])) >= 0.0 and np.all(np.isfinite(full["J"]))
 
 
 @pytest.mark.order(3)
 @pytest.mark.watchdog(900)
 def test_c5_200_stages_deep_bench_typing(env):
-    """BASELINE configs[4] (float16 cost-to-go storage) in the bench's typing, 200 stages with the monitor."""
-    _c4_deep(env, "c5")
+    """BASELINE configs[4] (float16 cost-to-go storage) in the bench's typing, 100 stages with the monitor every 25.
+    Not 200: with binary16 storage this problem's sweep is numerically unstable at the extrapolating corner of the grid -
+    rounding noise of relative size 2^-11 between neighbouring cells is amplified by the 7.6-cell extrapolation of w each
+    stage: min J turns negative after ~25 stages (-14.5 at 30, -535 at 60, -3.8e4 at 100) and passes binary16's range
+    (inf, then NaN) after ~110 (profiles/r04_c5_horizon.log; the float32 sweep stays in [0, 75] over 200 stages).
+    Non-finite sweeps are outside the parity contract; up to there the kernel equals the oracle's
+    binary16 sweep bit for bit, which is what this test pins."""
+    full = _c4_deep(env, "c5", 100, 25)
+    assert np.all(np.isfinite(full["J"].astype(np.float32)))
 
 
 @pytest.mark.order(4)
