@@ -383,6 +383,8 @@ const char *hjb_multi_last_error(hjb_multi m);
  * halo_needed_hi, bytes per label, planes of the last axis. */
 typedef struct hjb_rank_s *hjb_rank;
 int32_t hjb_rank_create(const hjb_problem *problem, int32_t device, int32_t rank, int32_t world, int32_t overlap, hjb_rank *out);
+/* the same from a flat builder (include/hjbdp_matlab.h: a MATLAB worker per GPU binds this one) */
+int32_t hjb_rank_create_from(hjb_builder b, int32_t device, int32_t rank, int32_t world, int32_t overlap, hjb_rank *out);
 int32_t hjb_rank_info(hjb_rank r, int32_t *out10);
 int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream);
 int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value);

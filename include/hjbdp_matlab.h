@@ -50,6 +50,21 @@ int32_t hjb_multi_set_option(void *multi, const char *key, int64_t value);
 const char *hjb_multi_last_error(void *multi);
 int32_t hjb_destroy_multi(void *multi);
 
+/* one process (MATLAB worker) per GPU: this rank's slab of the last state axis, one call per stage; the worker owns the
+ * device buffers (hjb_device_*) and moves the halo planes between stages (include/hjbdp.h "one process per GPU") */
+int32_t hjb_rank_create_from(void *builder, int32_t device, int32_t rank, int32_t world, int32_t overlap, void **rank_out);
+int32_t hjb_rank_info(void *rank, int32_t *out10);
+int32_t hjb_rank_stage(void *rank, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream);
+int32_t hjb_rank_set_option(void *rank, const char *key, int64_t value);
+int32_t hjb_rank_get_option(void *rank, const char *key, int64_t *value);
+int32_t hjb_rank_check_status(void *rank, void *stream);
+int32_t hjb_rank_destroy(void *rank);
+const char *hjb_rank_last_error(void *rank);
+/* device buffers for hosts without a HIP binding of their own */
+int32_t hjb_device_malloc(int32_t device, int64_t bytes, void **out);
+int32_t hjb_device_free(int32_t device, void *p);
+int32_t hjb_device_copy(int32_t device, void *dst, const void *src, int64_t bytes, int32_t kind);
+
 /* griddedInterpolant(..., 'nearest' | 'linear') lookups of the results (Solver_position.m:144-146, Dynamic_Solver.m:132-135) */
 int32_t hjb_policy_lookup(int32_t device, int32_t dtype, int32_t D, const int32_t *n, const double *const *knots,
                           const void *values, int64_t nq, const void *queries, int32_t method, void *out);

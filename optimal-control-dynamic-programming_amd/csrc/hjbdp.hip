@@ -3215,6 +3215,17 @@ int32_t hjb_rank_create(const hjb_problem *p, int32_t device, int32_t rank, int3
     return HJB_OK;
 }
 
+// hjb_rank_create for hosts that describe the problem with the flat builder (MATLAB's calllib: one worker per GPU)
+int32_t hjb_rank_create_from(hjb_builder b, int32_t device, int32_t rank, int32_t world, int32_t overlap, hjb_rank *out) {
+    if (!b || !out) return bfail(b, HJB_E_INVALID, "null argument");
+    hjb_problem p;
+    const int st0 = builder_bind(b, &p);
+    if (st0) return st0;
+    const int st = hjb_rank_create(&p, device, rank, world, overlap, out);
+    if (st) b->err = g_last_error;
+    return st;
+}
+
 int32_t hjb_rank_info(hjb_rank r, int32_t *out10) {
     if (!r || !out10) return rfail(r, HJB_E_INVALID, "null argument");
     out10[0] = r->begin; out10[1] = r->end; out10[2] = r->hlo; out10[3] = r->hhi;

@@ -183,6 +183,7 @@ SYMBOLS = {
     "hjb_multi_last_error": (C.c_char_p, [C.c_void_p]),
     # one process per GPU: a rank's slab as interior + boundary strips
     "hjb_rank_create": (C.c_int32, [C.POINTER(hjb_problem), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hjb_rank_create_from": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "hjb_rank_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hjb_rank_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_rank_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),

@@ -15,6 +15,10 @@ function out = hjbdp_solve(prob, n_stages, varargin)
 %                expansion (Solver_pos_att.m:307-314), any singleton dims squeezed out
 %     single     logical: run in single (Dynamic_Solver.m:69) or double (test_coder.m) precision
 %     terminal   optional [nS] terminal cost (default zeros, Dynamic_Solver.m:83-84)
+%     model      optional struct (h, tables = {x4, x5, x6, x7}): HJB_MODEL_QUAT_EULER321 - the next values of state axes
+%                1..3 (yaw, pitch, roll) are computed inside the stage kernel from the four quaternion tables over those
+%                axes (Solver_attitude.m:449-489) instead of being passed as nS-sized operands; next_terms{1..3} are empty.
+%                D = 6, C = 3, single only.  What makes 51^6 states possible (Solver_attitude_hjbdp_run.m).
 %   'devices': a scalar runs on that GPU (hjb_create_from / hjb_solve_flat); a vector [0 1 .. 7] partitions the LAST
 %   state axis over those GPUs of this process (hjb_create_multi_from / hjb_solve_multi_flat; no per-stage planes).
 %   'fast_axes' (default false = the reference's own axis order, the bit-parity-tested one; opt in exactly as the Python
@@ -28,6 +32,9 @@ function out = hjbdp_solve(prob, n_stages, varargin)
 %   formed, located and weighted in double, the weight rounded to single once - the typing of Solver_pos_att.m:299-327
 %   (double x_next .. w_next, single F_gI.Values); costs nothing per stage (hjbdp.h HJB_TAB_F64).
 %   'monitor_single' (default false): the monitor's sum(F.Values(:)) as a single-precision sum (Solver_pos_att.m:274).
+%   'labels' (default 'int32'; 'uint8' | 'uint16' | 'auto'): storage class of the argmin labels inside the library and on
+%   the way back (hjbdp.h HJB_IDX_*; 'auto' = the narrowest that holds prod(m)): Solver_pos_att's U_Optimal_id has 9 values.
+%   out.idx is converted to double either way (MATLAB's min returns double indices).
 %   out: J (final values), idx (1-based argmin labels), and with keep_stages J_stages / idx_stages
 %        [nS x n_stages] with stage k_s in column k_s, stages_done, stopped_early, sweep_ms.
 %
@@ -41,6 +48,7 @@ function out = hjbdp_solve(prob, n_stages, varargin)
     addParameter(p, 'fast_axes', false);
     addParameter(p, 'double_tables', false);
     addParameter(p, 'monitor_single', false);
+    addParameter(p, 'labels', 'int32');
     parse(p, varargin{:});
     o = p.Results;
     L = 'libhjbdp';
@@ -56,10 +64,24 @@ function out = hjbdp_solve(prob, n_stages, varargin)
     bv = b.Value;
     freeb = onCleanup(@() calllib(L, 'hjb_problem_free', bv));
     ncls = cls;                                   % class of the next-state operands as handed to the library
-    if o.double_tables
-        if ~prob.single, error('hjbdp:arg', 'double_tables is for prob.single = true'); end
-        check(calllib(L, 'hjb_problem_set_types', bv, int32(0), int32(1)), bv, 'builder');   % HJB_IDX_I32, HJB_TAB_F64
-        ncls = 'double';
+    top = prod(double(prob.m));                   % the largest (1-based) label
+    switch o.labels
+        case 'int32',  idt = 0;
+        case 'uint8',  idt = 1;
+        case 'uint16', idt = 2;
+        case 'auto',   idt = 3;
+        otherwise, error('hjbdp:arg', 'labels must be int32, uint8, uint16 or auto');
+    end
+    icls = 'int32';                               % class of the label arrays that come back
+    if idt == 1 || (idt == 3 && top <= 255), icls = 'uint8'; elseif idt == 2 || (idt == 3 && top <= 65535), icls = 'uint16'; end
+    if o.double_tables && ~prob.single, error('hjbdp:arg', 'double_tables is for prob.single = true'); end
+    if o.double_tables || idt ~= 0
+        check(calllib(L, 'hjb_problem_set_types', bv, int32(idt), int32(o.double_tables)), bv, 'builder');   % HJB_IDX_*, HJB_TAB_F64
+    end
+    if o.double_tables, ncls = 'double'; end
+    if isfield(prob, 'model') && ~isempty(prob.model)      % HJB_MODEL_QUAT_EULER321 = 1
+        tb = cellfun(@(t) single(t(:)), prob.model.tables, 'UniformOutput', false);
+        check(calllib(L, 'hjb_problem_set_model', bv, int32(1), double(prob.model.h), tb{1}, tb{2}, tb{3}, tb{4}), bv, 'builder');
     end
     mask = @(dims) uint32(sum(bitshift(1, dims - 1)));
     for a = 1:D
@@ -90,7 +112,8 @@ function out = hjbdp_solve(prob, n_stages, varargin)
         term = cast(prob.terminal(:), cls);
         if D > 1, term = reshape(permute(reshape(term, shape0), order), [], 1); end
     end
-    Jf = libpointer(ptr, zeros(nS, 1, cls));  If = libpointer('int32Ptr', zeros(nS, 1, 'int32'));
+    iptr = [icls 'Ptr'];
+    Jf = libpointer(ptr, zeros(nS, 1, cls));  If = libpointer(iptr, zeros(nS, 1, icls));
     done = libpointer('int32Ptr', int32(0));  early = libpointer('int32Ptr', int32(0));  ms = libpointer('doublePtr', 0);
     h = libpointer('voidPtrPtr');
     if isscalar(o.devices)
@@ -100,7 +123,7 @@ function out = hjbdp_solve(prob, n_stages, varargin)
         if o.monitor_single, check(calllib(L, 'hjb_set_option', hv, 'monitor_single', int64(1)), hv, 'handle'); end
         Js = [];  Is = [];
         if o.keep_stages
-            Js = libpointer(ptr, zeros(nS * n_stages, 1, cls));  Is = libpointer('int32Ptr', zeros(nS * n_stages, 1, 'int32'));
+            Js = libpointer(ptr, zeros(nS * n_stages, 1, cls));  Is = libpointer(iptr, zeros(nS * n_stages, 1, icls));
         end
         check(calllib(L, 'hjb_solve_flat', hv, int32(n_stages), int32(o.monitor_period), o.monitor_tol, term, Jf, If, Js, Is, ...
                       done, early, ms), hv, 'handle');

@@ -173,7 +173,7 @@ def _prototypes(text):
         args = []
         for a in m.group(2).split(","):
             a = re.sub(r"\b(const|struct)\b", " ", a)
-            a = re.sub(r"\b(hjb_builder|hjb_handle|hjb_multi)\b", "void *", a)      # opaque handles
+            a = re.sub(r"\b(hjb_builder|hjb_handle|hjb_multi|hjb_rank)\b", "void *", a)      # opaque handles
             a = re.sub(r"[A-Za-z_][A-Za-z_0-9]*\s*$", "", a.strip()) if not a.strip().endswith("*") and a.strip() != "void" else a
             args.append(re.sub(r"\s+", "", a))
         out[m.group(1)] = args
@@ -193,9 +193,78 @@ def test_matlab_header_is_the_flat_subset_of_the_c_header(lib):
         assert args == full[name], (name, args, full[name])
     for name in ("hjb_problem_new", "hjb_create_from", "hjb_solve_flat", "hjb_create_multi_from", "hjb_solve_multi_flat"):
         assert name in flat
-    shim = (ROOT / "optimal-control-dynamic-programming_amd" / "matlab" / "hjbdp_solve.m").read_text()
-    for name in re.findall(r"calllib\(L, '(hjb_[a-z_0-9]+)'", shim):
-        assert name in flat, name                    # the MATLAB shim calls nothing the flat header lacks
+    for name in ("hjb_rank_create_from", "hjb_rank_stage", "hjb_rank_info", "hjb_device_malloc", "hjb_device_copy"):
+        assert name in flat                          # a MATLAB worker per GPU can bind the rank API
+    # every calllib in every .m file: a function the flat header declares, called with as many arguments as it takes
+    mdir = ROOT / "optimal-control-dynamic-programming_amd" / "matlab"
+    n_calls = 0
+    for mfile in sorted(mdir.glob("*.m")):
+        for name, nargs in _matlab_calllibs(mfile.read_text()):
+            assert name in flat, (mfile.name, name)
+            want = 0 if flat[name] == ["void"] else len(flat[name])
+            assert nargs == want, (mfile.name, name, nargs, flat[name])
+            n_calls += 1
+    assert n_calls >= 18
+
+
+def _matlab_calllibs(text):
+    """(function name, number of arguments after the name) of every calllib(L, 'hjb_...', ...) in MATLAB source."""
+    text = re.sub(r"\.\.\.[^\n]*\n", " ", text)            # line continuations
+    code = "\n".join(l if not l.lstrip().startswith("%") else "" for l in text.split("\n"))
+    out = []
+    for m in re.finditer(r"calllib\(L,\s*'(hjb_[a-z_0-9]+)'", code):
+        i, depth, nargs, in_str = m.end(), 1, 0, False
+        while depth > 0:
+            c = code[i]
+            if in_str:
+                in_str = c != "'"
+            elif c == "'" and not (code[i - 1].isalnum() or code[i - 1] in ")]}_."):     # a quote that opens a string, not a transpose
+                in_str = True
+            elif c in "([{":
+                depth += 1
+            elif c in ")]}":
+                depth -= 1
+            elif c == "," and depth == 1:
+                nargs += 1
+            elif c == "\n":
+                raise AssertionError("unterminated calllib: " + code[m.start():m.start() + 80])
+            i += 1
+        out.append((m.group(1), nargs))
+    return out
+
+
+def test_matlab_solver_shims_cover_the_reference_methods():
+    """north_star: 'Host code stays in MATLAB'.  One .m body per reference method on the path, each citing the lines it
+    replaces, each ending in the properties / files the reference method leaves, each on hjbdp_solve (the one file that
+    touches calllib)."""
+    mdir = ROOT / "optimal-control-dynamic-programming_amd" / "matlab"
+    want = {
+        "Dynamic_Solver_hjbdp_run.m": ("test/Dynamic_Solver.m:66-105", ["obj.u_star", "obj.J_star", "obj.F = griddedInterpolant"]),
+        "Solver_position_hjbdp_simplified_run.m": ("position-control/Solver_position.m:94-150",
+                                                   ["obj.U1_Opt = pol", "obj.U3_Opt = pol", "'nearest'", "obj.n_mesh_x = length"]),
+        "Solver_attitude_hjbdp_simplified_run.m": ("attitude-control/Solver_attitude.m:196-259",
+                                                   ["obj.U1_Opt = pol", "obj.U3_Opt = pol", "'nearest'"]),
+        "Solver_attitude_hjbdp_run.m": ("attitude-control/Solver_attitude.m:261-300",
+                                        ["obj.F = griddedInterpolant", "obj.U1_Opt = single(obj.U_vector", "obj.U3_Opt = single(obj.U_vector",
+                                         "prob.model"]),
+        "Solver_pos_att_hjbdp_channel.m": ("pos-att/Solver_pos_att.m:244-297",
+                                           ["save(file_name, 'F_gI', 'U_Optimal_id', 'f0_allcomb', 'f1_allcomb', 'f6_allcomb', 'f7_allcomb')",
+                                            "'double_tables', true", "'monitor_single', true", "'monitor_period', 50"]),
+        "Solver_pos_att_hjbdp_simplified_run.m": ("pos-att/Solver_pos_att.m:197-242", ["channel_x_controller_1_failure"]),
+    }
+    for name, (cite, needles) in want.items():
+        text = (mdir / name).read_text()
+        assert cite in text, (name, cite)
+        for nd in needles:
+            assert nd in text, (name, nd)
+        if name != "Solver_pos_att_hjbdp_simplified_run.m":
+            assert "hjbdp_solve(" in text and "calllib" not in text.replace("calllib can", ""), name
+    # the reference files the shims cite exist where they say (this container only: the GPU box has no /root/reference)
+    ref = Path("/root/reference")
+    if ref.exists():
+        for rel in ("test/Dynamic_Solver.m", "position-control/Solver_position.m", "attitude-control/Solver_attitude.m",
+                    "pos-att/Solver_pos_att.m"):
+            assert (ref / rel).exists(), rel
 
 
 def test_mex_gateway_compiles_against_the_c_header():

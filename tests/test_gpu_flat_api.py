@@ -332,3 +332,136 @@ def test_flat_api_reference_typing_of_pos_att(env):
     ref = c_oracle.sweep(_abi, spec, stages, monitor_period=10, monitor_tol=1e-2, monitor_single=True)
     assert done.value == ref["stages_done"] and bool(early.value) == ref["stopped_early"]
     assert np.array_equal(J, ref["J"]) and np.array_equal(idx, ref["idx"])
+
+
+# ---- the MATLAB solver shims' call sequences (matlab/*.m), replayed through ctypes: tests/matlab_twin.py ----------------
+
+def _twin():
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import matlab_twin
+    return matlab_twin
+
+
+@pytest.mark.order(8)
+def test_matlab_shim_sequences_solver_position(env):
+    """matlab/Solver_position_hjbdp_simplified_run.m: the three channels through hjbdp_solve.m's call sequence equal the
+    Python mirror (oracle-checked in tests/test_gpu_solvers.py) bit for bit, on the reference's own grid; the 'nearest'
+    policy tables U_vector(U_idx) follow."""
+    hjbdp, _abi, c_oracle = env
+    mt = _twin()
+    lib = hjbdp.load_library()
+    sp = hjbdp.Solver_position()
+    sp.simplified_run(n_stages=40)
+    ref = hjbdp.Solver_position()
+    for ch in range(3):
+        prob = mt.position_channel_prob(ref, ch)
+        assert len(prob["knots"][0]) == 201 and len(prob["knots"][1]) == 201           # sym_linspace: 200 -> 201 points
+        out = mt.hjbdp_solve(lib, prob, 40)
+        assert out["J"].shape == (201, 201) and out["idx"].dtype == np.float64
+        assert np.array_equal(out["J"], sp.F_values[ch]) and np.array_equal(out["idx"], sp.U_idx[ch])
+        pol = ref.U_vector[out["idx"].astype(int) - 1]                                  # griddedInterpolant(..., U_vector(U_idx), 'nearest')
+        assert np.array_equal(pol, getattr(sp, "U%d_Opt" % (ch + 1)).Values)
+    # ... and on two "devices" of this process (hjb_create_multi_from / hjb_solve_multi_flat)
+    out2 = mt.hjbdp_solve(lib, mt.position_channel_prob(ref, 0), 40, devices=[0, 0])
+    assert np.array_equal(out2["J"], sp.F_values[0]) and np.array_equal(out2["idx"], sp.U_idx[0])
+
+
+@pytest.mark.order(8)
+def test_matlab_shim_sequences_attitude_simplified(env):
+    """matlab/Solver_attitude_hjbdp_simplified_run.m against the Python mirror."""
+    hjbdp, _abi, c_oracle = env
+    mt = _twin()
+    lib = hjbdp.load_library()
+    sa = hjbdp.Solver_attitude(n_mesh_t=60, n_mesh_w_simplified=140)
+    sa.simplified_run(n_stages=30)
+    for ch in range(3):
+        out = mt.hjbdp_solve(lib, mt.attitude_simplified_prob(sa, ch), 30)
+        assert np.array_equal(out["J"], sa.F_values[ch]) and np.array_equal(out["idx"], sa.U_idx[ch])
+
+
+@pytest.mark.order(8)
+@pytest.mark.parametrize("on_the_fly", [True, False])
+def test_matlab_shim_sequences_attitude_run(env, on_the_fly):
+    """matlab/Solver_attitude_hjbdp_run.m: the 6-D problem built in the library's axis order with hjb_problem_set_model
+    (on the fly) or with the three tabulated next-angle operands, uint8 labels ('labels', 'auto'), results permuted back:
+    obj.F.Values and the three U_i_Opt index arrays equal the Python mirror's run()."""
+    hjbdp, _abi, c_oracle = env
+    mt = _twin()
+    lib = hjbdp.load_library()
+    sa = hjbdp.Solver_attitude(n_mesh_w=6, n_mesh_q=5)
+    sa.run(n_stages=5, on_the_fly=on_the_fly)
+    assert sa.kernel_variant == 4
+    prob, dims = mt.attitude_run_prob(sa, on_the_fly=on_the_fly)
+    out = mt.hjbdp_solve(lib, prob, 5, labels="auto")
+    J, (i1, i2, i3) = mt.attitude_run_finish(out, dims)
+    assert J.shape == (6, 6, 6, 5, 5, 5)
+    assert np.array_equal(J, sa.F_values)
+    for mine, theirs in zip((i1, i2, i3), sa.U_idx):
+        assert np.array_equal(mine + 1, theirs)
+    assert np.array_equal(sa.U_vector[i3].astype(np.float32), sa.U3_Opt)
+
+
+@pytest.mark.order(8)
+@pytest.mark.parametrize("cost_mode", ["exact", "terms"])
+def test_matlab_shim_sequences_pos_att_channel(env, cost_mode):
+    """matlab/Solver_pos_att_hjbdp_channel.m on the reference's own grid (30 x 30 x 20 x 15 x 9): double query tables,
+    single-precision monitor every 50 stages, uint8 labels - F_gI.Values, U_Optimal_id, the stage the monitor stopped at
+    and the *_allcomb vectors equal the Python mirror's channel (oracle-checked incl. the monitor); with 'fast_axes' the
+    library's relabelling gives the same J to rounding."""
+    hjbdp, _abi, c_oracle = env
+    mt = _twin()
+    lib = hjbdp.load_library()
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = cost_mode
+    sx, sv, st, sw = pa.grids()
+    args = (sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    c = pa.calculate_one_channel_U_Opt(*args, "channel_x_controller_1", n_stages=120)
+    prob, combos = mt.pos_att_channel_prob(pa, *args, cost_mode=cost_mode)
+    out = mt.hjbdp_solve(lib, prob, 120, **mt.POS_ATT_SOLVE_KW)
+    assert out["J"].shape == (30, 30, 20, 15)
+    assert np.array_equal(out["J"], c["F_gI_Values"]) and np.array_equal(out["idx"], c["U_Optimal_id"])
+    assert out["stages_done"] == c["stages_done"] and out["stopped_early"] == c["stopped_early"]
+    for k, v in zip(("f0_allcomb", "f1_allcomb", "f6_allcomb", "f7_allcomb"), combos):
+        assert np.array_equal(v, c[k])
+    if cost_mode == "terms":
+        fast = mt.hjbdp_solve(lib, prob, 120, fast_axes=True, **mt.POS_ATT_SOLVE_KW)
+        assert fast["axis_order"] == [1, 3, 4, 2]
+        assert np.allclose(fast["J"], out["J"], rtol=5e-5, atol=1e-6)
+
+
+def test_rank_create_from_builder_equals_struct_form(env):
+    """hjb_rank_create_from (the flat form a MATLAB worker per GPU binds): same partition, same stage kernel, same bits as
+    hjb_rank_create on the struct."""
+    hjbdp, _abi, c_oracle = env
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_abi import _builder_from_spec
+    from problems import colsweep_problem, random_terminal
+    lib = hjbdp.load_library()
+    spec = colsweep_problem(90, (66, 8, 9, 12), nU=9)
+    term = random_terminal(spec, 2)
+    Jr, ir = c_oracle.backup_stage(_abi, spec, term)
+    nl, inner = spec.n[-1], spec.nS // spec.n[-1]
+    for rank in range(3):
+        b = _builder_from_spec(lib, spec)
+        r = C.c_void_p()
+        assert lib.hjb_rank_create_from(b, 0, rank, 3, 1, C.byref(r)) == _abi.HJB_OK, lib.hjb_problem_last_error(b)
+        assert lib.hjb_problem_free(b) == _abi.HJB_OK
+        info = (C.c_int32 * 10)()
+        assert lib.hjb_rank_info(r, info) == _abi.HJB_OK
+        begin, end, hlo, hhi = info[0], info[1], info[2], info[3]
+        rb = hjbdp.core.RankSlab(spec, 0, rank, 3)
+        assert (rb.begin, rb.end, rb.halo_lo, rb.halo_hi, rb.split, rb.kernel_variant) == (begin, end, hlo, hhi, info[4], info[5])
+        rb.close()
+        planes = end - begin + hlo + hhi
+        view = np.ascontiguousarray(term.reshape(inner, nl, order="F")[:, begin - hlo:end + hhi].reshape(-1, order="F"))
+        with hjbdp.DeviceBuffer(view.nbytes) as dIn, hjbdp.DeviceBuffer(view.nbytes) as dOut, \
+                hjbdp.DeviceBuffer(inner * (end - begin) * info[8]) as dI:
+            dIn.upload(view)
+            dOut.upload(view)
+            assert lib.hjb_rank_stage(r, int(dIn), int(dOut), int(dI), None, None) == _abi.HJB_OK, lib.hjb_rank_last_error(r)
+            assert lib.hjb_rank_check_status(r, None) == _abi.HJB_OK
+            Jo = dOut.download(np.float32).reshape(inner, planes, order="F")[:, hlo:hlo + end - begin]
+            io = dI.download({1: np.uint8, 2: np.uint16, 4: np.int32}[info[8]])
+        assert np.array_equal(Jo, Jr.reshape(inner, nl, order="F")[:, begin:end])
+        assert np.array_equal(io.reshape(inner, end - begin, order="F"), ir.reshape(inner, nl, order="F")[:, begin:end])
+        assert lib.hjb_rank_destroy(r) == _abi.HJB_OK
