@@ -9,8 +9,12 @@ Workload: C4, the configuration the north-star target is quoted on ("the 6-D pos
           cost (Solver_pos_att.m:264-265), state axes relabelled (x, theta, w, v) = Solver_pos_att.FAST_AXIS_ORDER.
           The other BASELINE configs are measured in the same run as extra keys of the line (`other_workloads`:
           C5 = C4 with float16 cost-to-go storage, C2 = Solver_position 101^3 x 21^3, 6D = the attitude model of
-          Solver_attitude.run on 24^6 states x 11^3 torques - SURVEY 8(d)'s "6-D" figure), each with its own roofline
-          object from the same live counter passes; they are also parity tests.
+          Solver_attitude.run on 24^6 states x 11^3 torques - SURVEY 8(d)'s "6-D" figure - and C3 = that model on
+          51^6 states with the next angles computed in the kernel: BASELINE configs[2], 176 GB resident, 1 warm-up + 2
+          timed stages, skipped with the reason stated when less than 190 GB of HBM are free), each with its own
+          roofline object from the same live counter passes; they are also parity tests.
+Timing  : the timed region (K steps between barriers) is repeated 3 times; `ms_per_step` / `value` are the MEDIAN
+          repetition, `ms_per_step_min` and `ms_per_step_reps` say what the others were.
 Step    : ONE stage of the backward sweep = one fused backup kernel over the whole grid (1.866e9 backups).
 N GPUs  : one process per GPU (torchrun), the FIXED grid sharded along its last state axis (v: next states move
           < 1 plane, so the halo is one plane each side) = STRONG scaling; neighbour halo exchange per stage over RCCL
@@ -21,7 +25,8 @@ Prints ONE JSON line on rank 0.  `roofline`: the path is VALU-bound at every BAS
 `achieved` = algorithmic flops F_alg(4) = 71 per backup / launch time against the 157.3 TFLOP/s fp32 vector peak; the
 executed-instruction view (`valu_issue_util`) and `traffic` come from rocprofv3 --pmc passes that THIS run makes on
 child processes of the same command (rank 0, N = 1; null when rocprofv3 is unavailable).  `cpu_baseline` times the
-oracle's C twin (oracle/hjb_oracle.c, OpenMP) on a bounded slab sample of the same workload.
+oracle's C twin (oracle/hjb_oracle.c, OpenMP) on a bounded slab sample of the same workload IN THE SAME TYPING
+(float64-built queries, float32 blend: `cpu_baseline.typing`).
 """
 from __future__ import annotations
 
@@ -48,9 +53,13 @@ KERNEL_OF_VARIANT = {7: "k_backup_colsweep", 6: "k_backup_row", 5: "k_backup_tab
                      2: "k_backup_packed", 1: "k_backup_nested", 3: "k_backup_ctrlsplit", 0: "k_backup_generic"}
 # how the stage kernel of each workload is told apart in one rocprofv3 pass over all of them (demangled names)
 # (substring the name must hold, substring it must not hold): the binary16 type is spelt differently by demanglers
+# the first entry may be a tuple of alternatives (the window modes of K3: three- or four-plane window)
 KERNEL_FILTER = {"c4": ("k_backup_colsweep<float, float", None), "c5": ("k_backup_colsweep", "k_backup_colsweep<float, float"),   # rocprofv3 leaves the binary16 name mangled
-                 "c2": ("k_backup_packed2<float, 3", None), "6d": ("k_backup_packed2<float, 6", None)}
-EXTRA_STEPS = {"c5": 20, "c2": 20, "6d": 4}
+                 "c2": ("k_backup_packed2<float, 3", None),
+                 "6d": (("k_backup_packed2<float, 6, 5>", "k_backup_packed2<float, 6, 2>"), None),      # tabulated next angles
+                 "c3": (("k_backup_packed2<float, 6, 6>", "k_backup_packed2<float, 6, 3>"), None)}      # on-the-fly model
+EXTRA_STEPS = {"c5": 20, "c2": 20, "6d": 4, "c3": 2}
+C3_NEEDS_GIB = 190          # J_k+1 + J_k (70.4 GB each) + uint16 labels (35.2 GB) = 176 GB resident
 
 
 def f_alg(D):
@@ -94,6 +103,15 @@ def build_spec(workload, n_last=None, n=120):
         spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=spec.index_base,
                                  idx_dtype="auto")
         return spec, "6D Solver_attitude.run model: %s states (yaw,pitch,roll,w1,w2,w3) x 11^3 torques, float32, uint16 argmin, 1 stage per step" % "x".join(str(k) for k in spec.n)
+    if workload == "c3":
+        # BASELINE configs[2]: Solver_attitude.run's model on 51^6 states x 11^3 torques, next angles computed in the stage
+        # kernel from four 51^3 quaternion tables (hjbdp.h HJB_MODEL_QUAT_EULER321): nothing nS-sized but J and the labels
+        sa = hjbdp.Solver_attitude(n_mesh_w=n, n_mesh_q=n)
+        sa.U_vector = np.linspace(-0.11, 0.11, 11)
+        s0 = sa.build_spec_model()
+        spec = hjbdp.ProblemSpec(s0.knots, s0.m, s0.next_terms, s0.cost_terms, dtype=np.float32, index_base=s0.index_base,
+                                 model=s0.model, idx_dtype="auto")
+        return spec, "C3 Solver_attitude.run model: %s states (yaw,pitch,roll,w1,w2,w3) x 11^3 torques, float32, on-the-fly quaternion model, uint16 argmin, 1 stage per step" % "x".join(str(k) for k in spec.n)
     if workload == "c2":
         from hjbdp.synthetic import position3d_spec
         spec = position3d_spec(n=101, mu=21, n_last=n_last)
@@ -117,6 +135,9 @@ def cpu_baseline(spec, budget_s=15.0, dataflow_spec=None):
     hl, hh = required_halo(spec)
     mid = spec.n[-1] // 2
     rng = np.random.default_rng(0)
+    typing = ("float64-built queries (double next-state operands, located and weighted in double, weight rounded once), "
+              "float32 blend / cost / argmin: the GPU line's typing" if spec.table_dtype is not None
+              else "%s throughout" % np.dtype(spec.dtype).name)
 
     def run(planes, impl):
         b, e = mid, mid + planes
@@ -129,7 +150,7 @@ def cpu_baseline(spec, budget_s=15.0, dataflow_spec=None):
         t1 = run(1, impl)
         planes = int(max(1, min(spec.n[-1] // 2 - hh - 1, budget / max(t1, 1e-3))))
         t = run(planes, impl) if planes > 1 else t1
-        return {"value": inner * planes * spec.nU / t, "unit": "backups/s", "cores": cores, "kind": "port",
+        return {"value": inner * planes * spec.nU / t, "unit": "backups/s", "cores": cores, "kind": "port", "typing": typing,
                 "sample": "%d of %d planes of the last state axis (%d states x %d controls, 1 stage) in %.1f s" % (
                     planes, spec.n[-1], inner * planes, spec.nU, t)}
     # two forms of the C twin, same results bit for bit (tests/test_oracle_golden.py): the scalar one every parity
@@ -192,7 +213,8 @@ def collect_pmc(argv_child, kernel_filters, timeout_s=420):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
                         for w, (kf, knot) in kernel_filters.items():
-                            if kf in row["Kernel_Name"] and not (knot and knot in row["Kernel_Name"]):
+                            kfs = kf if isinstance(kf, tuple) else (kf,)
+                            if any(k in row["Kernel_Name"] for k in kfs) and not (knot and knot in row["Kernel_Name"]):
                                 # one row per (dispatch, counter[, dimension instance]): sum the instances of a dispatch, then
                                 # average over the dispatches
                                 a = acc[w].setdefault(row["Counter_Name"], {})
@@ -206,8 +228,49 @@ def collect_pmc(argv_child, kernel_filters, timeout_s=420):
     return (out or None), "; ".join(notes)
 
 
-def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=False):
-    """Times `steps` stages of `workload` on this rank's slab.  -> dict of measurements."""
+def run_c3(args, steps, warmup, dev, n=51):
+    """C3 (BASELINE configs[2]) on ONE GPU, library stage calls on torch-owned device buffers (two J buffers + uint16
+    labels = 176 GB at n = 51): `warmup` + `steps` stages from a zero terminal cost, HIP events on the launch stream.
+    -> dict like run_workload's, or {"skipped": reason}."""
+    import torch
+    import hjbdp
+    spec, name = build_spec("c3", n=n)
+    need = (2 * spec.nS * 4 + spec.nS * spec.idx_np_dtype.itemsize) / 2 ** 30
+    free, total = torch.cuda.mem_get_info(dev)
+    if n == 51 and free < C3_NEEDS_GIB * 2 ** 30:
+        return {"skipped": "C3 needs %d GiB of free HBM (%.0f GiB resident), this device has %.0f of %.0f GiB free"
+                           % (C3_NEEDS_GIB, need, free / 2 ** 30, total / 2 ** 30), "workload": name}
+    J = [torch.zeros(spec.nS, dtype=torch.float32, device=dev) for _ in range(2)]
+    idx = torch.empty(spec.nS, dtype=torch.int16, device=dev)            # uint16 labels: 1331 torque triples
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with hjbdp.Backup(spec, device=dev.index or 0) as bk:
+        info = bk.info()
+        k = 0
+        for _ in range(warmup):
+            bk.backup_stage_device(J[k & 1], J[1 - (k & 1)], idx, stream=stream)
+            k += 1
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            bk.backup_stage_device(J[k & 1], J[1 - (k & 1)], idx, stream=stream)
+            k += 1
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        bk.check_device_status(stream)
+    dev_ms = ev0.elapsed_time(ev1)
+    cs = float(J[k & 1].double().sum()) if steps + warmup > 0 else 0.0
+    del J, idx
+    torch.cuda.empty_cache()
+    return {"spec": spec, "name": name, "info": info, "wall": wall, "dev_ms": dev_ms, "steps": steps, "states_rank": spec.nS,
+            "halo": (0, 0), "checksum": cs, "total_backups": spec.nS * spec.nU * steps, "walls": [wall]}
+
+
+def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=False, reps=1):
+    """Times `steps` stages of `workload` on this rank's slab, `reps` times over (each repetition bracketed by barriers;
+    the MEDIAN repetition is reported, all of them are returned).  -> dict of measurements."""
     import torch
     from hjbdp.sharded import ShardedSweep
     n = {"c2": 101, "6d": 24}.get(workload, args.grid_n)
@@ -226,28 +289,33 @@ def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=Fal
 
     for _ in range(warmup):
         sw.step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                      # the stream the stage kernels are launched on
-    for _ in range(steps):
-        sw.step()
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    walls, devs = [], []
+    for _ in range(max(1, reps)):
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                      # the stream the stage kernels are launched on
+        for _ in range(steps):
+            sw.step()
+        ev1.record()
+        barrier()
+        w = time.perf_counter() - t0
+        devs.append(ev0.elapsed_time(ev1))
+        if world > 1:
+            tt = torch.tensor([w], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            w = float(tt[0])
+        walls.append(w)
     sw.check_device_status()
-    if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt[0])
+    med = sorted(range(len(walls)), key=lambda i: walls[i])[len(walls) // 2]      # the median repetition (by the max-over-ranks wall)
+    wall, dev_ms = walls[med], devs[med]
     cs = sw.owned_J().double().sum().reshape(1)
     if world > 1:
         cs = cs.cpu() if args.backend != "nccl" else cs
         dist.all_reduce(cs)
     res = {"spec": spec, "name": name, "info": info, "wall": wall, "dev_ms": dev_ms, "steps": steps,
            "states_rank": sw.owned * sw.inner, "halo": (sw.halo_lo, sw.halo_hi), "checksum": float(cs[0]),
-           "total_backups": spec.nS * spec.nU * steps}
+           "total_backups": spec.nS * spec.nU * steps, "walls": walls}
     sw.close()
     return res
 
@@ -261,6 +329,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs / the weak-scaling figure")
+    ap.add_argument("--no-c3", action="store_true", help="skip the C3 leg (51^6 states, 176 GB, ~20 s + ~50 s of counter passes)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange halos, then compute (no overlap)")
     ap.add_argument("--variant", type=int, default=None, help="force a stage-kernel variant (testing)")
     ap.add_argument("--grid-n", type=int, default=120, help="points per axis of the pos-att grid (config: 120; smaller = testing)")
@@ -278,7 +347,9 @@ def main():
         args.gpus = world
 
     # ---- PMC passes on child processes, before this process initialises the GPU ------------------------------
-    extras = [w for w in ("c5", "c2", "6d") if w != args.workload] if (world == 1 and not args.no_extras and args.grid_n == 120) else []
+    extras = [w for w in ("c5", "c2", "6d", "c3") if w != args.workload] if (world == 1 and not args.no_extras and args.grid_n == 120) else []
+    if args.no_c3 and "c3" in extras:
+        extras.remove("c3")
     pmc_all, pmc_note = None, "not collected"
     if world == 1 and not args.pmc_child and not args.no_pmc:
         child = ["--workload", args.workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc",
@@ -311,10 +382,13 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    head = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist)
+    head = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist, reps=1 if args.pmc_child else 3)
     if args.pmc_child:                      # the counter passes: a few launches of every workload's stage kernel, nothing else
         for w in extras:
-            run_workload(args, w, 2, 1, world, rank, dev, dist)
+            if w == "c3":
+                run_c3(args, 1, 0, dev)
+            else:
+                run_workload(args, w, 2, 1, world, rank, dev, dist)
         return
     spec, info = head["spec"], head["info"]
     value = head["total_backups"] / head["wall"]
@@ -380,6 +454,9 @@ def main():
     out = {
         "metric": "bellman_backups_per_s", "value": value, "unit": "backups/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["wall"] * 1e3 / args.steps,
+        "ms_per_step_min": min(head["walls"]) * 1e3 / args.steps,
+        "ms_per_step_reps": [w * 1e3 / args.steps for w in head["walls"]],
+        "timing": "3 repetitions of the K-step timed region, each between barriers; value / ms_per_step = the median repetition",
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if spec.j_dtype.itemsize == 4 else "f32 (J stored as f16)", "data": "synthetic",
         "config": {"workload": head["name"], "states": spec.nS, "states_per_gpu": head["states_rank"], "controls": spec.nU,
@@ -396,7 +473,10 @@ def main():
         if world == 1:
             others = {}
             for w in extras:
-                r = run_workload(args, w, EXTRA_STEPS[w], 2, world, rank, dev, dist)
+                r = run_c3(args, EXTRA_STEPS[w], 1, dev) if w == "c3" else run_workload(args, w, EXTRA_STEPS[w], 2, world, rank, dev, dist)
+                if "skipped" in r:
+                    others[w] = r
+                    continue
                 others[w] = {"workload": r["name"], "value": r["total_backups"] / r["wall"], "unit": "backups/s",
                              "ms_per_step": r["wall"] * 1e3 / r["steps"], "kernel_variant": r["info"]["kernel_variant"],
                              "roofline": roofline_of(r, w), "checksum_sum_J": r["checksum"]}
@@ -407,12 +487,7 @@ def main():
                                    "ms_per_step": r["wall"] * 1e3 / r["steps"], "states_per_gpu": r["states_rank"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         small = build_spec(args.workload, n=32)[0] if args.workload in ("c4", "c5") else None
-        # the CPU forms locate their queries in float32 (the AVX2 twin has no float64-query mode): same grid, same
-        # controls, same number of operations - the typing of the weights is the only difference from the GPU workload
-        cspec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=spec.dtype, index_base=spec.index_base,
-                                  j_storage=None if spec.j_dtype == spec.dtype else spec.j_dtype)
-        out["cpu_baseline"] = cpu_baseline(cspec, dataflow_spec=small)
-        out["cpu_baseline"]["sample"] += "; float32 queries (the GPU line uses float64-built query tables)"
+        out["cpu_baseline"] = cpu_baseline(spec, dataflow_spec=small)      # the GPU line's own problem, typing included
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -314,10 +314,27 @@ DEFINE_BACKUP(double, backup_f64, fma)
  * axis-0 states of one grid row per iteration, one lane each.  Lane by lane it performs exactly the operations of the
  * scalar twin above in the same order (IEEE adds / multiplies, vfmadd for the lerps, the same binary search, strict
  * '<'), so its results are bit-identical - tests/test_oracle_golden.py holds it to that.  float32 arithmetic only
- * (float32 / float16 storage), no state model, J < 2^31 elements; anything else returns HJB_E_UNSUPPORTED. */
+ * (float32 / float16 storage), no state model, J < 2^31 elements; anything else returns HJB_E_UNSUPPORTED.
+ * table_dtype HJB_TAB_F64 (Solver_pos_att.m:299-327, the typing bench.py's GPU line runs): the next-state terms are double,
+ * a query is summed, located and weighted in double on the double knots (two 4-lane halves), the weight rounded to float
+ * once - the scalar twin's tab64 branch, lane by lane. */
+/* upper_bound(q) - 1 clamped to [0, n-2] on double knots for four lanes; returns the cell as 64-bit lanes */
+static inline __m256i avx2_cell_pd(const double *kk, int n, __m256d q) {
+    __m256i lo = _mm256_setzero_si256(), hi = _mm256_set1_epi64x(n - 1);
+    for (;;) {
+        const __m256i act = _mm256_cmpgt_epi64(_mm256_sub_epi64(hi, lo), _mm256_set1_epi64x(1));
+        if (!_mm256_movemask_epi8(act)) break;
+        const __m256i mid = _mm256_srli_epi64(_mm256_add_epi64(lo, hi), 1);
+        const __m256i le = _mm256_castpd_si256(_mm256_cmp_pd(_mm256_i64gather_pd(kk, mid, 8), q, _CMP_LE_OQ));
+        lo = _mm256_blendv_epi8(lo, mid, _mm256_and_si256(act, le));
+        hi = _mm256_blendv_epi8(hi, mid, _mm256_andnot_si256(le, act));
+    }
+    return lo;
+}
 static int backup_f32_avx2(const hjb_problem *p, const float *Jn, float *Jout, int32_t *idx_out, int nthreads) {
     const int D = p->D, C = p->C;
-    if (p->model || p->table_dtype == HJB_TAB_F64) return HJB_E_UNSUPPORTED;
+    if (p->model) return HJB_E_UNSUPPORTED;
+    const int tab64 = p->table_dtype == HJB_TAB_F64;
     float *knots[HJB_MAX_D], *rdx[HJB_MAX_D];
     term_t nt[HJB_MAX_D][HJB_MAX_TERMS], ct[HJB_MAX_TERMS];
     int32_t jstride[HJB_MAX_D];
@@ -377,7 +394,45 @@ static int backup_f32_avx2(const hjb_problem *p, const float *Jn, float *Jout, i
             for (int64_t u = 0; u < nU; ++u) {
                 __m256 v[1 << HJB_MAX_D], tw[HJB_MAX_D];
                 __m256i base = _mm256_setzero_si256();
-                for (int a = 0; a < D; ++a) {
+                for (int a = 0; a < D && tab64; ++a) {       /* double queries, weight rounded once */
+                    __m256d qd[2] = {_mm256_setzero_pd(), _mm256_setzero_pd()};
+                    for (int k = 0; k < p->n_next_terms[a]; ++k) {
+                        int64_t off = 0;
+                        for (int d = 1; d < D + C; ++d) off += nt[a][k].stride[d] * gi[d];
+                        const double *dp = (const double *)nt[a][k].data + off;
+                        const int s0 = (int)nt[a][k].stride[0];
+                        const __m256i ix = _mm256_mullo_epi32(li, _mm256_set1_epi32(s0));
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const __m128i ih = hf ? _mm256_extracti128_si256(ix, 1) : _mm256_castsi256_si128(ix);
+                            const __m256d x = s0 == 0 ? _mm256_set1_pd(dp[0]) : _mm256_i32gather_pd(dp, ih, 8);
+                            qd[hf] = (k == 0) ? x : _mm256_add_pd(qd[hf], x);
+                        }
+                    }
+                    const double *kd = p->knots[a];
+                    __m128 th[2];
+                    __m128i ch[2];
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const __m256i lo = avx2_cell_pd(kd, p->n[a], qd[hf]);
+                        const __m256d k0 = _mm256_i64gather_pd(kd, lo, 8);
+                        const __m256d k1 = _mm256_i64gather_pd(kd, _mm256_add_epi64(lo, _mm256_set1_epi64x(1)), 8);
+                        const __m256d r = _mm256_div_pd(_mm256_set1_pd(1.0), _mm256_sub_pd(k1, k0));
+                        th[hf] = _mm256_cvtpd_ps(_mm256_mul_pd(_mm256_sub_pd(qd[hf], k0), r));
+                        ch[hf] = _mm256_castsi256_si128(_mm256_permutevar8x32_epi32(lo, _mm256_setr_epi32(0, 2, 4, 6, 0, 2, 4, 6)));
+                    }
+                    tw[a] = _mm256_insertf128_ps(_mm256_castps128_ps256(th[0]), th[1], 1);
+                    __m256i cell = _mm256_inserti128_si256(_mm256_castsi128_si256(ch[0]), ch[1], 1);
+                    if (a == D - 1) {
+                        cell = _mm256_sub_epi32(cell, _mm256_set1_epi32(plane0));
+                        __m256i bad = _mm256_or_si256(_mm256_cmpgt_epi32(_mm256_setzero_si256(), cell),
+                                                      _mm256_cmpgt_epi32(_mm256_add_epi32(cell, _mm256_set1_epi32(2)), _mm256_set1_epi32(nplanes)));
+                        if (_mm256_movemask_epi8(bad)) {
+                            err = 1;
+                            cell = _mm256_max_epi32(_mm256_min_epi32(cell, _mm256_set1_epi32(nplanes - 2)), _mm256_setzero_si256());
+                        }
+                    }
+                    base = _mm256_add_epi32(base, _mm256_mullo_epi32(cell, _mm256_set1_epi32(jstride[a])));
+                }
+                for (int a = 0; a < D && !tab64; ++a) {
                     __m256 q = _mm256_setzero_ps();
                     for (int k = 0; k < p->n_next_terms[a]; ++k) {
                         int64_t off = 0;

@@ -233,6 +233,17 @@ def _matlab_calllibs(text):
     return out
 
 
+def test_ctypes_twin_calls_what_the_matlab_shim_calls():
+    """tests/matlab_twin.py::hjbdp_solve is the stand-in the GPU tests run for matlab/hjbdp_solve.m: both must drive the same
+    set of flat entry points (names; the arities of the .m side are checked above, ctypes checks its own)."""
+    shim = (ROOT / "optimal-control-dynamic-programming_amd" / "matlab" / "hjbdp_solve.m").read_text()
+    twin = (ROOT / "tests" / "matlab_twin.py").read_text()
+    twin = twin[twin.index("def hjbdp_solve("):twin.index("# the reference classes' helper methods")]
+    in_m = {name for name, _ in _matlab_calllibs(shim)}
+    in_py = set(re.findall(r"lib\.(hjb_[a-z_0-9]+)", twin))
+    assert in_m == in_py, in_m ^ in_py
+
+
 def test_matlab_solver_shims_cover_the_reference_methods():
     """north_star: 'Host code stays in MATLAB'.  One .m body per reference method on the path, each citing the lines it
     replaces, each ending in the properties / files the reference method leaves, each on hjbdp_solve (the one file that

@@ -135,7 +135,7 @@ def test_slab_oracle_matches_whole_grid(orc):
     assert np.array_equal(io, iw.reshape(72, 12, order="F")[:, b:e].reshape(-1, order="F"))
 
 
-@pytest.mark.parametrize("case", ["random3d", "random4d_f16", "kirk", "rows_of_5", "one_axis", "slab"])
+@pytest.mark.parametrize("case", ["random3d", "random4d_f16", "kirk", "rows_of_5", "one_axis", "slab", "tab64_4d", "tab64_slab_f16"])
 def test_avx2_twin_equals_scalar_twin(orc, golden, case):
     """The row-vectorised C twin (bench.py's faster CPU baseline) performs the scalar twin's
     operations lane by lane: cost-to-go and argmin bit for bit, with ties, extrapolation, ragged rows and slabs."""
@@ -152,6 +152,17 @@ def test_avx2_twin_equals_scalar_twin(orc, golden, case):
         spec = random_problem(6, (5, 4, 3), (7,), dtype=np.float32, spread=0.5, nonuniform=True)
     elif case == "one_axis":
         spec = random_problem(7, (41,), (9,), dtype=np.float32, spread=0.4)
+    elif case in ("tab64_4d", "tab64_slab_f16"):
+        # the reference's pos-att typing (Solver_pos_att.m:299-327): double query tables, single blend - what bench.py's
+        # CPU leg times beside the GPU line
+        import hjbdp
+        from problems import colsweep_problem
+        s64 = (colsweep_problem(31, (21, 6, 7, 10), dtype=np.float64) if case == "tab64_4d"
+               else random_problem(32, (13, 7, 12), (5, 2), dtype=np.float64, spread=0.08, nonuniform=True))
+        spec = hjbdp.ProblemSpec(s64.knots, s64.m, s64.next_terms, s64.cost_terms, dtype=np.float32, table_dtype=np.float64,
+                                 index_base=1, j_storage=np.float16 if case == "tab64_slab_f16" else None)
+        if case == "tab64_slab_f16":
+            slab = (3, 9, 2, 2)
     else:
         spec = random_problem(99, (9, 8, 12), (4, 3), dtype=np.float32, spread=0.08)
         slab = (4, 8, 2, 2)
