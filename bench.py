@@ -261,7 +261,7 @@ def run_c3(args, steps, warmup, dev, n=51):
         wall = time.perf_counter() - t0
         bk.check_device_status(stream)
     dev_ms = ev0.elapsed_time(ev1)
-    cs = float(J[k & 1].double().sum()) if steps + warmup > 0 else 0.0
+    cs = float(J[k & 1].sum(dtype=torch.float64))          # float64 accumulation, no 141 GB temporary
     del J, idx
     torch.cuda.empty_cache()
     return {"spec": spec, "name": name, "info": info, "wall": wall, "dev_ms": dev_ms, "steps": steps, "states_rank": spec.nS,

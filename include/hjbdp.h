@@ -393,6 +393,27 @@ int32_t hjb_rank_check_status(hjb_rank r, void *stream);
 int32_t hjb_rank_destroy(hjb_rank r);
 const char *hjb_rank_last_error(hjb_rank r);
 
+/* ---- RCCL inside the library: a rank's halo exchange and monitor all-reduce without torch or MPI -------------------------
+ * per stage ncclGroupStart; ncclSend / ncclRecv x <= 4; ncclGroupEnd on a transfer stream (one xGMI link
+ * per neighbour pair), every monitor period a 2-double ncclAllReduce.  librccl.so.1 is dlopen'ed on first use (override:
+ * $HJBDP_RCCL_LIB); libhjbdp has no link dependency on it.  The host's part: rank 0 calls hjb_rank_comm_unique_id and hands
+ * the 128 bytes to every rank by any means (a file, a socket, MATLAB's labSend); every rank calls hjb_rank_comm_init
+ * (collective), then either hjb_rank_sweep (the whole `for k_s` loop incl. the monitor of Solver_pos_att.m:268-285) or,
+ * stage by stage, hjb_rank_step = hjb_rank_exchange (transfer stream, behind the compute stream) + hjb_rank_stage with the
+ * boundary strips waiting for the halos.  hjb_rank_monitor_sums: sum J and sum of labels over the WHOLE grid on every rank.
+ * Option "comm_loopback" (hjb_rank_set_option before hjb_rank_comm_init; one-GPU transport test): a communicator of one
+ * rank whose two neighbours are itself - the planes it sends down arrive in its own upper halo, those it sends up in its
+ * lower halo - so the RCCL calls, pointers, counts and stream ordering run on a box with a single GPU.
+ * tools/bench_ranks.cpp is a C++ driver on these calls (one process per GPU, no Python). */
+int32_t hjb_rank_comm_unique_id(void *id128_out);
+int32_t hjb_rank_comm_init(hjb_rank r, const void *id128);
+int32_t hjb_rank_exchange(hjb_rank r, void *dJ, void *compute_stream);
+void *hjb_rank_transfer_stream(hjb_rank r);
+int32_t hjb_rank_step(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream);
+int32_t hjb_rank_monitor_sums(hjb_rank r, const void *dJ, const void *d_idx, void *compute_stream, double *sums2);
+int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, double monitor_tol, void *dJ0, void *dJ1, void *d_idx,
+                       void *compute_stream, int32_t *stages_done, int32_t *stopped_early, int32_t *final_in_0, double *sweep_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,13 @@ int32_t hjb_rank_get_option(void *rank, const char *key, int64_t *value);
 int32_t hjb_rank_check_status(void *rank, void *stream);
 int32_t hjb_rank_destroy(void *rank);
 const char *hjb_rank_last_error(void *rank);
+/* RCCL transport inside the library (include/hjbdp.h): the 128-byte id from rank 0 goes to every worker by labSend / a file */
+int32_t hjb_rank_comm_unique_id(void *id128_out);
+int32_t hjb_rank_comm_init(void *rank, const void *id128);
+int32_t hjb_rank_step(void *rank, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream);
+int32_t hjb_rank_monitor_sums(void *rank, const void *dJ, const void *d_idx, void *compute_stream, double *sums2);
+int32_t hjb_rank_sweep(void *rank, int32_t n_stages, int32_t monitor_period, double monitor_tol, void *dJ0, void *dJ1, void *d_idx,
+                       void *compute_stream, int32_t *stages_done, int32_t *stopped_early, int32_t *final_in_0, double *sweep_ms);
 /* device buffers for hosts without a HIP binding of their own */
 int32_t hjb_device_malloc(int32_t device, int64_t bytes, void **out);
 int32_t hjb_device_free(int32_t device, void *p);

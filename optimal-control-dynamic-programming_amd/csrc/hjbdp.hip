@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <chrono>
 #include <climits>
 #include <cstring>
@@ -35,6 +36,8 @@
 #include "kernels_probe.h"
 #include "kernels_prep_mfma.h"
 #include "kernels_reduce.h"
+
+struct ncclUniqueIdBytes { char internal[128]; };      // rccl.h ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
 #include "kernels_devmem.h"
 
 using namespace hjb;
@@ -3105,6 +3108,14 @@ struct hjb_rank_s {
     int64_t inner = 0;
     size_t esz = 4, isz = 4;
     std::string err;
+    // RCCL transport (hjb_rank_comm_init): the communicator, the transfer stream, an event that orders it behind the
+    // compute stream, the monitor's reduction scratch, and the loopback switch of the one-GPU transport test
+    void *comm = nullptr;
+    hipStream_t xfer = nullptr;
+    hipEvent_t xready = nullptr;
+    double *d_partials = nullptr, *d_sums = nullptr;
+    bool loopback = false;
+    int dtype = HJB_F32, up_needs = 0, dn_needs = 0;
 };
 
 static int rfail(hjb_rank r, int code, const char *fmt, ...) {
@@ -3119,6 +3130,7 @@ static int rfail(hjb_rank r, int code, const char *fmt, ...) {
 }
 
 const char *hjb_rank_last_error(hjb_rank r) { return r ? r->err.c_str() : g_last_error.c_str(); }
+static void rank_comm_release(hjb_rank r);
 
 int32_t hjb_rank_destroy(hjb_rank r) {
     if (!r) return HJB_OK;
@@ -3130,6 +3142,7 @@ int32_t hjb_rank_destroy(hjb_rank r) {
     }
     if (r->fork) (void)hipEventDestroy(r->fork);
     if (r->halo) (void)hipEventDestroy(r->halo);
+    rank_comm_release(r);
     for (int i = 0; i < 3; ++i) if (r->part[i]) (void)hjb_destroy((hjb_handle)r->part[i]);
     if (r->whole) (void)hjb_destroy((hjb_handle)r->whole);
     delete r;
@@ -3164,6 +3177,9 @@ int32_t hjb_rank_create(const hjb_problem *p, int32_t device, int32_t rank, int3
     range(rank, &r->begin, &r->end);
     r->hlo = std::min(r->need_lo, r->begin);
     r->hhi = std::min(r->need_hi, nl - r->end);
+    r->dtype = p->dtype;
+    r->up_needs = rank + 1 < world ? std::min(r->need_lo, r->end) : 0;        // my top planes -> rank + 1's lower halo
+    r->dn_needs = rank > 0 ? std::min(r->need_hi, nl - r->begin) : 0;         // my bottom planes -> rank - 1's upper halo
     for (int k = 0; k < world; ++k) {            // a halo must come from the immediate neighbour only
         int b, e;
         range(k, &b, &e);
@@ -3238,6 +3254,15 @@ int32_t hjb_rank_info(hjb_rank r, int32_t *out10) {
 
 int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value) {
     if (!r || !key) return rfail(r, HJB_E_INVALID, "null argument");
+    if (!strcmp(key, "comm_loopback")) {      // before hjb_rank_comm_init: the one-GPU transport test (hjbdp.h)
+        if (r->comm) return rfail(r, HJB_E_INVALID, "comm_loopback must be set before hjb_rank_comm_init");
+        r->loopback = value != 0;
+        if (r->loopback) {                    // this rank plays both neighbours: it needs what it would have received
+            r->up_needs = r->hlo;
+            r->dn_needs = r->hhi;
+        }
+        return HJB_OK;
+    }
     Handle *hs[4] = {r->whole, r->part[0], r->part[1], r->part[2]};
     for (Handle *h : hs)
         if (h) {
@@ -3308,6 +3333,221 @@ int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx,
         }
     return HJB_OK;
 #undef RANK_TRY
+}
+
+// ---- RCCL inside the library: the halo exchange and the monitor's all-reduce of a rank, no torch, no MPI ------------------
+// per stage `ncclGroupStart; ncclSend / ncclRecv x <= 4; ncclGroupEnd` on a transfer stream (one xGMI link per
+// neighbour pair), every monitor period a 2-double ncclAllReduce.  librccl is dlopen'ed on first use: libhjbdp carries no link
+// dependency on it (a single-GPU host never loads it; a process that already holds a librccl - torch's - shares it).
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, ncclUniqueIdBytes, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+constexpr int kNcclUint8 = 1, kNcclFloat64 = 8, kNcclSum = 0;      // rccl.h: ncclDataType_t / ncclRedOp_t
+
+bool rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return true;
+    const char *names[] = {getenv("HJBDP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names) {
+        if (!n || !n[0]) continue;
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) { g_rccl.why = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return false; }
+    auto sym = [&](const char *name) -> void * {
+        void *f = dlsym(lib, name);
+        if (!f) g_rccl.why = std::string("librccl lacks ") + name;
+        return f;
+    };
+    RcclApi a;
+    a.GetUniqueId = (int (*)(void *))sym("ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void **, int, ncclUniqueIdBytes, int))sym("ncclCommInitRank");
+    a.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+    a.GroupStart = (int (*)())sym("ncclGroupStart");
+    a.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    a.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))sym("ncclSend");
+    a.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))sym("ncclRecv");
+    a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
+    a.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv || !a.AllReduce ||
+        !a.GetErrorString) {
+        dlclose(lib);
+        return false;
+    }
+    a.lib = lib;
+    a.why = g_rccl.why;
+    g_rccl = a;
+    return true;
+}
+}  // namespace
+
+#define RCCL_TRY(r, expr)                                                                                     \
+    do {                                                                                                      \
+        const int e_ = (expr);                                                                                \
+        if (e_ != 0) return rfail(r, HJB_E_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(e_));        \
+    } while (0)
+#define RANKH_TRY(r, expr)                                                                                    \
+    do {                                                                                                      \
+        const hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return rfail(r, HJB_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+static void rank_comm_release(hjb_rank r) {
+    if (r->comm && g_rccl.lib) (void)g_rccl.CommDestroy(r->comm);
+    r->comm = nullptr;
+    if (r->xfer) (void)hipStreamDestroy(r->xfer);
+    if (r->xready) (void)hipEventDestroy(r->xready);
+    if (r->d_partials) (void)hipFree(r->d_partials);
+    if (r->d_sums) (void)hipFree(r->d_sums);
+    r->xfer = nullptr; r->xready = nullptr; r->d_partials = nullptr; r->d_sums = nullptr;
+}
+
+int32_t hjb_rank_comm_unique_id(void *id128_out) {
+    if (!id128_out) return rfail(nullptr, HJB_E_INVALID, "null argument");
+    if (!rccl_load()) return rfail(nullptr, HJB_E_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why.c_str());
+    RCCL_TRY(nullptr, g_rccl.GetUniqueId(id128_out));
+    return HJB_OK;
+}
+
+int32_t hjb_rank_comm_init(hjb_rank r, const void *id128) {
+    if (!r || !id128) return rfail(r, HJB_E_INVALID, "null argument");
+    if (r->comm) return rfail(r, HJB_E_INVALID, "this rank already has a communicator");
+    if (!rccl_load()) return rfail(r, HJB_E_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why.c_str());
+    RANKH_TRY(r, hipSetDevice(r->device));
+    ncclUniqueIdBytes id;
+    memcpy(id.internal, id128, sizeof id.internal);
+    // loopback (option "comm_loopback", the one-GPU transport test): a communicator of ONE rank, both neighbours = this rank
+    RCCL_TRY(r, g_rccl.CommInitRank(&r->comm, r->loopback ? 1 : r->world, id, r->loopback ? 0 : r->rank));
+    RANKH_TRY(r, hipStreamCreateWithFlags(&r->xfer, hipStreamNonBlocking));
+    RANKH_TRY(r, hipEventCreateWithFlags(&r->xready, hipEventDisableTiming));
+    RANKH_TRY(r, hipMalloc((void **)&r->d_partials, sizeof(double) * 2 * kReduceBlocks));
+    RANKH_TRY(r, hipMalloc((void **)&r->d_sums, sizeof(double) * 2));
+    return HJB_OK;
+}
+
+// The halo exchange of dJ (this rank's haloed J buffer) on the library's transfer stream, ordered behind everything
+// `compute_stream` holds at the time of the call (the stage that wrote dJ).  Returns at once; hjb_rank_stage's halo_stream
+// argument = hjb_rank_transfer_stream(r) makes the boundary strips wait for it (hjb_rank_step does both).
+int32_t hjb_rank_exchange(hjb_rank r, void *dJ, void *compute_stream) {
+    if (!r || !dJ) return rfail(r, HJB_E_INVALID, "null argument");
+    if (!r->comm) return rfail(r, HJB_E_INVALID, "hjb_rank_comm_init first");
+    RANKH_TRY(r, hipSetDevice(r->device));
+    RANKH_TRY(r, hipEventRecord(r->xready, (hipStream_t)compute_stream));
+    RANKH_TRY(r, hipStreamWaitEvent(r->xfer, r->xready, 0));
+    const size_t plane_b = (size_t)r->inner * r->esz;
+    const int owned = r->end - r->begin;
+    char *J = (char *)dJ;
+    const int dn = r->loopback ? 0 : r->rank - 1, up = r->loopback ? 0 : r->rank + 1;
+    if (!(r->dn_needs || r->hlo || r->up_needs || r->hhi)) return HJB_OK;
+    RCCL_TRY(r, g_rccl.GroupStart());
+    int e1 = 0;
+    // towards rank - 1: my lowest owned planes are its upper halo; its top planes are my lower halo
+    if (r->dn_needs && !e1) e1 = g_rccl.Send(J + plane_b * r->hlo, plane_b * r->dn_needs, kNcclUint8, dn, r->comm, r->xfer);
+    if (r->up_needs && !e1) e1 = g_rccl.Send(J + plane_b * (r->hlo + owned - r->up_needs), plane_b * r->up_needs, kNcclUint8, up, r->comm, r->xfer);
+    // loopback: what goes "down" comes back as my own upper halo, what goes "up" as my lower halo (receives posted in the
+    // order the one peer's sends were)
+    if (r->loopback) {
+        if (r->hhi && !e1) e1 = g_rccl.Recv(J + plane_b * (r->hlo + owned), plane_b * r->hhi, kNcclUint8, 0, r->comm, r->xfer);
+        if (r->hlo && !e1) e1 = g_rccl.Recv(J, plane_b * r->hlo, kNcclUint8, 0, r->comm, r->xfer);
+    } else {
+        if (r->hlo && !e1) e1 = g_rccl.Recv(J, plane_b * r->hlo, kNcclUint8, dn, r->comm, r->xfer);
+        if (r->hhi && !e1) e1 = g_rccl.Recv(J + plane_b * (r->hlo + owned), plane_b * r->hhi, kNcclUint8, up, r->comm, r->xfer);
+    }
+    const int e2 = g_rccl.GroupEnd();
+    if (e1 || e2) return rfail(r, HJB_E_DEVICE, "halo exchange: %s", g_rccl.GetErrorString(e1 ? e1 : e2));
+    return HJB_OK;
+}
+
+void *hjb_rank_transfer_stream(hjb_rank r) { return r ? (void *)r->xfer : nullptr; }
+
+// exchange + stage: one call per stage for a host that owns nothing but the two J buffers and the label buffer
+int32_t hjb_rank_step(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream) {
+    if (!r) return rfail(r, HJB_E_INVALID, "null argument");
+    if (r->world > 1 || r->loopback) {
+        const int st = hjb_rank_exchange(r, dJ_in, compute_stream);
+        if (st) return st;
+    }
+    return hjb_rank_stage(r, dJ_in, dJ_out, d_idx, compute_stream, (r->world > 1 || r->loopback) ? (void *)r->xfer : nullptr);
+}
+
+// The monitor's two sums (Solver_pos_att.m:274-275) over the WHOLE grid: this rank's owned planes reduced on the device
+// (fixed tree, float64), then one 2-double ncclAllReduce; sums2 = {sum J, sum labels} on every rank.
+int32_t hjb_rank_monitor_sums(hjb_rank r, const void *dJ, const void *d_idx, void *compute_stream, double *sums2) {
+    if (!r || !dJ || !sums2) return rfail(r, HJB_E_INVALID, "null argument");
+    if (!r->comm) return rfail(r, HJB_E_INVALID, "hjb_rank_comm_init first");
+    RANKH_TRY(r, hipSetDevice(r->device));
+    hipStream_t cs = (hipStream_t)compute_stream;
+    const size_t plane_b = (size_t)r->inner * r->esz;
+    const int64_t n = r->inner * (int64_t)(r->end - r->begin);
+    if (launch_monitor_sums(r->dtype, false, (const char *)dJ + plane_b * r->hlo, d_idx, (int32_t)r->isz, n, r->d_partials, r->d_sums, cs) != HJB_OK)
+        return rfail(r, HJB_E_DEVICE, "monitor reduction launch failed");
+    if (!d_idx) RANKH_TRY(r, hipMemsetAsync(r->d_sums + 1, 0, sizeof(double), cs));
+    RCCL_TRY(r, g_rccl.AllReduce(r->d_sums, r->d_sums, 2, kNcclFloat64, kNcclSum, r->comm, cs));
+    RANKH_TRY(r, hipMemcpyAsync(sums2, r->d_sums, 2 * sizeof(double), hipMemcpyDeviceToHost, cs));
+    RANKH_TRY(r, hipStreamSynchronize(cs));
+    return HJB_OK;
+}
+
+// The whole backward sweep of a rank: terminal cost in dJ0 (haloed layout, owned planes filled), per stage exchange + stage
+// ping-ponging dJ0 / dJ1, the monitor every `monitor_period` stages (the same stop decision on every rank: the sums are
+// all-reduced).  *final_in_0 says which buffer holds the last stage.  What SURVEY 8b (iii)'s C++ driver (tools/bench_ranks.cpp)
+// and a MATLAB worker per GPU call.
+int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, double monitor_tol, void *dJ0, void *dJ1, void *d_idx,
+                       void *compute_stream, int32_t *stages_done, int32_t *stopped_early, int32_t *final_in_0, double *sweep_ms) {
+    if (!r || !dJ0 || !dJ1 || n_stages < 0) return rfail(r, HJB_E_INVALID, "bad argument");
+    if (r->world > 1 && !r->comm) return rfail(r, HJB_E_INVALID, "hjb_rank_comm_init first (world > 1)");
+    if (monitor_period > 0 && !r->comm) return rfail(r, HJB_E_INVALID, "the monitor needs a communicator (hjb_rank_comm_init), also at world == 1");
+    RANKH_TRY(r, hipSetDevice(r->device));
+    hipStream_t cs = (hipStream_t)compute_stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    RANKH_TRY(r, hipEventCreate(&e0));
+    RANKH_TRY(r, hipEventCreate(&e1));
+    RANKH_TRY(r, hipEventRecord(e0, cs));
+    void *J[2] = {dJ0, dJ1};
+    int cur = 0, done = 0, early = 0, st = HJB_OK;
+    double fprev = 0.0;
+    for (int k_s = n_stages; k_s >= 1 && !st; --k_s) {
+        st = hjb_rank_step(r, J[cur], J[1 - cur], d_idx, compute_stream);
+        if (st) break;
+        cur = 1 - cur;
+        ++done;
+        if (monitor_period > 0 && (k_s % monitor_period) == 0) {
+            double sums[2];
+            st = hjb_rank_monitor_sums(r, J[cur], d_idx, compute_stream, sums);
+            if (st) break;
+            const double e = sums[0] - fprev;
+            fprev = sums[0];
+            if (std::fabs(e) < monitor_tol) { early = 1; break; }
+        }
+    }
+    if (!st) {
+        (void)hipEventRecord(e1, cs);
+        if (hipEventSynchronize(e1) != hipSuccess) st = rfail(r, HJB_E_DEVICE, "sweep: synchronisation failed");
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (sweep_ms) *sweep_ms = ms;
+        if (!st) st = hjb_rank_check_status(r, compute_stream);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (stages_done) *stages_done = done;
+    if (stopped_early) *stopped_early = early;
+    if (final_in_0) *final_in_0 = cur == 0;
+    return st;
 }
 
 // ---- device-buffer helpers -------------------------------------------------------------------------------------------

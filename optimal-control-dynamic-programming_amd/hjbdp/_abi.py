@@ -184,6 +184,14 @@ SYMBOLS = {
     # one process per GPU: a rank's slab as interior + boundary strips
     "hjb_rank_create": (C.c_int32, [C.POINTER(hjb_problem), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "hjb_rank_create_from": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hjb_rank_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "hjb_rank_comm_init": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "hjb_rank_exchange": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_rank_transfer_stream": (C.c_void_p, [C.c_void_p]),
+    "hjb_rank_step": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_rank_monitor_sums": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "hjb_rank_sweep": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "hjb_rank_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hjb_rank_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_rank_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),

@@ -465,3 +465,112 @@ def test_rank_create_from_builder_equals_struct_form(env):
         assert np.array_equal(Jo, Jr.reshape(inner, nl, order="F")[:, begin:end])
         assert np.array_equal(io.reshape(inner, end - begin, order="F"), ir.reshape(inner, nl, order="F")[:, begin:end])
         assert lib.hjb_rank_destroy(r) == _abi.HJB_OK
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rccl_transport_inside_the_library_loopback(env, overlap):
+    """hjb_rank_comm_init / hjb_rank_exchange / hjb_rank_step / hjb_rank_monitor_sums: the RCCL calls of a middle rank
+    (ncclGroupStart, two ncclSend, two ncclRecv, ncclGroupEnd on the library's transfer stream; a 2-double ncclAllReduce)
+    executed for real on this box's ONE GPU through the loopback option - a communicator of one rank that is both of its
+    neighbours: the planes it sends down arrive in its own upper halo, those it sends up in its lower halo.  After the
+    exchange the halos hold exactly those planes, and the stage that follows (interior beside the transfer, strips behind
+    it) equals the oracle's backup of that buffer bit for bit."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, random_terminal
+    spec0 = colsweep_problem(15, (36, 7, 9, 14), gax=2)
+    spec = hjbdp.ProblemSpec(spec0.knots, spec0.m, spec0.next_terms, spec0.cost_terms, dtype=np.float32, index_base=1, idx_dtype="auto")
+    inner = spec.nS // spec.n[-1]
+    rk = hjbdp.core.RankSlab(spec, 0, 1, 3, overlap=overlap)
+    lib = rk.lib
+    assert rk.halo_lo > 0 and rk.halo_hi > 0 and rk.split == (1 if overlap else 0)
+    owned, hlo, hhi = rk.end - rk.begin, rk.halo_lo, rk.halo_hi
+    planes = owned + hlo + hhi
+    rk.set_option("comm_loopback", 1)
+    uid = (C.c_char * 128)()
+    assert lib.hjb_rank_comm_unique_id(uid) == _abi.HJB_OK, lib.hjb_rank_last_error(None)
+    assert lib.hjb_rank_comm_init(rk._r, uid) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
+    assert lib.hjb_rank_transfer_stream(rk._r)
+    rng = np.random.default_rng(5)
+    init = (rng.random((inner, planes)) * 3).astype(np.float32)
+    with hjbdp.DeviceBuffer(init.nbytes) as dIn, hjbdp.DeviceBuffer(init.nbytes) as dOut, \
+            hjbdp.DeviceBuffer(inner * owned * rk.idx_bytes) as dI:
+        dIn.upload(np.asfortranarray(init).reshape(-1, order="F"))
+        dOut.upload(np.asfortranarray(init).reshape(-1, order="F"))
+        assert lib.hjb_rank_exchange(rk._r, int(dIn), None) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
+        rk.check_device_status(lib.hjb_rank_transfer_stream(rk._r))          # synchronises the transfer stream
+        got = dIn.download(np.float32).reshape(inner, planes, order="F")
+        want = init.copy()
+        want[:, :hlo] = init[:, hlo + owned - hlo:hlo + owned]               # sent "up", came back as my lower halo
+        want[:, hlo + owned:] = init[:, hlo:hlo + hhi]                       # sent "down", came back as my upper halo
+        assert np.array_equal(got, want)
+        # exchange + stage in one call; the oracle backs the exchanged buffer up as this rank's slab
+        dIn.upload(np.asfortranarray(init).reshape(-1, order="F"))
+        assert lib.hjb_rank_step(rk._r, int(dIn), int(dOut), int(dI), None) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
+        rk.check_device_status()
+        Jo, io = c_oracle.backup_stage(_abi, spec, np.asfortranarray(want).reshape(-1, order="F"), slab=(rk.begin, rk.end, hlo, hhi))
+        mine = dOut.download(np.float32).reshape(inner, planes, order="F")[:, hlo:hlo + owned]
+        assert np.array_equal(mine, Jo.reshape(inner, planes, order="F")[:, hlo:hlo + owned])
+        assert np.array_equal(dI.download(spec.idx_np_dtype), io)
+        # the monitor's two sums through ncclAllReduce (one rank: the local sums)
+        sums = (C.c_double * 2)()
+        assert lib.hjb_rank_monitor_sums(rk._r, int(dOut), int(dI), None, sums) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
+        assert abs(sums[0] - float(mine.astype(np.float64).sum())) <= 1e-9 * abs(sums[0])
+        assert sums[1] == float(io.astype(np.float64).sum())
+    rk.close()
+
+
+def test_rank_sweep_whole_loop_in_the_library(env):
+    """hjb_rank_sweep (what tools/bench_ranks.cpp and a MATLAB worker per GPU call): the `for k_s` loop of one rank with
+    the monitor's all-reduced sums; at world = 1 it must be hjb_solve's sweep - same J, same labels, same stop stage."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, random_terminal
+    spec0 = colsweep_problem(16, (40, 7, 8, 9), gax=3)
+    spec = hjbdp.ProblemSpec(spec0.knots, spec0.m, spec0.next_terms, spec0.cost_terms, dtype=np.float32, index_base=1, idx_dtype="auto")
+    term = random_terminal(spec, 4)
+    rk = hjbdp.core.RankSlab(spec, 0, 0, 1)
+    lib = rk.lib
+    uid = (C.c_char * 128)()
+    assert lib.hjb_rank_comm_unique_id(uid) == _abi.HJB_OK, lib.hjb_rank_last_error(None)
+    assert lib.hjb_rank_comm_init(rk._r, uid) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
+    for tol in (0.0, 1e30):                                   # never stops / stops at the first monitor point
+        ref = c_oracle.sweep(_abi, spec, 9, terminal=term, monitor_period=3, monitor_tol=tol)
+        with hjbdp.DeviceBuffer(spec.nS * 4) as d0, hjbdp.DeviceBuffer(spec.nS * 4) as d1, hjbdp.DeviceBuffer(spec.nS * rk.idx_bytes) as dI:
+            d0.upload(term)
+            done, early, in0, ms = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+            st = lib.hjb_rank_sweep(rk._r, 9, 3, tol, int(d0), int(d1), int(dI), None, C.byref(done), C.byref(early), C.byref(in0), C.byref(ms))
+            assert st == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
+            assert (done.value, bool(early.value)) == (ref["stages_done"], ref["stopped_early"])
+            J = (d0 if in0.value else d1).download(np.float32)
+            assert np.array_equal(J, ref["J"]) and np.array_equal(dI.download(spec.idx_np_dtype), ref["idx"])
+            assert ms.value > 0
+    rk.close()
+
+
+@pytest.mark.watchdog(600)
+def test_cpp_rank_driver_matches_the_python_path(env):
+    """tools/bench_ranks.cpp (SURVEY 8b iii: a C++ driver, one process per GPU, RCCL inside the library, no Python in the
+    loop): built here with g++ against the in-tree libhjbdp.so and run as one rank on a 34^4 pos-att grid.  It states the
+    problem in C++ through the flat builder; the sum of J after 1 + 12 stages must equal hjb_solve's on bench.py's spec of
+    the same grid (the same operands bit for bit, or the sums would differ), and the JSON line carries bench.py's keys."""
+    import json
+    import subprocess
+    hjbdp, _abi, c_oracle = env
+    import bench
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run(["bash", str(root / "tools" / "build_bench_ranks.sh")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = subprocess.run([str(root / "tools" / "bench_ranks"), "--gpus", "1", "--steps", "12", "--warmup", "1", "--grid-n", "34"],
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-2000:])
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "checksum_sum_J"):
+        assert key in line, key
+    assert line["metric"] == "bellman_backups_per_s" and line["n_gpus"] == 1 and line["steps"] == 12 and line["config"]["kernel_variant"] == 7
+    spec, _ = bench.build_spec("c4", n=34)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 7
+        out = bk.solve(13)
+    want = float(out["J"].astype(np.float64).sum())
+    assert abs(line["checksum_sum_J"] - want) <= 1e-11 * abs(want), (line["checksum_sum_J"], want)
+    assert abs(line["value"] - 34 ** 4 * 9 * 12 / (line["ms_per_step"] * 12e-3)) <= 1e-5 * line["value"]
