@@ -261,7 +261,7 @@ def run_c3(args, steps, warmup, dev, n=51):
         wall = time.perf_counter() - t0
         bk.check_device_status(stream)
     dev_ms = ev0.elapsed_time(ev1)
-    cs = float(J[k & 1].sum(dtype=torch.float64))          # float64 accumulation, no 141 GB temporary
+    cs = sum(float(c.double().sum()) for c in J[k & 1].split(1 << 28))      # float64 sums of 1 GiB pieces: no 141 GB temporary
     del J, idx
     torch.cuda.empty_cache()
     return {"spec": spec, "name": name, "info": info, "wall": wall, "dev_ms": dev_ms, "steps": steps, "states_rank": spec.nS,
@@ -404,10 +404,17 @@ def main():
         gbs = bytes_state * res["states_rank"] / (launch_ms * 1e-3) / 1e9
         kname = KERNEL_OF_VARIANT.get(inf["kernel_variant"], "k_backup")
         pmc = (pmc_all or {}).get(workload)
-        traffic = valu_util = None
+        traffic = traffic_raw = valu_util = None
         if pmc:
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # rocprofv3 reports KiB
+                # rocprofv3 reports KiB.  On gfx950 FETCH_SIZE tallies the L2's 128-byte fabric requests at 64 bytes
+                # (MI355X_MICROARCH.md, HBM: "double it before comparing with a byte count"); calibrated on THIS library's
+                # access shapes - 4 / 8 / 16 bytes per lane, streamed and at scattered rows, each byte of 2 GiB read once:
+                # FETCH_SIZE = 0.5000 x bytes in all six (tools/fetch_calib.hip, profiles/r04_fetch_calib.json).  64-byte
+                # requests (re-reads of small L2-evicted pieces) would be counted in full, so the corrected figure is an
+                # upper bound and the uncorrected one a lower bound of the bytes fetched.
+                traffic_raw = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+                traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
             if "SQ_INSTS_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
                 cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                                   # summed over the 8 XCDs
                 valu_util = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_WAVE_INSTR / (1024.0 * cyc)
@@ -419,7 +426,8 @@ def main():
             if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES"):
                 wait_frac = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
         rf = {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
-              "traffic": traffic, "kernel": kname, "avg_launch_ms": launch_ms, "alg_flop_per_backup": f_alg(sp.D),
+              "traffic": traffic, "traffic_uncorrected": traffic_raw, "kernel": kname, "avg_launch_ms": launch_ms,
+              "alg_flop_per_backup": f_alg(sp.D),
               "alg_bytes_per_launch": bytes_state * res["states_rank"], "valu_issue_util": valu_util,
               "valu_busy": valu_busy, "waves_waiting_frac": wait_frac, "pmc": pmc,
               "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "alg_bytes_per_state": bytes_state}}
@@ -442,7 +450,9 @@ def main():
     kname = rf["kernel"]
     rf["pmc_source"] = ("rocprofv3 --pmc passes made by this run on `bench.py --pmc-child --workload %s --steps 3` (one child per "
                         "counter set, every workload of this line in it; mean per launch of each stage kernel; FETCH_SIZE / "
-                        "WRITE_SIZE in KiB, dword-per-lane accesses count 1x)" % args.workload) if pmc_all else pmc_note
+                        "WRITE_SIZE in KiB; traffic = 2 x FETCH_SIZE + WRITE_SIZE: gfx950 tallies 128-byte fabric reads at 64 bytes - "
+                        "0.5000 x bytes on every access shape of this library, profiles/r04_fetch_calib.json; traffic_uncorrected = "
+                        "FETCH_SIZE + WRITE_SIZE is the lower bound)" % args.workload) if pmc_all else pmc_note
     rf["note"] = ("fp32 VALU binds (SURVEY 8d), not HBM and not MFMA (interpolation is a gather; K = D <= 6); peak = fp32 vector "
                   "peak = f32-input MFMA peak.  achieved = ALGORITHMIC flops (F_alg(D) per backup) / launch time; the "
                   "kernel shares the control-independent lerps between the controls, so it executes fewer.  "

@@ -115,6 +115,18 @@ typedef struct hjb_problem {
                                        serve such a problem.  cost_terms stay arrays of the problem dtype. */
     double model_h;
     const void *model_tables[4];
+    int32_t cost_dtype;             /* HJB_COST_DEFAULT (0): cost_terms are arrays of the problem dtype, summed in it.
+                                       HJB_COST_F64 (dtype HJB_F32 / HJB_F16S, no state model): the data of every
+                                       cost_terms entry are float64 and the stage cost of a (state, control) is the ordered
+                                       sum of the terms IN DOUBLE, rounded to float32 ONCE - the reference's
+                                       J_current_M = single(Qx*x.^2 + Qv*v.^2 + Qw*w.^2 + Qt*t.^2 + (R*f1.^2 + ...))
+                                       (Solver_pos_att.m:800-801: a double expression under implicit expansion, one cast)
+                                       without the [n_x,n_v,n_t,n_w,nU] array: bit-identical to passing that array as one
+                                       term, at any grid size.  The state part is summed once per state, each control adds
+                                       its part in double and rounds.  Served by the table-driven kernel (variant 5) and
+                                       the column sweep (variant 7, state terms + one control term); ~10 % slower than
+                                       float32 terms on C4. */
+    int32_t reserved_;
 } hjb_problem;
 
 #define HJB_IDX_I32 0
@@ -124,6 +136,9 @@ typedef struct hjb_problem {
 
 #define HJB_TAB_DEFAULT 0
 #define HJB_TAB_F64 1
+
+#define HJB_COST_DEFAULT 0
+#define HJB_COST_F64 1
 
 #define HJB_MODEL_NONE 0
 #define HJB_MODEL_QUAT_EULER321 1
@@ -201,6 +216,8 @@ typedef struct hjb_info {
     int32_t halo_needed_hi;
     int32_t idx_bytes;       /* bytes per stored argmin label: 4, 1 or 2 (hjb_problem.idx_dtype resolved) */
     int32_t table_dtype;     /* HJB_TAB_* in effect                                     */
+    int32_t cost_dtype;      /* HJB_COST_* in effect                                    */
+    int32_t reserved_;
 } hjb_info;
 
 const char *hjb_version(void);
@@ -315,6 +332,9 @@ int32_t hjb_problem_set_slab(hjb_builder b, int32_t slab_begin, int32_t slab_end
 /* hjb_problem.idx_dtype (HJB_IDX_*) and hjb_problem.table_dtype (HJB_TAB_*).  Call it right after hjb_problem_new:
  * with HJB_TAB_F64 the `data` of every hjb_problem_add_next_term that follows is float64 (cost terms stay float). */
 int32_t hjb_problem_set_types(hjb_builder b, int32_t idx_dtype, int32_t table_dtype);
+/* hjb_problem.cost_dtype (HJB_COST_*): call it before the first hjb_problem_add_cost_term - under HJB_COST_F64 the cost
+ * terms' data are float64 */
+int32_t hjb_problem_set_cost_type(hjb_builder b, int32_t cost_dtype);
 int32_t hjb_problem_set_model(hjb_builder b, int32_t model, double model_h, const void *t0, const void *t1,
                               const void *t2, const void *t3);
 /* Relabel the state axes of a problem under construction: new axis i = old axis order[i] (terms over several state
@@ -403,7 +423,9 @@ const char *hjb_rank_last_error(hjb_rank r);
  * boundary strips waiting for the halos.  hjb_rank_monitor_sums: sum J and sum of labels over the WHOLE grid on every rank.
  * Option "comm_loopback" (hjb_rank_set_option before hjb_rank_comm_init; one-GPU transport test): a communicator of one
  * rank whose two neighbours are itself - the planes it sends down arrive in its own upper halo, those it sends up in its
- * lower halo - so the RCCL calls, pointers, counts and stream ordering run on a box with a single GPU.
+ * lower halo - so the RCCL calls, pointers, counts and stream ordering run on a box with a single GPU.  Option
+ * "xfer_delay_us" (emulation only, tools/emulate_ranks.py): a spin of that many microseconds on the transfer stream behind
+ * every exchange, standing in for link latency the one-GPU loopback does not have.
  * tools/bench_ranks.cpp is a C++ driver on these calls (one process per GPU, no Python). */
 int32_t hjb_rank_comm_unique_id(void *id128_out);
 int32_t hjb_rank_comm_init(hjb_rank r, const void *id128);

@@ -22,6 +22,7 @@ int32_t hjb_problem_add_next_term(void *builder, int32_t axis, uint32_t mask, co
 int32_t hjb_problem_add_cost_term(void *builder, uint32_t mask, const void *data, int64_t count);
 int32_t hjb_problem_set_slab(void *builder, int32_t slab_begin, int32_t slab_end, int32_t halo_lo, int32_t halo_hi);
 int32_t hjb_problem_set_types(void *builder, int32_t idx_dtype, int32_t table_dtype);
+int32_t hjb_problem_set_cost_type(void *builder, int32_t cost_dtype);
 int32_t hjb_problem_set_model(void *builder, int32_t model, double model_h, const void *t0, const void *t1, const void *t2, const void *t3);
 int32_t hjb_problem_permute_axes(void *builder, const int32_t *order);
 int32_t hjb_problem_suggest_order(void *builder, int32_t *order_out, int32_t *found);

@@ -69,6 +69,7 @@ struct Handle {
     char *d_idx = nullptr;        // argmin labels of the owned states, idx_bytes each
     int idx_bytes = 4;            // hjb_problem.idx_dtype resolved: 4 (int32), 1 (uint8) or 2 (uint16)
     bool tab64 = false;           // hjb_problem.table_dtype == HJB_TAB_F64: (cell, t) tables built in float64 from float64 terms
+    bool cost64 = false;          // hjb_problem.cost_dtype == HJB_COST_F64: cost terms float64, summed in double, one rounding per backup
     DParams *dp64 = nullptr;      // ... the float64 shadow of the axes (knots, 1/dx, next-state terms) the table build reads
     double *d_partials = nullptr;  // monitor reduction scratch
     double *d_sums = nullptr;      // [2]: sum J, sum idx
@@ -122,6 +123,7 @@ struct Handle {
     int cs_xcd_axis = 0;          // option "cs_xcd_axis": 0 = the XCDs split the group axis, 1 = the window axis
     int cs_split = 0;             // option "cs_split": parts a column is swept in (0 = automatic, see colsweep_split)
     int cs_coop = 0;              // option "cs_coop": allow the cooperative form (kernels_colcoop.h) where it applies
+    std::vector<double> cs_cu64;  // cost_dtype F64: the control term of the cost in float64, per control (plan building)
     int cs_coop_why = 0;          // why it does not: 1 groups, 2 axis 1 sees the window axis, 3 n0 / storage, 4 cells, 5 window knots, 6 axis-0 knots
     int cs_coop_epl = 0;          // ... it applies: elements per staging load (0 = does not apply)
     int cc_grid = 0;              // its launch grid
@@ -399,8 +401,12 @@ int build(Handle *h, const hjb_problem *p) {
         int npre = 0;
         while (npre < P.n_cost && (p->cost_terms[npre].mask & ~state_mask) == 0) ++npre;
         P.n_cost_prefix = npre;
+        P.cost_f64 = h->cost64 ? 1 : 0;
         for (int k = 0; k < P.n_cost; ++k) {
-            int st = make_term<T>(h, p, p->cost_terms[k], &P.cost[k]);
+            // cost_dtype F64: the caller's cost terms are float64.  The float32 copy serves the host-side structure analysis
+            // only (no stage kernel that sums the cost in float32 is admitted); the kernels read the float64 copy
+            int st = h->cost64 ? make_term<T, double>(h, p, p->cost_terms[k], &P.cost[k]) : make_term<T>(h, p, p->cost_terms[k], &P.cost[k]);
+            if (!st && h->cost64) st = make_term<double, double>(h, p, p->cost_terms[k], &P.cost64[k]);
             if (st) return st;
         }
     }
@@ -740,6 +746,9 @@ int build(Handle *h, const hjb_problem *p) {
         h->tabled_ok = false;     // the other stage kernels do not evaluate the model
         h->nested_fast = false;
     }
+    if (h->cost64 && !h->tabled_ok)
+        return fail(h, HJB_E_UNSUPPORTED, "cost_dtype HJB_COST_F64 is served by the table-driven kernels (variants 5, 7): this grid's per-axis "
+                    "(cell, weight) tables do not fit - pass the cost terms in float32 (cost_dtype HJB_COST_DEFAULT)");
     if (h->tab64 && !h->tabled_ok)
         return fail(h, HJB_E_UNSUPPORTED, "table_dtype HJB_TAB_F64 needs the per-axis (cell, weight) tables to fit (variants 5-7): this grid's tables do not - "
                     "pass table_dtype = HJB_TAB_DEFAULT (Python mirrors: table_dtype=None) to run it on float32 queries");
@@ -1031,6 +1040,7 @@ bool colsweep_plan(Handle *h, int gax, const std::vector<TabEntry<T>> (&tab)[2],
                         sl[1] = bits(tt[gax - 2][u]);
                         sl[3] = u;
                         for (size_t k = 0; k < cu.size(); ++k) sl[k == 0 ? 2 : 3 + k] = bits(cu[k][(size_t)u]);
+                        if (!h->cs_cu64.empty()) memcpy(&sl[4], &h->cs_cu64[(size_t)u], sizeof(double));
                     }
                 }
                 q[1 + kCsGMax + g] = usedbits | (nw << 8);
@@ -1256,6 +1266,11 @@ int ensure_colsweep_t(Handle *h) {
     std::vector<std::vector<T>> cu((size_t)ncu, std::vector<T>((size_t)h->nU));
     for (int k = 0; k < ncu; ++k)
         HIP_TRY(h, hipMemcpy(cu[(size_t)k].data(), P.cost[P.n_cost_prefix + k].data, (size_t)h->nU * sizeof(T), hipMemcpyDeviceToHost));
+    h->cs_cu64.clear();
+    if (h->cost64 && ncu == 1) {       // the one control term in float64: a slot carries it in words 4, 5 (cost form 2)
+        h->cs_cu64.resize((size_t)h->nU);
+        HIP_TRY(h, hipMemcpy(h->cs_cu64.data(), P.cost64[P.n_cost_prefix].data, (size_t)h->nU * sizeof(double), hipMemcpyDeviceToHost));
+    }
     // group by the axis that leaves fewer corner rows to load
     std::vector<int32_t> plan[2];
     int64_t rows[2] = {0, 0};
@@ -1393,6 +1408,8 @@ void choose_launch(Handle *h) {
         h->variant = h->forced_variant >= 0 ? h->forced_variant : (cs_auto ? 7 : (h->row_auto ? 6 : (h->tabled_ok ? 5 : 0)));
     if (h->variant == 7 && h->cs_state != 1) h->variant = h->row_ok ? 6 : (h->tabled_ok ? 5 : 0);
     if (h->tab64 && h->variant < 5) h->variant = 5;       // float64-built tables: the table-driven kernels only (tabled_ok holds)
+    // float64 cost terms: the tabled kernel, or the column sweep in its usual cost shape (state terms + one control term)
+    if (h->cost64 && !(h->variant == 5 || (h->variant == 7 && h->hcs.ncu == 1 && h->hp.n_cost_prefix > 0 && !h->hcs.coop))) h->variant = 5;
     // build the variant 5/6 tables now (never inside a launch: launches may be under graph capture)
     h->launch_status = HJB_OK;
     if ((h->variant == 5 || h->variant == 6) && (h->launch_status = ensure_tabled(h)) != HJB_OK) {
@@ -1453,17 +1470,21 @@ int launch_stage(Handle *h, const void *dJn, void *dJo, void *didx, hipStream_t 
     if (h->tab64 && (h->variant < 5 || h->launch_status != HJB_OK))
         return fail(h, h->launch_status != HJB_OK ? h->launch_status : HJB_E_UNSUPPORTED,
                     "table_dtype HJB_TAB_F64 is served by the table-driven kernels only (variant %d, table build status %d)", h->variant, h->launch_status);
+    if (h->cost64 && h->variant != 5 && h->variant != 7)
+        return fail(h, HJB_E_UNSUPPORTED, "cost_dtype HJB_COST_F64 is served by stage kernels 5 and 7 only (variant %d)", h->variant);
     switch (h->variant) {
         case 7: {
             if (!h->dtb || !h->dcs) return fail(h, HJB_E_DEVICE, "variant 7 plan missing");
             if (!f32) return fail(h, HJB_E_UNSUPPORTED, "variant 7 is float32 arithmetic only");
             const bool fastcost = h->hcs.ncu == 1 && h->hp.n_cost_prefix > 0;    // state terms + one control term
+            if (h->cost64 && !fastcost) return fail(h, HJB_E_UNSUPPORTED, "variant 7 sums float64 cost terms in its usual cost shape only");
+            const int costform = h->cost64 ? 2 : (fastcost ? 1 : 0);
             // cooperative form: its staging loads are 16 bytes wide (a J pointer handed in unaligned runs the other form)
-            if (h->hcs.coop && h->cc_grid > 0 && h->hcs.ng <= kCcNCG && ((uintptr_t)dJn & 15u) == 0) {
+            if (!h->cost64 && h->hcs.coop && h->cc_grid > 0 && h->hcs.ng <= kCcNCG && ((uintptr_t)dJn & 15u) == 0) {
                 a.grid = (unsigned)h->cc_grid;
                 miss = stage_colcoop(a, h->hcs.gax, h->hcs.ng, fastcost);
             } else {
-                miss = stage_colsweep(a, h->hcs.gax, h->hcs.ng, fastcost, h->hcs.dpp != 0);
+                miss = stage_colsweep(a, h->hcs.gax, h->hcs.ng, costform, h->hcs.dpp != 0);
             }
             if (miss) return fail(h, HJB_E_DEVICE, "variant 7: %d groups", h->hcs.ng);
             break;
@@ -1549,6 +1570,7 @@ int check_status(Handle *h, hipStream_t st) {
 int make_probe(Handle *h, const hjb_probe *pb, DProbe *out) {
     if (h->hp.model) return fail(h, HJB_E_UNSUPPORTED, "the probe block is not available for problems with a state model");
     if (h->tab64) return fail(h, HJB_E_UNSUPPORTED, "the probe block reports float32 next states; not available with table_dtype HJB_TAB_F64");
+    if (h->cost64) return fail(h, HJB_E_UNSUPPORTED, "the probe block reports the float32 stage cost; not available with cost_dtype HJB_COST_F64");
     memset(out, 0, sizeof *out);
     int64_t B = 1;
     for (int a = 0; a < h->hp.D; ++a) {
@@ -1698,6 +1720,9 @@ static int analyse_problem(const hjb_problem *p, int *idx_bytes_out, int64_t *n_
     }
     if (p->idx_dtype < HJB_IDX_I32 || p->idx_dtype > HJB_IDX_AUTO) return fail(nullptr, HJB_E_INVALID, "idx_dtype %d", p->idx_dtype);
     if (p->table_dtype != HJB_TAB_DEFAULT && p->table_dtype != HJB_TAB_F64) return fail(nullptr, HJB_E_INVALID, "table_dtype %d", p->table_dtype);
+    if (p->cost_dtype != HJB_COST_DEFAULT && p->cost_dtype != HJB_COST_F64) return fail(nullptr, HJB_E_INVALID, "cost_dtype %d", p->cost_dtype);
+    if (p->cost_dtype == HJB_COST_F64 && (p->dtype == HJB_F64 || p->model))
+        return fail(nullptr, HJB_E_INVALID, "cost_dtype HJB_COST_F64 is for float32 arithmetic without a state model (a float64 problem sums its cost in float64 anyway)");
     if (p->table_dtype == HJB_TAB_F64 && (p->dtype == HJB_F64 || p->model))
         return fail(nullptr, HJB_E_INVALID, "table_dtype HJB_TAB_F64 is for float32 arithmetic without a state model (a float64 problem is float64 throughout)");
     const int G = p->D + p->C;
@@ -1772,6 +1797,7 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
     h->device = device;
     h->idx_bytes = idx_bytes;
     h->tab64 = p->table_dtype == HJB_TAB_F64;
+    h->cost64 = p->cost_dtype == HJB_COST_F64;
     h->dtype = p->dtype;
     h->esz = p->dtype == HJB_F16S ? 2 : (p->dtype == HJB_F32 ? 4 : 8);
     h->prob = *p;
@@ -1839,6 +1865,8 @@ int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
     info->halo_needed_hi = h->halo_need_hi;
     info->idx_bytes = h->idx_bytes;
     info->table_dtype = h->tab64 ? HJB_TAB_F64 : HJB_TAB_DEFAULT;
+    info->cost_dtype = h->cost64 ? HJB_COST_F64 : HJB_COST_DEFAULT;
+    info->reserved_ = 0;
     return HJB_OK;
 }
 
@@ -1864,6 +1892,9 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         if (h->tab64 && value >= 0 && value <= 4)
             return fail(h, HJB_E_UNSUPPORTED, "variant %lld evaluates the next-state terms in the kernel, in float32; a problem with "
                         "table_dtype HJB_TAB_F64 runs on the table-driven kernels (5, 6, 7)", (long long)value);
+        if (h->cost64 && value >= 0 && value != 5 && value != 7)
+            return fail(h, HJB_E_UNSUPPORTED, "variant %lld sums the stage cost in float32; a problem with cost_dtype HJB_COST_F64 runs on "
+                        "the tabled kernel (5) or the column sweep (7)", (long long)value);
         if (h->hp.model && value != -1 && value != 4)
             return fail(h, HJB_E_UNSUPPORTED, "a problem with a state model runs on variant 4 only");
         if (value == 5 && !h->tabled_ok)
@@ -2150,7 +2181,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     const bool graph_ok = h->use_graph && !dJst && !dIst && !o->probe && !every_stage && o->n_stages >= 2 * kGraphStages;
     // K9: several stages per launch for local 2-D problems (no per-stage outputs, no monitor read-backs)
     bool tiled = false;
-    if (h->use_temporal && !dJst && !dIst && !o->probe && !every_stage && o->monitor_period <= 0 && o->n_stages >= 2 * kTileK && h->forced_variant < 0) {
+    if (h->use_temporal && !h->cost64 && !dJst && !dIst && !o->probe && !every_stage && o->monitor_period <= 0 && o->n_stages >= 2 * kTileK && h->forced_variant < 0) {
         if (h->tile2d < 0) {
             const int tst = examine_tile2d(h);
             if (tst) { cleanup(); return tst; }
@@ -2411,7 +2442,17 @@ int32_t hjb_problem_set_knots(hjb_builder b, int32_t axis, const double *knots, 
 
 // bytes per element of a term array the caller hands in: next-state terms are float64 under table_dtype HJB_TAB_F64
 static size_t term_esz(const hjb_problem &p, bool next_term) {
-    return (p.dtype == HJB_F64 || (next_term && p.table_dtype == HJB_TAB_F64)) ? 8 : 4;
+    return (p.dtype == HJB_F64 || (next_term && p.table_dtype == HJB_TAB_F64) || (!next_term && p.cost_dtype == HJB_COST_F64)) ? 8 : 4;
+}
+
+int32_t hjb_problem_set_cost_type(hjb_builder b, int32_t cost_dtype) {
+    if (!b) return bfail(b, HJB_E_INVALID, "null builder");
+    if (cost_dtype != HJB_COST_DEFAULT && cost_dtype != HJB_COST_F64) return bfail(b, HJB_E_INVALID, "cost_dtype %d", cost_dtype);
+    if (cost_dtype == HJB_COST_F64 && b->p.dtype == HJB_F64) return bfail(b, HJB_E_INVALID, "cost_dtype HJB_COST_F64 is for float32 arithmetic");
+    if (cost_dtype != b->p.cost_dtype && b->p.n_cost_terms)
+        return bfail(b, HJB_E_INVALID, "set the cost dtype before adding cost terms (it is their element type)");
+    b->p.cost_dtype = cost_dtype;
+    return HJB_OK;
 }
 
 int32_t hjb_problem_set_types(hjb_builder b, int32_t idx_dtype, int32_t table_dtype) {
@@ -3116,6 +3157,7 @@ struct hjb_rank_s {
     double *d_partials = nullptr, *d_sums = nullptr;
     bool loopback = false;
     int dtype = HJB_F32, up_needs = 0, dn_needs = 0;
+    int64_t xfer_delay_ticks = 0;     // option "xfer_delay_us": a spin of that length behind every exchange (link-latency emulation)
 };
 
 static int rfail(hjb_rank r, int code, const char *fmt, ...) {
@@ -3254,6 +3296,12 @@ int32_t hjb_rank_info(hjb_rank r, int32_t *out10) {
 
 int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value) {
     if (!r || !key) return rfail(r, HJB_E_INVALID, "null argument");
+    if (!strcmp(key, "xfer_delay_us")) {      // emulation only: every halo exchange takes this much longer (tools/emulate_ranks.py)
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess || khz <= 0) khz = 100000;
+        r->xfer_delay_ticks = value > 0 ? value * (int64_t)khz / 1000 : 0;
+        return HJB_OK;
+    }
     if (!strcmp(key, "comm_loopback")) {      // before hjb_rank_comm_init: the one-GPU transport test (hjbdp.h)
         if (r->comm) return rfail(r, HJB_E_INVALID, "comm_loopback must be set before hjb_rank_comm_init");
         r->loopback = value != 0;
@@ -3406,6 +3454,12 @@ bool rccl_load() {
         if (e_ != hipSuccess) return rfail(r, HJB_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
 
+// a fixed wall-clock delay on a stream (wall_clock64: the constant-rate counter): option "xfer_delay_us"
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 static void rank_comm_release(hjb_rank r) {
     if (r->comm && g_rccl.lib) (void)g_rccl.CommDestroy(r->comm);
     r->comm = nullptr;
@@ -3469,6 +3523,7 @@ int32_t hjb_rank_exchange(hjb_rank r, void *dJ, void *compute_stream) {
     }
     const int e2 = g_rccl.GroupEnd();
     if (e1 || e2) return rfail(r, HJB_E_DEVICE, "halo exchange: %s", g_rccl.GetErrorString(e1 ? e1 : e2));
+    if (r->xfer_delay_ticks > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, r->xfer, (long long)r->xfer_delay_ticks);
     return HJB_OK;
 }
 

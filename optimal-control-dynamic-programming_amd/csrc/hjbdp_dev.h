@@ -45,6 +45,11 @@ struct DParams {
     int32_t *status;          // device word, set to 1 when a query leaves the slab
     DAxis axis[HJB_MAX_D];
     DTerm cost[HJB_MAX_TERMS];
+    // hjb_problem.cost_dtype == HJB_COST_F64: the cost terms in float64 (same strides as cost[]); a stage cost is their ordered
+    // sum in double rounded to float32 once (Solver_pos_att.m:800-801).  cost[] then holds float32 copies for host analysis only
+    DTerm cost64[HJB_MAX_TERMS];
+    int32_t cost_f64;
+    int32_t pad_cost;
     // hjb_problem.model (HJB_MODEL_QUAT_EULER321): quaternion tables x4,x5,x6,x7 over (n0,n1,n2), step h
     int32_t model;
     float model_h;

@@ -35,7 +35,7 @@ int stage_ctrlsplit(const StageArgs &a, bool j_in_lds);                         
 int stage_packed2(const StageArgs &a, int mode);                                 // variant 4
 int stage_tabled(const StageArgs &a);                                            // variant 5
 int stage_rowwise(const StageArgs &a, bool lean);                                // variant 6
-int stage_colsweep(const StageArgs &a, int gax, int ng, bool fastcost, bool dpp);   // variant 7
+int stage_colsweep(const StageArgs &a, int gax, int ng, int costform, bool dpp);    // variant 7 (costform: 0 general, 1 fast, 2 fast in float64)
 int stage_colcoop(const StageArgs &a, int gax, int ng, bool fastcost);           // variant 7, cooperative form
 int stage_tile2d(const StageArgs &a, const void *plan, int K);                   // K9 (several stages per launch)
 int stage_tile2d_plan(int dtype, const DParams *dp, const DTabled *dtb, void *plan, int64_t n_entries);

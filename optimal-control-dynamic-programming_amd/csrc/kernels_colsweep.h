@@ -176,9 +176,9 @@ template <typename T, typename TJ> __device__ __forceinline__ T raw_to(uint32_t 
 // swapping roles in a loop unrolled by two would save the copy of each row, but keep both sets alive: 92 -> 124 VGPRs.)
 typedef float cs_f4 __attribute__((ext_vector_type(4)));
 typedef float cs_f2 __attribute__((ext_vector_type(2)));
-template <typename T, int GAX, bool FASTCOST, typename FA, typename SP>
+template <typename T, int GAX, bool FASTCOST, typename FA, typename SP, bool C64 = false>
 __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&Aold)[kCsNW], cs_f2 (&Anew)[kCsNW], T t1, SP slots,
-                                         T gstep, int ncu, int npre, T &best, int &best_u) {
+                                         T gstep, int ncu, int npre, T &best, int &best_u, double gstep64 = 0.0) {
     typedef cs_f2 f2;
     typedef cs_f4 f4;
     constexpr int NW = kCsNW, MM = kCsMMax;
@@ -217,7 +217,11 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
             interp = fma_t<T>(tw, (T)(v1 - v0), v0);
         }
         T gg;
-        if (FASTCOST) {                              // the usual shape: state terms + ONE control term
+        if (FASTCOST && C64) {                       // cost_dtype F64: state part + the control term in double, one rounding
+            const f4 mx = slots[(g * MM + s) * 2 + 1];
+            const double cu = __hiloint2double(__float_as_int(mx.y), __float_as_int(mx.x));
+            gg = (T)(gstep64 + cu);
+        } else if (FASTCOST) {                       // the usual shape: state terms + ONE control term
             gg = (T)(gstep + ms.z);
         } else {
             const f4 mx = slots[(g * MM + s) * 2 + 1];
@@ -253,8 +257,8 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
 
 // Five waves per SIMD (<= 96 VGPRs) for the one-load form with up to five groups - the C4 / C5 kernel, which the
 // register allocator otherwise leaves at 98; the wider forms take what they need.
-template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DPP && NG <= 5) ? 5 : 1, (DPP && NG <= 5) ? 5 : 4)))
+template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP, bool C64 = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DPP && NG <= 5 && !C64) ? 5 : 1, (DPP && NG <= 5 && !C64) ? 5 : 4)))
 k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
                   const TJ *__restrict__ Jn, TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");
@@ -364,9 +368,17 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     int si[D] = {i0, 0, i2, i3 + P->slab_begin};
     const int cjz[HJB_MAX_C] = {0, 0, 0};
     T gcol = (T)0;
-    for (int k = 0; k < npre_col; ++k) {
-        const T x = term_value<T, D>(P->cost[k], si, cjz);
-        gcol = (k == 0) ? x : (T)(gcol + x);
+    double gcol64 = 0.0;                          // C64: the column-constant state terms of the cost in double
+    if constexpr (C64) {
+        for (int k = 0; k < npre_col; ++k) {
+            const double x = term_value<double, D>(P->cost64[k], si, cjz);
+            gcol64 = (k == 0) ? x : gcol64 + x;
+        }
+    } else {
+        for (int k = 0; k < npre_col; ++k) {
+            const T x = term_value<T, D>(P->cost[k], si, cjz);
+            gcol = (k == 0) ? x : (T)(gcol + x);
+        }
     }
     // Scalar bases: (lower, upper) group row [x (lower, upper) axis-0 neighbour], and ONE 32-bit per-lane byte offset per
     // (group, window knot), advanced along the column: every gather is `global_load v, v_off, s[base]`, no 64-bit vector
@@ -458,6 +470,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     };
     static_assert(NG - (NG + 1) / 2 <= 3 && (NG + 1) / 2 <= 3, "await_groups counts up to nine younger window knots");
     T best, gstep, t1;
+    double gstep64 = 0.0;
     int best_u;
     typedef __attribute__((address_space(3))) const f4 lds_f4;
     lds_f4 *slots = (lds_f4 *)&s_slots[wave][0];
@@ -475,7 +488,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                                      : f2{raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])} - l;
                     return __builtin_elementwise_fma(t0p, d, l);
                 };
-                cs_group<T, GAX, FASTCOST>(used[g], g, row0, A[g], A[g], t1, slots, gstep, ncu, npre, best, best_u);
+                cs_group<T, GAX, FASTCOST, decltype(row0), decltype(slots), C64>(used[g], g, row0, A[g], A[g], t1, slots, gstep, ncu, npre, best, best_u, gstep64);
             }
         }
     };
@@ -532,7 +545,14 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         load_groups(NGH, NG, (uint32_t)(c1 + 1) * s1_bytes);              // H1 of this step
         // ---- this state's cost without the control terms -----------------------------------------------
         gstep = gcol;
-        if (one_su) {                            // the usual shape: ONE per-step term, the same for every state of the wave
+        if constexpr (C64) {                     // the per-step state terms added in double (any shape: this form is not the headline)
+            si[1] = i1;
+            gstep64 = gcol64;
+            for (int k = npre_col; k < npre; ++k) {
+                const double x = term_value<double, D>(P->cost64[k], si, cjz);
+                gstep64 = (k == 0) ? x : gstep64 + x;
+            }
+        } else if (one_su) {                     // the usual shape: ONE per-step term, the same for every state of the wave
             const T x = su_ptr[su_s1 * i1];
             gstep = npre_col == 0 ? x : (T)(gcol + x);
         } else if (npre > npre_col) {

@@ -111,9 +111,18 @@ k_backup_tabled(const DParams *__restrict__ P, const DTabled *__restrict__ TB, c
         }
         if (bad0) *P->status = 1;
         T gpre = (T)0;
-        for (int k = 0; k < P->n_cost_prefix; ++k) {
-            T x = term_value<T, D>(P->cost[k], si, cj);
-            gpre = (k == 0) ? x : (T)(gpre + x);
+        double gpre64 = 0.0;                     // cost_dtype F64: the state part of the cost in double (Solver_pos_att.m:800)
+        const bool c64 = P->cost_f64 != 0;
+        if (c64) {
+            for (int k = 0; k < P->n_cost_prefix; ++k) {
+                const double x = term_value<double, D>(P->cost64[k], si, cj);
+                gpre64 = (k == 0) ? x : gpre64 + x;
+            }
+        } else {
+            for (int k = 0; k < P->n_cost_prefix; ++k) {
+                T x = term_value<T, D>(P->cost[k], si, cj);
+                gpre = (k == 0) ? x : (T)(gpre + x);
+            }
         }
         T best = (T)0;
         int64_t best_u = 0;
@@ -153,9 +162,18 @@ k_backup_tabled(const DParams *__restrict__ P, const DTabled *__restrict__ TB, c
                     v[j] = fma_t<T>(tw[a], (T)(v[2 * j + 1] - v[2 * j]), v[2 * j]);
             }
             T g = gpre;
-            for (int k = P->n_cost_prefix; k < P->n_cost; ++k) {
-                T x = term_value<T, D>(P->cost[k], si, cj);
-                g = (k == 0) ? x : (T)(g + x);
+            if (c64) {                           // the control part added in double, ONE rounding to the arithmetic type
+                double g64 = gpre64;
+                for (int k = P->n_cost_prefix; k < P->n_cost; ++k) {
+                    const double x = term_value<double, D>(P->cost64[k], si, cj);
+                    g64 = (k == 0) ? x : g64 + x;
+                }
+                g = (T)g64;
+            } else {
+                for (int k = P->n_cost_prefix; k < P->n_cost; ++k) {
+                    T x = term_value<T, D>(P->cost[k], si, cj);
+                    g = (k == 0) ? x : (T)(g + x);
+                }
             }
             const T tot = (T)(g + v[0]);
             if (u == 0 || tot < best) {

@@ -28,4 +28,23 @@ static int colsweep_go(const StageArgs &a, int ng, bool fastcost, bool dpp) {
     return 0;
 }
 
+// cost form 2 (hjb_problem.cost_dtype == HJB_COST_F64: state terms + one control term, summed in double): units of their own
+template <typename TJ, int GAX>
+static int colsweep_go_c64(const StageArgs &a, int ng, bool dpp) {
+    const dim3 g(a.grid), b(a.block);
+    const TJ *Jn = (const TJ *)a.Jn;
+    TJ *Jo = (TJ *)a.Jo;
+#define HJB_CS64(NG)                                                                                                   \
+    case NG:                                                                                                           \
+        if (dpp) hipLaunchKernelGGL((k_backup_colsweep<float, TJ, GAX, NG, true, true, true>), g, b, 0, a.st, a.dp, a.dtb, a.dcs, Jn, Jo, a.idx);    \
+        else hipLaunchKernelGGL((k_backup_colsweep<float, TJ, GAX, NG, true, false, true>), g, b, 0, a.st, a.dp, a.dtb, a.dcs, Jn, Jo, a.idx);       \
+        break;
+    switch (ng) {
+        HJB_CS64(1) HJB_CS64(2) HJB_CS64(3) HJB_CS64(4) HJB_CS64(5) HJB_CS64(6)
+        default: return 1;
+    }
+#undef HJB_CS64
+    return 0;
+}
+
 }  // namespace hjb

@@ -38,6 +38,7 @@ HJB_COPY_D2D = 2
 
 HJB_MODEL_NONE = 0
 HJB_MODEL_QUAT_EULER321 = 1
+HJB_COST_DEFAULT, HJB_COST_F64 = 0, 1
 
 
 class hjb_term(C.Structure):
@@ -66,6 +67,8 @@ class hjb_problem(C.Structure):
         ("table_dtype", C.c_int32),
         ("model_h", C.c_double),
         ("model_tables", C.c_void_p * 4),
+        ("cost_dtype", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -125,6 +128,8 @@ class hjb_info(C.Structure):
         ("halo_needed_hi", C.c_int32),
         ("idx_bytes", C.c_int32),
         ("table_dtype", C.c_int32),
+        ("cost_dtype", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -162,6 +167,7 @@ SYMBOLS = {
     "hjb_problem_add_cost_term": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]),
     "hjb_problem_set_slab": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hjb_problem_set_types": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "hjb_problem_set_cost_type": (C.c_int32, [C.c_void_p, C.c_int32]),
     "hjb_problem_set_model": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_problem_permute_axes": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hjb_problem_suggest_order": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -46,11 +46,17 @@ class ProblemSpec:
     narrowest that holds nU - 1 + index_base; hjbdp.h hjb_problem.idx_dtype).
     table_dtype: None, or np.float64 with float32 arithmetic = the reference's pos-att typing
     (Solver_pos_att.m:299-327: double query tables, single F_gI.Values): next_terms are kept in float64, each query
-    is formed, located and weighted in double and the weight rounded to float32 once (hjbdp.h HJB_TAB_F64)."""
+    is formed, located and weighted in double and the weight rounded to float32 once (hjbdp.h HJB_TAB_F64).
+    cost_dtype: None, or np.float64 with float32 arithmetic: cost_terms are kept in float64 and the stage cost of a
+    (state, control) is their ordered sum in double rounded to float32 once - `single(double expression)` of
+    Solver_pos_att.m:800-801 without the nS x nU array (hjbdp.h HJB_COST_F64)."""
 
     def __init__(self, knots, m, next_terms, cost_terms, dtype=np.float64, index_base=0, j_storage=None, model=None,
-                 idx_dtype=None, table_dtype=None):
+                 idx_dtype=None, table_dtype=None, cost_dtype=None):
         self.dtype = np.dtype(dtype)
+        self.cost_dtype = None if cost_dtype is None else np.dtype(cost_dtype)
+        if self.cost_dtype is not None and not (self.cost_dtype == np.float64 and self.dtype == np.float32 and model is None):
+            raise ValueError("cost_dtype must be float64 with float32 arithmetic (and no state model)")
         self.table_dtype = None if table_dtype is None else np.dtype(table_dtype)
         if self.table_dtype is not None and not (self.table_dtype == np.float64 and self.dtype == np.float32 and model is None):
             raise ValueError("table_dtype must be float64 with float32 arithmetic (and no state model)")
@@ -78,7 +84,7 @@ class ProblemSpec:
             raise ValueError("C=%d not in 1..%d" % (self.C, _abi.HJB_MAX_C))
         g = self.n + self.m
         self.next_terms = [[self._check(t, g, self.table_dtype or self.dtype) for t in ts] for ts in next_terms]
-        self.cost_terms = [self._check(t, g) for t in cost_terms]
+        self.cost_terms = [self._check(t, g, self.cost_dtype or self.dtype) for t in cost_terms]
         if len(self.next_terms) != self.D:
             raise ValueError("need one term list per state axis")
         # model = {"kind": "quat_euler321", "h": step, "tables": [x4, x5, x6, x7] over (n0, n1, n2)}: the next
@@ -140,6 +146,7 @@ class ProblemSpec:
         p.idx_dtype = {None: _abi.HJB_IDX_I32, "auto": _abi.HJB_IDX_AUTO, np.dtype(np.int32): _abi.HJB_IDX_I32,
                        np.dtype(np.uint8): _abi.HJB_IDX_U8, np.dtype(np.uint16): _abi.HJB_IDX_U16}[self.idx_dtype]
         p.table_dtype = _abi.HJB_TAB_F64 if self.table_dtype is not None else _abi.HJB_TAB_DEFAULT
+        p.cost_dtype = _abi.HJB_COST_F64 if self.cost_dtype is not None else _abi.HJB_COST_DEFAULT
         p.n_cost_terms = len(self.cost_terms)
         for k, t in enumerate(self.cost_terms):
             p.cost_terms[k].mask = t.mask
@@ -181,7 +188,7 @@ def permute_state_axes(spec: ProblemSpec, order):
     cost = [remap(t) for t in spec.cost_terms]
     new = ProblemSpec(knots, spec.m, nxt, cost, dtype=spec.dtype, index_base=spec.index_base,
                       j_storage=None if spec.j_dtype == spec.dtype else spec.j_dtype,
-                      idx_dtype=spec.idx_dtype, table_dtype=spec.table_dtype)
+                      idx_dtype=spec.idx_dtype, table_dtype=spec.table_dtype, cost_dtype=spec.cost_dtype)
     inv = [order.index(a) for a in range(D)]
 
     def to_old(flat):

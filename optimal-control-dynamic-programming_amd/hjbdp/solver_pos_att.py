@@ -126,13 +126,17 @@ class Solver_pos_att:
             W = s_w[None, None, None, :, None]
             full = (Qx * X ** 2 + Qv * V ** 2 + Qw * W ** 2 + Qt * Tt ** 2 + cu[None, None, None, None, :]).astype(f32)
             cost = [Term((0, 1, 2, 3, 4), full)]
-        elif self.cost_mode == "terms":
+        elif self.cost_mode in ("terms", "f64"):
+            # 'terms': the five separable operands of :800 summed in single inside the library (<= 2 ulp from the double sum);
+            # 'f64': the same operands kept in double, summed in double, ONE rounding per (state, control) - the reference's
+            # single(double expression), bit-identical to 'exact' without the nS x nU array (hjbdp.h HJB_COST_F64)
             cost = [Term((0,), Qx * s_x ** 2), Term((1,), Qv * s_v ** 2), Term((3,), Qw * s_w ** 2),
                     Term((2,), Qt * s_t ** 2), Term((4,), cu)]
         else:
-            raise ValueError("cost_mode must be 'exact' or 'terms'")
+            raise ValueError("cost_mode must be 'exact', 'terms' or 'f64'")
         spec = ProblemSpec([s_x, s_v, s_t, s_w], [len(fa)], nxt, cost, dtype=np.float32, index_base=1,
-                           idx_dtype=self.idx_dtype, table_dtype=self.table_dtype)
+                           idx_dtype=self.idx_dtype, table_dtype=self.table_dtype,
+                           cost_dtype=np.float64 if self.cost_mode == "f64" else None)
         return spec, (fa, fb, fc, fd)
 
     def calculate_one_channel_U_Opt(self, s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw, R, J, file_name,

@@ -12,7 +12,9 @@ function out = Solver_pos_att_hjbdp_channel(obj, s_x, s_v, s_t, s_w, f0, f1, f6,
 %   (:330-402) go to the library as their 1-D operands.
 %   'cost_mode' 'exact' (default): J_current_M = single(double sum) exactly as J_current_reshaped (:784-802) forms
 %   it, passed as one [n_x,n_v,n_t,n_w,nU] operand (fine up to ~1e8 entries); 'terms': its five separable operands,
-%   summed in single inside the library in the reference's order (<= 2 ulp from the double sum) - for grids like 120^4.
+%   summed in single inside the library in the reference's order (<= 2 ulp from the double sum) - for grids like 120^4;
+%   'f64': the separable operands in DOUBLE, summed in double per (state, control) and rounded to single ONCE - bit-identical
+%   to 'exact' at any grid size (hjbdp.h HJB_COST_F64; ~10 % slower than 'terms' on 120^4).
 %   'fast_axes' true lets the library run (x, theta, w, v) - its column-sweep kernel, 3.7x faster on large grids -
 %   with results permuted back (J equal to rounding, see hjbdp_solve).  Other name/value pairs go to hjbdp_solve.
 % NOT executed in the build image (no MATLAB); tested twin: hjbdp/solver_pos_att.py::calculate_one_channel_U_Opt
@@ -40,17 +42,21 @@ function out = Solver_pos_att_hjbdp_channel(obj, s_x, s_v, s_t, s_w, f0, f1, f6,
     prob.single = true;
     prob.next_terms = {[T(1, s_x), T(2, h * s_v)], [T(2, s_v), T(5, dv)], [T(3, s_t), T(4, h * s_w)], [T(4, s_w), T(5, dw)]};
     cu = R * fa.^2 + R * fb.^2 + R * fc.^2 + R * fd.^2;          % :801
+    extra = {};
     switch cost_mode
         case 'exact'    % :261-263, :800-801 as is
             prob.cost_terms = T(1:5, J_current_reshaped(obj, s_x, s_v, s_t, s_w, f0_allcomb, f1_allcomb, f6_allcomb, f7_allcomb, ...
                                                         Qx, Qv, Qt, Qw, R));
         case 'terms'    % sum order of :800: Qx x^2 + Qv v^2 + Qw w^2 + Qt t^2 + (R f.^2 ...)
             prob.cost_terms = [T(1, Qx * s_x.^2), T(2, Qv * s_v.^2), T(4, Qw * s_w.^2), T(3, Qt * s_t.^2), T(5, cu)];
+        case 'f64'
+            prob.cost_terms = [T(1, Qx * s_x.^2), T(2, Qv * s_v.^2), T(4, Qw * s_w.^2), T(3, Qt * s_t.^2), T(5, cu)];
+            extra = {'double_cost', true};
         otherwise
-            error('hjbdp:arg', 'cost_mode must be exact or terms');
+            error('hjbdp:arg', 'cost_mode must be exact, terms or f64');
     end
     out = hjbdp_solve(prob, n_stages, 'monitor_period', 50, 'monitor_tol', 1e-2, 'monitor_single', true, ...
-                      'double_tables', true, 'labels', 'auto', rest{:});            % :266-286
+                      'double_tables', true, 'labels', 'auto', extra{:}, rest{:});            % :266-286
     if out.stopped_early
         fprintf('sum of errors in the last 50 stages is under tolerance, breaking loop...\n')
     end

@@ -31,6 +31,9 @@ function out = hjbdp_solve(prob, n_stages, varargin)
 %   'double_tables' (default false; with prob.single): next_terms data go to the library as double and every query is
 %   formed, located and weighted in double, the weight rounded to single once - the typing of Solver_pos_att.m:299-327
 %   (double x_next .. w_next, single F_gI.Values); costs nothing per stage (hjbdp.h HJB_TAB_F64).
+%   'double_cost' (default false; with prob.single): cost_terms data go to the library as double and the stage cost of a
+%   (state, control) is their ordered sum in double rounded to single ONCE - single(Qx*x.^2 + ... ) of Solver_pos_att.m:800-801
+%   without the [n_x,n_v,n_t,n_w,nU] array, bit-identical to passing that array as one term (hjbdp.h HJB_COST_F64).
 %   'monitor_single' (default false): the monitor's sum(F.Values(:)) as a single-precision sum (Solver_pos_att.m:274).
 %   'labels' (default 'int32'; 'uint8' | 'uint16' | 'auto'): storage class of the argmin labels inside the library and on
 %   the way back (hjbdp.h HJB_IDX_*; 'auto' = the narrowest that holds prod(m)): Solver_pos_att's U_Optimal_id has 9 values.
@@ -48,6 +51,7 @@ function out = hjbdp_solve(prob, n_stages, varargin)
     addParameter(p, 'fast_axes', false);
     addParameter(p, 'double_tables', false);
     addParameter(p, 'monitor_single', false);
+    addParameter(p, 'double_cost', false);
     addParameter(p, 'labels', 'int32');
     parse(p, varargin{:});
     o = p.Results;
@@ -79,6 +83,12 @@ function out = hjbdp_solve(prob, n_stages, varargin)
         check(calllib(L, 'hjb_problem_set_types', bv, int32(idt), int32(o.double_tables)), bv, 'builder');   % HJB_IDX_*, HJB_TAB_F64
     end
     if o.double_tables, ncls = 'double'; end
+    ccls = cls;                                   % class of the cost operands as handed to the library
+    if o.double_cost
+        if ~prob.single, error('hjbdp:arg', 'double_cost is for prob.single = true'); end
+        check(calllib(L, 'hjb_problem_set_cost_type', bv, int32(1)), bv, 'builder');          % HJB_COST_F64
+        ccls = 'double';
+    end
     if isfield(prob, 'model') && ~isempty(prob.model)      % HJB_MODEL_QUAT_EULER321 = 1
         tb = cellfun(@(t) single(t(:)), prob.model.tables, 'UniformOutput', false);
         check(calllib(L, 'hjb_problem_set_model', bv, int32(1), double(prob.model.h), tb{1}, tb{2}, tb{3}, tb{4}), bv, 'builder');
@@ -93,7 +103,7 @@ function out = hjbdp_solve(prob, n_stages, varargin)
         end
     end
     for k = 1:numel(prob.cost_terms)
-        v = cast(prob.cost_terms(k).data(:), cls);
+        v = cast(prob.cost_terms(k).data(:), ccls);
         check(calllib(L, 'hjb_problem_add_cost_term', bv, mask(prob.cost_terms(k).dims), v, int64(numel(v))), bv, 'builder');
     end
     order = 1:D;                                  % order(i) = the caller's axis that the library runs as axis i

@@ -160,6 +160,7 @@ static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float
            jsep != NULL: J_next(i) = ((jsep[0][i0] + jsep[1][i1]) + ...) instead of an array */        \
         const int D = p->D, C = p->C;                                                                  \
         const int tab64 = p->table_dtype == HJB_TAB_F64 && sizeof(T) == 4;                             \
+        const int cost64 = p->cost_dtype == HJB_COST_F64 && sizeof(T) == 4;   /* Solver_pos_att.m:800-801 */ \
         T *knots[HJB_MAX_D], *rdx[HJB_MAX_D];                                                          \
         term_t nt[HJB_MAX_D][HJB_MAX_TERMS], ct[HJB_MAX_TERMS];                                        \
         int64_t jstride[HJB_MAX_D];                                                                    \
@@ -278,7 +279,17 @@ static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float
                     for (int j = 0; j < half; ++j) v[j] = FMA(tw[a], (T)(v[2 * j + 1] - v[2 * j]), v[2 * j]); \
                 }                                                                                      \
                 T g = 0;                                                                               \
-                for (int k = 0; k < p->n_cost_terms; ++k) {                                            \
+                if (cost64) {           /* the ordered sum in double, rounded to single ONCE */       \
+                    double g64 = 0;                                                                    \
+                    for (int k = 0; k < p->n_cost_terms; ++k) {                                        \
+                        int64_t off = 0;                                                               \
+                        for (int d = 0; d < D + C; ++d) off += ct[k].stride[d] * gi[d];                \
+                        const double x = ((const double *)ct[k].data)[off];                            \
+                        g64 = (k == 0) ? x : g64 + x;                                                  \
+                    }                                                                                  \
+                    g = (T)g64;                                                                        \
+                }                                                                                      \
+                for (int k = 0; k < p->n_cost_terms && !cost64; ++k) {                                 \
                     int64_t off = 0;                                                                   \
                     for (int d = 0; d < D + C; ++d) off += ct[k].stride[d] * gi[d];                    \
                     T x = ((const T *)ct[k].data)[off];                                                \
@@ -335,6 +346,7 @@ static int backup_f32_avx2(const hjb_problem *p, const float *Jn, float *Jout, i
     const int D = p->D, C = p->C;
     if (p->model) return HJB_E_UNSUPPORTED;
     const int tab64 = p->table_dtype == HJB_TAB_F64;
+    const int cost64 = p->cost_dtype == HJB_COST_F64;
     float *knots[HJB_MAX_D], *rdx[HJB_MAX_D];
     term_t nt[HJB_MAX_D][HJB_MAX_TERMS], ct[HJB_MAX_TERMS];
     int32_t jstride[HJB_MAX_D];
@@ -472,7 +484,23 @@ static int backup_f32_avx2(const hjb_problem *p, const float *Jn, float *Jout, i
                     for (int j = 0; j < half; ++j) v[j] = _mm256_fmadd_ps(tw[a], _mm256_sub_ps(v[2 * j + 1], v[2 * j]), v[2 * j]);
                 }
                 __m256 g = _mm256_setzero_ps();
-                for (int k = 0; k < p->n_cost_terms; ++k) {
+                if (cost64) {           /* the ordered sum in double (two 4-lane halves), rounded to single once */
+                    __m256d gd[2] = {_mm256_setzero_pd(), _mm256_setzero_pd()};
+                    for (int k = 0; k < p->n_cost_terms; ++k) {
+                        int64_t off = 0;
+                        for (int d = 1; d < D + C; ++d) off += ct[k].stride[d] * gi[d];
+                        const double *dp = (const double *)ct[k].data + off;
+                        const int s0 = (int)ct[k].stride[0];
+                        const __m256i ix = _mm256_mullo_epi32(li, _mm256_set1_epi32(s0));
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const __m128i ih = hf ? _mm256_extracti128_si256(ix, 1) : _mm256_castsi256_si128(ix);
+                            const __m256d x = s0 == 0 ? _mm256_set1_pd(dp[0]) : _mm256_i32gather_pd(dp, ih, 8);
+                            gd[hf] = (k == 0) ? x : _mm256_add_pd(gd[hf], x);
+                        }
+                    }
+                    g = _mm256_insertf128_ps(_mm256_castps128_ps256(_mm256_cvtpd_ps(gd[0])), _mm256_cvtpd_ps(gd[1]), 1);
+                }
+                for (int k = 0; k < p->n_cost_terms && !cost64; ++k) {
                     int64_t off = 0;
                     for (int d = 1; d < D + C; ++d) off += ct[k].stride[d] * gi[d];
                     const float *dp = (const float *)ct[k].data + off;

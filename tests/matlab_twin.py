@@ -20,7 +20,7 @@ def T(dims, data):
 
 
 def hjbdp_solve(lib, prob, n_stages, keep_stages=False, monitor_period=0, monitor_tol=0.0, devices=0, fast_axes=False,
-                double_tables=False, monitor_single=False, labels="int32"):
+                double_tables=False, monitor_single=False, labels="int32", double_cost=False):
     D, Cn = len(prob["knots"]), len(prob["m"])
     cls, dt = (np.float32, 0) if prob["single"] else (np.float64, 1)
     n = [len(k) for k in prob["knots"]]
@@ -48,6 +48,12 @@ def hjbdp_solve(lib, prob, n_stages, keep_stages=False, monitor_period=0, monito
             check(lib.hjb_problem_set_types(b, idt, 1 if double_tables else 0), b, "builder")
         if double_tables:
             ncls = np.float64
+        ccls = cls
+        if double_cost:
+            if not prob["single"]:
+                raise ValueError("double_cost is for prob.single = true")
+            check(lib.hjb_problem_set_cost_type(b, 1), b, "builder")
+            ccls = np.float64
         keep = []
         if prob.get("model"):
             tb = [np.ascontiguousarray(np.asarray(t, dtype=f32).reshape(-1, order="F")) for t in prob["model"]["tables"]]
@@ -64,7 +70,7 @@ def hjbdp_solve(lib, prob, n_stages, keep_stages=False, monitor_period=0, monito
                 v = np.ascontiguousarray(np.asarray(t["data"]).reshape(-1, order="F").astype(ncls))
                 check(lib.hjb_problem_add_next_term(b, a, mask(t["dims"]), v.ctypes.data, v.size), b, "builder")
         for t in prob["cost_terms"]:
-            v = np.ascontiguousarray(np.asarray(t["data"]).reshape(-1, order="F").astype(cls))
+            v = np.ascontiguousarray(np.asarray(t["data"]).reshape(-1, order="F").astype(ccls))
             check(lib.hjb_problem_add_cost_term(b, mask(t["dims"]), v.ctypes.data, v.size), b, "builder")
         order = list(range(D))
         if fast_axes and D > 1:
@@ -245,7 +251,7 @@ def pos_att_channel_prob(pa, s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw,
         Tt, W = s_t[None, None, :, None, None], s_w[None, None, None, :, None]
         full = (Qx * X ** 2 + Qv * V ** 2 + Qw * W ** 2 + Qt * Tt ** 2 + cu[None, None, None, None, :]).astype(f32)
         prob["cost_terms"] = [T([1, 2, 3, 4, 5], full)]
-    else:
+    else:       # 'terms' (summed in single inside the library) and 'f64' (hjbdp_solve 'double_cost': summed in double, one rounding)
         prob["cost_terms"] = [T(1, Qx * s_x ** 2), T(2, Qv * s_v ** 2), T(4, Qw * s_w ** 2), T(3, Qt * s_t ** 2), T(5, cu)]
     return prob, (fa, fb, fc, fd)
 

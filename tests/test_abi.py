@@ -38,12 +38,13 @@ def test_struct_layout_matches_header(lib):
     assert C.sizeof(_abi.hjb_term) == 16
     expect = 4 * 2 + 4 * 6 + 4 * 3 + 4 * 2  # D,C,n,m,dtype,index_base = 52 -> pad to 56
     expect = 56 + 8 * 6 + 4 * 6 + 16 * 12 * 6 + 8 + 16 * 12 + 16
-    expect += 4 + 4 + 8 + 8 * 4             # model, reserved1, model_h, model_tables[4]
+    expect += 4 + 4 + 8 + 8 * 4             # model, table_dtype, model_h, model_tables[4]
+    expect += 4 + 4                         # cost_dtype, reserved_
     assert C.sizeof(_abi.hjb_problem) == expect
     assert C.sizeof(_abi.hjb_solve_opts) == 4 + 4 + 8 + 8 * 5 + 8 + 8 + 8 + 4 + 4
     assert C.sizeof(_abi.hjb_probe) == 4 * 6 * 2 + 4 * 3 + 4 + 8 * 3
     assert C.sizeof(_abi.hjb_result) == 32
-    assert C.sizeof(_abi.hjb_info) == 56
+    assert C.sizeof(_abi.hjb_info) == 64
 
 
 def test_invalid_problems_are_rejected_with_status(lib):

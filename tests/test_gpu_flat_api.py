@@ -402,7 +402,7 @@ def test_matlab_shim_sequences_attitude_run(env, on_the_fly):
 
 
 @pytest.mark.order(8)
-@pytest.mark.parametrize("cost_mode", ["exact", "terms"])
+@pytest.mark.parametrize("cost_mode", ["exact", "terms", "f64"])
 def test_matlab_shim_sequences_pos_att_channel(env, cost_mode):
     """matlab/Solver_pos_att_hjbdp_channel.m on the reference's own grid (30 x 30 x 20 x 15 x 9): double query tables,
     single-precision monitor every 50 stages, uint8 labels - F_gI.Values, U_Optimal_id, the stage the monitor stopped at
@@ -417,7 +417,7 @@ def test_matlab_shim_sequences_pos_att_channel(env, cost_mode):
     args = (sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
     c = pa.calculate_one_channel_U_Opt(*args, "channel_x_controller_1", n_stages=120)
     prob, combos = mt.pos_att_channel_prob(pa, *args, cost_mode=cost_mode)
-    out = mt.hjbdp_solve(lib, prob, 120, **mt.POS_ATT_SOLVE_KW)
+    out = mt.hjbdp_solve(lib, prob, 120, double_cost=(cost_mode == "f64"), **mt.POS_ATT_SOLVE_KW)
     assert out["J"].shape == (30, 30, 20, 15)
     assert np.array_equal(out["J"], c["F_gI_Values"]) and np.array_equal(out["idx"], c["U_Optimal_id"])
     assert out["stages_done"] == c["stages_done"] and out["stopped_early"] == c["stopped_early"]
@@ -566,10 +566,10 @@ def test_cpp_rank_driver_matches_the_python_path(env):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "checksum_sum_J"):
         assert key in line, key
-    assert line["metric"] == "bellman_backups_per_s" and line["n_gpus"] == 1 and line["steps"] == 12 and line["config"]["kernel_variant"] == 7
+    assert line["metric"] == "bellman_backups_per_s" and line["n_gpus"] == 1 and line["steps"] == 12
     spec, _ = bench.build_spec("c4", n=34)
     with hjbdp.Backup(spec) as bk:
-        assert bk.info()["kernel_variant"] == 7
+        assert bk.info()["kernel_variant"] == line["config"]["kernel_variant"]        # the library's own choice on both sides
         out = bk.solve(13)
     want = float(out["J"].astype(np.float64).sum())
     assert abs(line["checksum_sum_J"] - want) <= 1e-11 * abs(want), (line["checksum_sum_J"], want)

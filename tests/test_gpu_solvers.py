@@ -220,15 +220,32 @@ def test_6d_24_pow_6_as_slabs_of_the_last_axis(env):
     torques, swept by hjb_solve_multi as 2 and as 4 slabs of the last axis (w3) - every slab on this box's one GPU, halo
     planes copied device to device per stage - must equal the whole-grid launch on EVERY state, two stages deep (the
     second stage reads what the exchange delivered), and a sample of first-stage states must equal the oracle."""
+    _c3_mode_as_slabs(env, 24, (2, 4), 246)
+
+
+@pytest.mark.order(6)
+@pytest.mark.watchdog(900)
+def test_c3_mode_32_pow_6_as_eight_slabs(env):
+    """north_star: "the state grid shards by outermost axis across up to 8 MI355X".  C3's kernel mode in the 8-GPU form -
+    eight slabs of four w3 planes - on a grid five times the 24^6 one: 32^6 = 1.07e9 states x 11^3 torques (J 4.3 GB),
+    all slabs on this box's one GPU: equal to the whole-grid launch on every state two stages deep, sampled states equal
+    to the oracle (the 8-GPU run of 51^6 itself - 22 GB per GPU - needs hardware the builder does not have)."""
+    free, total = env[0].device_mem_info(0)
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs 40 GB of free HBM")
+    _c3_mode_as_slabs(env, 32, (8,), 328)
+
+
+def _c3_mode_as_slabs(env, n, slab_counts, seed):
     hjbdp, _abi, c_oracle = env
-    sa = hjbdp.Solver_attitude(n_mesh_w=24, n_mesh_q=24)
+    sa = hjbdp.Solver_attitude(n_mesh_w=n, n_mesh_q=n)
     sa.U_vector = np.linspace(-0.11, 0.11, 11)
     spec0 = sa.build_spec_model()
     spec = hjbdp.ProblemSpec(spec0.knots, spec0.m, spec0.next_terms, spec0.cost_terms, dtype=np.float32, index_base=spec0.index_base,
                              model=spec0.model, idx_dtype="auto")
-    assert spec.nS == 24 ** 6 and spec.nU == 1331 and spec.idx_np_dtype == np.uint16
-    rng = np.random.default_rng(246)
-    vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
+    assert spec.nS == n ** 6 and spec.nU == 1331 and spec.idx_np_dtype == np.uint16
+    rng = np.random.default_rng(seed)
+    vecs = [(rng.random(na) * (1.0 + a)).astype(np.float32) for a, na in enumerate(spec.n)]
     term = vecs[0].reshape(-1, 1, 1, 1, 1, 1)
     for a in range(1, 6):                                   # ((v0 + v1) + v2) + ...: one float32 add per axis, like the checker
         shape = [1] * 6
@@ -239,14 +256,15 @@ def test_6d_24_pow_6_as_slabs_of_the_last_axis(env):
         assert bk.info()["kernel_variant"] == 4
         whole = bk.solve(2, terminal=term, keep_J=True)
     first = whole["J_stages"][:, 1]                         # the stage computed first (k_s = 2)
-    sel = np.unique(np.concatenate([rng.integers(0, spec.nS, 300), [0, spec.nS - 1, 24 ** 5 * 11 + 7, 24 ** 5 * 12 - 1]]))
+    sel = np.unique(np.concatenate([rng.integers(0, spec.nS, 300), [0, spec.nS - 1, n ** 5 * (n // 2 - 1) + 7, n ** 5 * (n // 2) - 1]]))
     Jr, ir = c_oracle.backup_states(_abi, spec, vecs, sel)
     assert np.array_equal(first[sel], Jr)
     del first
-    for n_slabs in (2, 4):
+    for n_slabs in slab_counts:
         with hjbdp.MultiBackup(spec, [0] * n_slabs) as mb:
             infos = [mb.slab_info(i) for i in range(n_slabs)]
-            assert all(i["kernel_variant"] == 4 for i in infos) and infos[-1]["end"] == 24
+            assert all(i["kernel_variant"] == 4 for i in infos) and infos[-1]["end"] == n
+            assert [i["end"] - i["begin"] for i in infos] == [n // n_slabs] * n_slabs
             assert any(i["halo_lo"] or i["halo_hi"] for i in infos)
             out = mb.solve(2, terminal=term)
         assert np.array_equal(out["J"], whole["J"]), n_slabs

@@ -253,3 +253,61 @@ def test_tab64_table_build_failure_is_loud(env, monkeypatch):
     monkeypatch.delenv("HJBDP_TEST_FAIL_TAB64_SCRATCH")
     with hjbdp.Backup(spec) as bk:
         assert bk.info()["table_dtype"] == _abi.HJB_TAB_F64 and bk.info()["kernel_variant"] >= 5
+
+
+@pytest.mark.parametrize("j_storage", [None, np.float16])
+def test_float64_cost_terms_every_serving_kernel(env, j_storage):
+    """hjb_problem.cost_dtype = HJB_COST_F64: cost terms float64, the stage cost summed in double and rounded once
+    (Solver_pos_att.m:800-801).  The tabled kernel (5) and the column sweep (7, one-load and two-load forms, both group
+    axes) against the oracle bit for bit, with float16 storage, irrational cost values (the double sum really differs from
+    the float32 one), slabs; kernels that sum in float32 are refused; on the reference's pos-att grid the 'f64' sweep equals
+    the 'exact' sweep (the materialised single(double sum)) bit for bit, monitor included."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem, random_problem, random_terminal
+    rng = np.random.default_rng(64)
+    for seed, gax, cost in ((1, 3, "fast"), (2, 2, "fast"), (3, 3, "step01")):
+        s0 = colsweep_problem(900 + seed, (70, 9, 8, 11), nU=9, gax=gax, cost=cost, dtype=np.float64)
+        ct = [hjbdp.Term(t.dims, np.asarray(t.data) * (1.0 + 1e-3 * rng.random(np.asarray(t.data).shape))) for t in s0.cost_terms]
+        spec = hjbdp.ProblemSpec(s0.knots, s0.m, s0.next_terms, ct, dtype=np.float32, index_base=1, idx_dtype="auto",
+                                 cost_dtype=np.float64, j_storage=j_storage)
+        s32 = hjbdp.ProblemSpec(s0.knots, s0.m, s0.next_terms, ct, dtype=np.float32, index_base=1, idx_dtype="auto", j_storage=j_storage)
+        term = random_terminal(spec, seed).astype(spec.j_dtype)
+        ref = c_oracle.sweep(_abi, spec, 4, terminal=term)
+        assert not np.array_equal(ref["J"], c_oracle.sweep(_abi, s32, 4, terminal=term)["J"])      # the typing matters
+        for variant, dpp in ((5, 1), (7, 1), (7, 0)):
+            with hjbdp.Backup(spec, variant=variant) as bk:
+                if variant == 7:
+                    bk.set_option("cs_dpp", dpp)
+                inf = bk.info()
+                assert inf["kernel_variant"] == variant and inf["cost_dtype"] == _abi.HJB_COST_F64
+                out = bk.solve(4, terminal=term)
+            assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"]), (seed, variant, dpp)
+        with hjbdp.Backup(spec) as bk:
+            assert bk.info()["kernel_variant"] in (5, 7)
+            for v in (0, 6):
+                with pytest.raises(hjbdp.HjbError):
+                    bk.set_option("variant", v)
+        with hjbdp.MultiBackup(spec, [0, 0, 0]) as mb:
+            outm = mb.solve(4, terminal=term)
+        assert np.array_equal(outm["J"], ref["J"]) and np.array_equal(outm["idx"], ref["idx"])
+    # two control dims, 3-D, through the tabled kernel
+    g0 = random_problem(71, (9, 8, 7), (4, 5), dtype=np.float64, nonuniform=True, index_base=1)
+    gen = hjbdp.ProblemSpec(g0.knots, g0.m, g0.next_terms, g0.cost_terms, dtype=np.float32, index_base=1, cost_dtype=np.float64,
+                            j_storage=j_storage)
+    term = random_terminal(gen, 7).astype(gen.j_dtype)
+    ref = c_oracle.sweep(_abi, gen, 3, terminal=term)
+    with hjbdp.Backup(gen) as bk:
+        assert bk.info()["kernel_variant"] == 5
+        out = bk.solve(3, terminal=term)
+    assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+    if j_storage is None:
+        outs = {}
+        for mode in ("exact", "f64"):
+            pa = hjbdp.Solver_pos_att()
+            pa.cost_mode = mode
+            sx, sv, st, sw = pa.grids()
+            outs[mode] = pa.calculate_one_channel_U_Opt(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1,
+                                                        pa.Qt1, pa.Qw1, pa.R1, pa.J2, "c_" + mode, n_stages=150)
+        a, b = outs["exact"], outs["f64"]
+        assert np.array_equal(a["F_gI_Values"].view(np.uint32), b["F_gI_Values"].view(np.uint32))
+        assert np.array_equal(a["U_Optimal_id"], b["U_Optimal_id"]) and a["stages_done"] == b["stages_done"]

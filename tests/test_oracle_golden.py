@@ -357,3 +357,33 @@ def test_oracle_single_precision_monitor_sum_is_the_stated_tree(orc):
     assert out["last_e"] == float(fin[0])
     assert out64["last_e"] == float(J.astype(np.float64).sum()) or abs(out64["last_e"] - J.astype(np.float64).sum()) < 1e-6
     assert abs(out["last_e"] - out64["last_e"]) <= 1e-5 * abs(out64["last_e"])
+
+
+def test_oracle_float64_cost_equals_the_materialised_single_of_double_sum(orc):
+    """hjb_problem.cost_dtype = HJB_COST_F64: the stage cost as the ordered sum of float64 operands in double, rounded to
+    single once, is `J_current_M = single(Qx*x.^2 + Qv*v.^2 + Qw*w.^2 + Qt*t.^2 + (R*f.^2 ...))` of Solver_pos_att.m:800-801.
+    On the reference's own pos-att grid the sweep with the five float64 operands ('f64') must equal the sweep with that
+    array materialised and passed as ONE float32 term ('exact') bit for bit - scalar twin and AVX2 twin - while the
+    float32 operand sum ('terms') differs in the last bits."""
+    _abi, c_oracle, hjb_oracle = orc
+    import hjbdp
+    specs = {}
+    for mode in ("exact", "f64", "terms"):
+        pa = hjbdp.Solver_pos_att()
+        pa.cost_mode = mode
+        sx, sv, st, sw = pa.grids()
+        specs[mode], _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
+                                               pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    assert specs["f64"].cost_dtype == np.float64 and specs["f64"].cost_terms[0].data.dtype == np.float64
+    assert specs["exact"].cost_dtype is None and len(specs["exact"].cost_terms) == 1
+    out = {m: c_oracle.sweep(_abi, s, 12) for m, s in specs.items()}
+    assert np.array_equal(out["exact"]["J"].view(np.uint32), out["f64"]["J"].view(np.uint32))
+    assert np.array_equal(out["exact"]["idx"], out["f64"]["idx"])
+    assert not np.array_equal(out["exact"]["J"], out["terms"]["J"])                   # the float32 operand sum is another function
+    assert np.max(np.abs(out["exact"]["J"] - out["terms"]["J"])) <= 1e-5 * np.max(out["exact"]["J"])
+    term = random_terminal(specs["f64"], 5)
+    Js, i_s = c_oracle.backup_stage(_abi, specs["f64"], term)
+    Jv, i_v = c_oracle.backup_stage(_abi, specs["f64"], term, impl="avx2")
+    Je, i_e = c_oracle.backup_stage(_abi, specs["exact"], term)
+    assert np.array_equal(Js.view(np.uint32), Jv.view(np.uint32)) and np.array_equal(i_s, i_v)
+    assert np.array_equal(Js.view(np.uint32), Je.view(np.uint32)) and np.array_equal(i_s, i_e)
