@@ -693,6 +693,14 @@ int build(Handle *h, const hjb_problem *p) {
                         near = step < 0.99 * width;
                     }
                     h->window3_ok = near;
+                    {   // visiting order of the 256-state chunks (kernels_packed2.h, option "chunk_order"): when the window slices
+                        // of ONE point of the level axes - the whole block of the state-only axes x 27 / 36 entries - outgrow an
+                        // XCD's 4 MiB L2, neighbouring chunks of that block must run together (state order); smaller blocks gain
+                        // more from the neighbouring points' shared window rows (transposed order).  C3: 51^3 x 27 x 4 B = 14 MB.
+                        int64_t blk = 1;
+                        for (int a = 0; a + 3 < D; ++a) blk *= p->n[a];
+                        h->hn.chunk_order = blk * (int64_t)h->esz * (near ? 27 : 36) > ((int64_t)4 << 20) ? 1 : 0;
+                    }
                     if (near) {
                         h->packed_pre += 3;                                        // modes 5 / 6
                         h->packed2_lds += 27 * 256 * 4;
@@ -2017,6 +2025,14 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the captured launches are the other form
         return HJB_OK;
     }
+    if (!strcmp(key, "chunk_order")) {      // variant 4, window modes: 0 transposed visiting order of the 256-state chunks, 1 state order
+        if (value != 0 && value != 1) return fail(h, HJB_E_INVALID, "chunk_order must be 0 or 1");
+        if (!h->dn) return fail(h, HJB_E_UNSUPPORTED, "chunk_order: variant 4's window modes only");
+        h->hn.chunk_order = (int32_t)value;
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpy(h->dn, &h->hn, sizeof(DNested), hipMemcpyHostToDevice));
+        return HJB_OK;
+    }
     if (!strcmp(key, "monitor_single")) {   // hjb_solve_opts.monitor_single for callers of the flat API (hjb_solve_flat)
         h->monitor_single = value != 0;
         return HJB_OK;
@@ -2034,6 +2050,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "packed2_mode")) *value = h->packed_mode ? h->packed_pre : -1;   // variant 4's contraction mode (kernels_packed2.h), -1: not eligible
     else if (!strcmp(key, "idx_bytes")) *value = h->idx_bytes;
     else if (!strcmp(key, "temporal")) *value = h->use_temporal;
+    else if (!strcmp(key, "chunk_order")) *value = h->dn ? h->hn.chunk_order : 0;
     else if (!strcmp(key, "row_lean")) *value = h->row_lean ? 1 : 0;
     else if (!strcmp(key, "lds_pad")) *value = (int64_t)h->lds_pad;
     else if (!strcmp(key, "cs_xcd_mod")) *value = h->cs_xcd_mod;

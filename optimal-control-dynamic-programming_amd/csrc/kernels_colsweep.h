@@ -257,8 +257,15 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
 
 // Five waves per SIMD (<= 96 VGPRs) for the one-load form with up to five groups - the C4 / C5 kernel, which the
 // register allocator otherwise leaves at 98; the wider forms take what they need.
+// HJB_CS_UNROLL2 (experiment, round 4; off): the step loop unrolled by two with the corner-row registers A swapping roles (the row
+// at knot c1 + 1 of one step is the row at knot c1 of the next: no copy of each new row into the old one's register - 15
+// v_mov_b64 per step) at four waves per SIMD.  profiles/r04_c4_experiments.log has the timing.
+#ifndef HJB_CS_UNROLL2
+#define HJB_CS_UNROLL2 0
+#endif
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP, bool C64 = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DPP && NG <= 5 && !C64) ? 5 : 1, (DPP && NG <= 5 && !C64) ? 5 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
+    HJB_CS_UNROLL2 ? 4 : ((DPP && NG <= 5 && !C64) ? 5 : 1), HJB_CS_UNROLL2 ? 4 : ((DPP && NG <= 5 && !C64) ? 5 : 4))))
 k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
                   const TJ *__restrict__ Jn, TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");
@@ -412,11 +419,14 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     // rotation.  Results go to LDS and are written out every kCsFlush steps: on gfx9 loads and stores share one counter
     // and complete out of order with each other, so a pending store makes every wait for a load a full drain.
     constexpr int NGH = (NG + 1) / 2;
-    f2 A[NG][NW];
+    constexpr int NA = HJB_CS_UNROLL2 ? 2 : 1;               // sets of corner-row registers (two: they swap roles every step)
+    f2 A[NA][NG][NW];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int q = 0; q < NA; ++q)
 #pragma unroll
-        for (int w = 0; w < NW; ++w) A[g][w] = f2{(T)0, (T)0};
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) A[q][g][w] = f2{(T)0, (T)0};
     constexpr int LPK = DPP ? 2 : 4;                         // gathers per window knot of a group
     int ngs = ng;                                            // the group count as a value of the current step (below)
     uint32_t rlo[NG][2][NW], rhi[NG][2][NW];
@@ -477,7 +487,8 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     asm volatile("" : "+v"(slots));          // one address register for the column, not one re-made per read
     // The arithmetic (cs_group) is written on PAIRS (lower, upper group row) of one window knot: v_pk_add_f32 /
     // v_pk_fma_f32 are IEEE per component, and with the pair as the unit of data no value has to be moved between registers.
-    auto compute_groups = [&](int g0, int g1) __attribute__((always_inline)) {
+    auto compute_groups = [&](int g0, int g1, auto PP) __attribute__((always_inline)) {
+        constexpr int po = decltype(PP)::value, pn = HJB_CS_UNROLL2 ? 1 - po : po;      // old / new set of this step
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
             if (g < ngs) {
@@ -488,7 +499,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                                      : f2{raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])} - l;
                     return __builtin_elementwise_fma(t0p, d, l);
                 };
-                cs_group<T, GAX, FASTCOST, decltype(row0), decltype(slots), C64>(used[g], g, row0, A[g], A[g], t1, slots, gstep, ncu, npre, best, best_u, gstep64);
+                cs_group<T, GAX, FASTCOST, decltype(row0), decltype(slots), C64>(used[g], g, row0, A[po][g], A[pn][g], t1, slots, gstep, ncu, npre, best, best_u, gstep64);
             }
         }
     };
@@ -512,97 +523,25 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     asm volatile("" : "+v"(gcol), "+v"(t0), "+v"(voff0));
     load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // prologue: H0 of step 0
     int slot = 0;                                            // LDS slot of this step's result (= i1 % kCsFlush)
-    for (int i1 = i1b; i1 < i1e; ++i1) {
-        // The four waves of the workgroup (neighbours along the group axis: half their corner rows are the same) take every
-        // step together, so that what one of them misses in L1 the others find there: 2.31 -> 2.26 ms per stage on C4.
-        // (A wave that has left - no column - does not count for the barrier.)
-        __builtin_amdgcn_s_barrier();
-        const int c1 = c1n;
-        t1 = t1n;
-        ngs = ng;
-        asm volatile("" : "+s"(ngs));        // group-count tests stay scalar compares of this step (see the slot bits)
-        {   // next step's axis-1 entry: a scalar load in flight during this step
-            if (i1 + 1 < i1e) tab1n += a1_s;
-            c1n = tab1n[0].cell;
-            t1n = tab1n[0].t;
-        }
-        if (c1 != prev_c1 + 1) {         // (re-)prime: A <- the row at knot c1 (column start; irregular axis-1 cells)
-            const uint32_t vrow = (uint32_t)c1 * s1_bytes;
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-                if (g < ng) {
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const uint32_t o = voff0 + (vrow + (uint32_t)w * w_bytes + rog[g]);
-                        const T l0 = (T) * reinterpret_cast<gptr<TJ>>(Jb00 + o), l1 = (T) * reinterpret_cast<gptr<TJ>>(Jb10 + o);
-                        const T h0 = DPP ? l0 : (T) * reinterpret_cast<gptr<TJ>>(Jb01 + o);
-                        const T h1 = DPP ? l1 : (T) * reinterpret_cast<gptr<TJ>>(Jb11 + o);
-                        A[g][w] = f2{xl(l0, h0), xl(l1, h1)};
-                    }
-                }
-        }
-        prev_c1 = c1;
-        load_groups(NGH, NG, (uint32_t)(c1 + 1) * s1_bytes);              // H1 of this step
-        // ---- this state's cost without the control terms -----------------------------------------------
-        gstep = gcol;
-        if constexpr (C64) {                     // the per-step state terms added in double (any shape: this form is not the headline)
-            si[1] = i1;
-            gstep64 = gcol64;
-            for (int k = npre_col; k < npre; ++k) {
-                const double x = term_value<double, D>(P->cost64[k], si, cjz);
-                gstep64 = (k == 0) ? x : gstep64 + x;
+    if constexpr (HJB_CS_UNROLL2 != 0) {
+        for (int i1 = i1b; i1 < i1e; ++i1) {
+            {
+#define CS_PO 0
+#include "kernels_colsweep_step.inc"
+#undef CS_PO
             }
-        } else if (one_su) {                     // the usual shape: ONE per-step term, the same for every state of the wave
-            const T x = su_ptr[su_s1 * i1];
-            gstep = npre_col == 0 ? x : (T)(gcol + x);
-        } else if (npre > npre_col) {
-            si[1] = i1;
-            if (step_uniform) {
-                for (int k = npre_col; k < npre; ++k) {
-                    const DTerm &tm = P->cost[k];
-                    const int off = tm.stride[1] * i1 + tm.stride[2] * i2 + tm.stride[3] * si[3];
-                    const T x = as_const<T>(tm.data)[off];
-                    gstep = (k == 0) ? x : (T)(gstep + x);
-                }
-            } else {
-                for (int k = npre_col; k < npre; ++k) {
-                    const T x = term_value<T, D>(P->cost[k], si, cjz);
-                    gstep = (k == 0) ? x : (T)(gstep + x);
-                }
+            if (++i1 >= i1e) break;
+            {
+#define CS_PO (NA - 1)
+#include "kernels_colsweep_step.inc"
+#undef CS_PO
             }
         }
-        best = __builtin_inff();                 // (inf, control 0): what an all-infinite column of totals yields as well
-        best_u = 0;
-        // from the moment its first half has landed until its last member is done a wave runs at raised priority: a wave that
-        // has its rows gets the vector pipe ahead of waves still forming addresses or parking results, and returns to issuing
-        // gathers sooner (C4, one box: 1.760 ms per stage without, 1.741 raised around each half's arithmetic only, 1.734
-        // like this; raised from the barrier on: 1.755; raised around the gather issue only: no change)
-        await_groups(0, NGH, nH1);                                        // H0 landed; H1 may still be in flight
-        __builtin_amdgcn_s_setprio(3);
-        compute_groups(0, NGH);
-        load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // H0 of the next step
-        await_groups(NGH, NG, nH0);                                       // H1 landed; the next H0 in flight
-        compute_groups(NGH, NG);
-        __builtin_amdgcn_s_setprio(0);
-        // ---- results: parked in LDS, written out every kCsFlush steps ------------------------------------
-        s_best[wave][slot][lane] = best;
-        s_idx[wave][slot][lane] = (uint8_t)best_u;
-        if (slot == kCsFlush - 1 || i1 == i1e - 1) {
-            __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                const int first = i1 - slot;
-                for (int j = 0; j <= slot; ++j) {
-                    stj<T, TJ>(Jout, (int64_t)(out_col + js1 * (uint32_t)(first + j)), s_best[wave][j][lane]);
-                    if (idx_out) st_idx(idx_out, idx_col + (uint32_t)n0 * (uint32_t)(first + j), (int32_t)s_idx[wave][j][lane] + index_base, idx_bytes);
-                }
-            }
-            // let the stores finish here (and with them the gathers in flight): the counted waits above rely on no
-            // store being pending, loads and stores complete out of order with each other
-            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-            __builtin_amdgcn_wave_barrier();
-            slot = 0;
-        } else {
-            ++slot;
+    } else {
+        for (int i1 = i1b; i1 < i1e; ++i1) {
+#define CS_PO 0
+#include "kernels_colsweep_step.inc"
+#undef CS_PO
         }
     }
 }

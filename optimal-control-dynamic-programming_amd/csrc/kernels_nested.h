@@ -47,7 +47,7 @@ struct DNested {
     int32_t m_o0, m_o1;
     int32_t ax_l0[HJB_MAX_D];   // per axis (last axis: end bounded by ax_kin)
     int32_t cost_l0;
-    int32_t pad2;
+    int32_t chunk_order;  // variant 4, window modes: 0 = chunks visited in the transposed order (kernels_packed2.h), 1 = in state order
     DInnerTerm in[kMaxInner];  // [0,n_ax_in): last-axis terms, [kMaxInAx, kMaxInAx+n_cost_in): cost
     // Variant 2 (packed) only: the canonical shape has at most ONE non-prefix,
     // non-inner term per axis and one cost term per outer level.  ot[a] (a < D):

@@ -300,6 +300,10 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
         for (int a = 0; a < NP; ++a) inner *= (unsigned int)P->n[a];
         ac = inner >= 256u ? inner / 256u : 1u;
+        // option "chunk_order" = 1: state order instead (each XCD a contiguous run of chunks = neighbouring angle chunks of
+        // ONE point of the level axes: what a grid whose angle block outgrows the L2 wants - C3: 51^3 x 27 window slices =
+        // 14 MB per point - where the transposed order re-fetches the slices for every chunk)
+        if (N->chunk_order == 1) ac = 1u;
         nw = (n_chunks + ac - 1) / ac;
         n_v = ac * nw;
     } else {

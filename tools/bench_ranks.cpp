@@ -211,7 +211,7 @@ int main(int argc, char **argv) {
            "\"data\": \"synthetic\", \"config\": {\"workload\": \"C4 Solver_pos_att channel x: %dx%dx%dx%d states (x,theta,w,v) x 9 thruster "
            "combinations, float32, float64-built query tables, uint8 argmin, 1 stage per step\", \"states\": %.0f, \"states_per_gpu\": %.0f, "
            "\"controls\": 9, \"stages\": %d, \"sharding\": \"%s\", \"kernel_variant\": %d, \"driver\": \"tools/bench_ranks.cpp (one process per GPU, "
-           "RCCL inside libhjbdp: hjb_rank_sweep)\"}, \"checksum_sum_J\": %.9e}\n",
+           "RCCL inside libhjbdp: hjb_rank_sweep)\"}, \"checksum_sum_J\": %.17g}\n",
            backups / t, gpus, steps, warmup, t * 1e3 / steps, n, n, n, n, states, states / gpus, steps,
            gpus > 1 ? (std::string("last state axis (v): ") + std::to_string(n / gpus) + " of " + std::to_string(n) + " planes per GPU, halo " +
                        std::to_string(sh->halo_lo) + "/" + std::to_string(sh->halo_hi) + " planes exchanged per stage over RCCL" +
