@@ -275,7 +275,7 @@ def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=Fal
     from hjbdp.sharded import ShardedSweep
     n = {"c2": 101, "6d": 24}.get(workload, args.grid_n)
     spec, name = build_spec(workload, n_last=n * world if weak else None, n=args.grid_n)
-    sw = ShardedSweep(spec, rank, world, dev, overlap=not args.no_overlap)
+    sw = ShardedSweep(spec, rank, world, dev, overlap=not args.no_overlap, transport=args.transport)
     if args.variant is not None:
         sw.set_option("variant", args.variant)
     info = sw.info()
@@ -334,6 +334,9 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="force a stage-kernel variant (testing)")
     ap.add_argument("--grid-n", type=int, default=120, help="points per axis of the pos-att grid (config: 120; smaller = testing)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --share-gpu is a 1-GPU test mode")
+    ap.add_argument("--transport", default="torch", choices=["torch", "lib"],
+                    help="N > 1: who moves the halo planes - torch.distributed P2P from Python (default), or the RCCL transport inside "
+                         "libhjbdp (hjb_rank_step: one library call per stage; needs one GPU per rank)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses cuda:0")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -452,7 +455,8 @@ def main():
                         "counter set, every workload of this line in it; mean per launch of each stage kernel; FETCH_SIZE / "
                         "WRITE_SIZE in KiB; traffic = 2 x FETCH_SIZE + WRITE_SIZE: gfx950 tallies 128-byte fabric reads at 64 bytes - "
                         "0.5000 x bytes on every access shape of this library, profiles/r04_fetch_calib.json; traffic_uncorrected = "
-                        "FETCH_SIZE + WRITE_SIZE is the lower bound)" % args.workload) if pmc_all else pmc_note
+                        "FETCH_SIZE + WRITE_SIZE is the lower bound; FETCH_SIZE counts the L2's requests to the fabric, Infinity-Cache "
+                        "hits included: fabric traffic, an upper bound of the HBM bytes)" % args.workload) if pmc_all else pmc_note
     rf["note"] = ("fp32 VALU binds (SURVEY 8d), not HBM and not MFMA (interpolation is a gather; K = D <= 6); peak = fp32 vector "
                   "peak = f32-input MFMA peak.  achieved = ALGORITHMIC flops (F_alg(D) per backup) / launch time; the "
                   "kernel shares the control-independent lerps between the controls, so it executes fewer.  "
@@ -473,7 +477,7 @@ def main():
                    "stages": args.steps,
                    "sharding": ("last state axis (v): %d of %d planes per GPU, halo %d/%d planes (rank 0) exchanged per stage over %s%s"
                                 % (head["states_rank"] // (spec.nS // spec.n[-1]), spec.n[-1], head["halo"][0], head["halo"][1],
-                                   "RCCL" if args.backend == "nccl" else args.backend + " (test transport)",
+                                   ("RCCL inside libhjbdp" if args.transport == "lib" else "RCCL (torch.distributed P2P)") if args.backend == "nccl" else args.backend + " (test transport)",
                                    "" if args.no_overlap else ", overlapped with the interior planes")) if world > 1 else "none",
                    "kernel_variant": info["kernel_variant"]},
         "roofline": rf,

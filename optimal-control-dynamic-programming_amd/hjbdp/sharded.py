@@ -80,9 +80,13 @@ def required_halo(spec: ProblemSpec):
 class ShardedSweep:
     """One rank's share of a sweep.  Buffers are torch tensors (HBM on GPUs)."""
 
-    def __init__(self, spec: ProblemSpec, rank, world, device, stage_fn=None, group=None, overlap=False):
+    def __init__(self, spec: ProblemSpec, rank, world, device, stage_fn=None, group=None, overlap=False, transport="torch"):
+        """transport: "torch" - the halo planes move with torch.distributed P2P (RCCL on GPUs, gloo in the CPU / shared-GPU
+        tests), issued from Python every stage; "lib" - with the RCCL transport INSIDE libhjbdp (hjb_rank_comm_init /
+        hjb_rank_step: one library call per stage; torch.distributed only carries the 128-byte communicator id once)."""
         import torch
         self.torch = torch
+        self.transport = transport
         self.spec, self.rank, self.world, self.group = spec, int(rank), int(world), group
         self.device = torch.device(device)
         nl = spec.n[-1]
@@ -122,6 +126,15 @@ class ShardedSweep:
             stage_fn = self._hip_stage
             if rk.split:
                 self._comm_stream = torch.cuda.Stream(device=self.device)
+            if transport == "lib" and world > 1:
+                import ctypes as C
+                import torch.distributed as dist
+                uid = (C.c_char * 128)()
+                if self.rank == 0:
+                    rk._check(rk.lib.hjb_rank_comm_unique_id(uid))
+                box = [bytes(uid)]
+                dist.broadcast_object_list(box, src=0, group=group)
+                rk._check(rk.lib.hjb_rank_comm_init(rk._r, box[0]))
         self.stage_fn = stage_fn
         self._halo_ops = {}
         # what my neighbours need from me
@@ -207,7 +220,11 @@ class ShardedSweep:
         """One backup of the owned planes.  Without overlap: halo exchange, then the fused kernel.  With
         overlap: start the exchange, run the interior planes, wait for the halos, run the boundary strips."""
         J_in, J_out = self.J[self.cur], self.J[1 - self.cur]
-        if self._rank is None or not self._rank.split:
+        if self._rank is not None and self.transport == "lib" and self.world > 1:
+            rk = self._rank
+            stream = self.torch.cuda.current_stream(self.device).cuda_stream
+            rk._check(rk.lib.hjb_rank_step(rk._r, J_in.data_ptr(), J_out.data_ptr(), self.idx.data_ptr(), stream))
+        elif self._rank is None or not self._rank.split:
             self.exchange_halos()
             self.stage_fn(J_in, J_out, self.idx)
         else:

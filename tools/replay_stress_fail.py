@@ -14,7 +14,7 @@ idx_dtype = {"<class 'numpy.uint16'>": np.uint16, "<class 'numpy.uint8'>": np.ui
 spec = hjbdp.ProblemSpec(d["knots"], d["m"], [[Term(dims, data) for dims, data in ts] for ts in d["next_terms"]],
                          [Term(dims, data) for dims, data in d["cost_terms"]], dtype=np.dtype(d["dtype"]), index_base=1,
                          j_storage=None if d["j_dtype"] == d["dtype"] else np.dtype(d["j_dtype"]), idx_dtype=idx_dtype,
-                         table_dtype=np.float64 if d["tab64"] else None)
+                         table_dtype=np.float64 if d["tab64"] else None, cost_dtype=np.float64 if d.get("cost64") else None)
 ref = c_oracle.sweep(_abi, spec, d["stages"], terminal=d["term"], nthreads=16, **d["mon"])
 for v in (None, 0, 1, 2, 3, 4, 5, 6, 7):
     try:

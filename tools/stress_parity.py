@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle parity stress: random shapes (D, C, grid sizes, dtype, knot spacing, displacement
-spread, J storage, argmin label width, float64-built query tables, the monitor in float32 or float64), every applicable
+spread, J storage, argmin label width, float64-built query tables, float64 cost terms, the monitor in float32 or float64), every applicable
 stage-kernel variant plus hjb_solve's multi-stage paths, whole grids and slabs.
 Every result must equal the C oracle's bit for bit.  usage: python tools/stress_parity.py [seconds=120] [seed=0]"""
 import os, sys, time
@@ -80,10 +80,11 @@ while time.time() < t_end:
     if idx_dtype is np.uint8 and spec.nU - 1 + spec.index_base > 255:
         idx_dtype = "auto"
     tab64 = bool(spec.dtype == np.float32 and rng.random() < 0.3)
-    if idx_dtype is not None or tab64:
+    cost64 = bool(spec.dtype == np.float32 and rng.random() < 0.25)      # round 4: float64 cost terms, one rounding per backup
+    if idx_dtype is not None or tab64 or cost64:
         spec = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=spec.dtype, index_base=spec.index_base,
                                  j_storage=None if spec.j_dtype == spec.dtype else spec.j_dtype, idx_dtype=idx_dtype,
-                                 table_dtype=np.float64 if tab64 else None)
+                                 table_dtype=np.float64 if tab64 else None, cost_dtype=np.float64 if cost64 else None)
     mon = {}
     if rng.random() < 0.3:
         mon = dict(monitor_period=int(rng.integers(1, 4)), monitor_tol=float(rng.choice([0.0, 1e-3, 1e30])),
@@ -144,12 +145,12 @@ while time.time() < t_end:
                     pickle.dump(dict(knots=[np.asarray(k) for k in spec.knots], m=list(spec.m),
                                      next_terms=[[(t.dims, np.asarray(t.data)) for t in ts] for ts in spec.next_terms],
                                      cost_terms=[(t.dims, np.asarray(t.data)) for t in spec.cost_terms], dtype=str(spec.dtype),
-                                     j_dtype=str(spec.j_dtype), idx_dtype=str(idx_dtype), tab64=tab64, term=term, stages=stages,
+                                     j_dtype=str(spec.j_dtype), idx_dtype=str(idx_dtype), tab64=tab64, cost64=cost64, term=term, stages=stages,
                                      mon=mon, forced=v), fh)
             except Exception as e:
                 print("  (dump failed: %s)" % e)
             print("MISMATCH", dict(D=D, C=C, n=n, m=m, dtype=str(np.dtype(dtype)), j=str(spec.j_dtype), nonuniform=nonuniform,
-                                   spread=spread, seed=seed, kind=str(kind), stages=stages, forced=v, ran=kv, idx=str(idx_dtype), tab64=tab64, mon=mon), flush=True)
+                                   spread=spread, seed=seed, kind=str(kind), stages=stages, forced=v, ran=kv, idx=str(idx_dtype), tab64=tab64, cost64=cost64, mon=mon), flush=True)
             sys.exit(1)
     # a random slab of the last axis with the halos the library asks for, one stage
     nl = spec.n[-1]
