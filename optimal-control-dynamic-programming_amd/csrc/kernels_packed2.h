@@ -168,7 +168,7 @@ __device__ __forceinline__ float contract_df(const TJ *__restrict__ Jn, int off,
 template <typename TJ, int D, int MODE>
 // The C2 modes are held to 96 VGPRs = five waves per SIMD (ten values spilled; 1.40 -> 1.35 ms per stage on C2; six waves
 // = 80 VGPRs spill 44 and run 1.7x slower); the window modes sit at three workgroups per CU by LDS whatever the registers.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 4 || MODE == 1) ? 5 : 1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 4 || MODE == 1) ? 5 : ((MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1))))
 k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
                  TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
@@ -191,6 +191,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     // W3P (any D >= 4): the host has checked that the inner control moves the last axis by less than one cell per step, so the second cell
     // a sweep enters is a neighbour of the first and the window needs 3 last-axis planes, not 4: 27 entries - with no padding
     // row in the weights 40 KB of LDS per workgroup on the 11-torque attitude grids, i.e. FOUR workgroups per CU instead of three
+    constexpr int kPairsUnrolled = 6;                      // the pair count the window modes' sweep is written out for
     constexpr int kWin = PRE ? (W3P ? 27 : 36) : 0;
     constexpr int kWq = W3P ? 3 : 4;                        // window planes
     float *my_w = reinterpret_cast<float *>(smem_raw) + threadIdx.x;
@@ -683,7 +684,24 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         // 4 packed subtractions + 4 packed fmas.  Same f1 - f0, same fma: same bits.
                         const f2 t2 = {__int_as_float(eA.y), __int_as_float(eB.y)};
                         f2 X2[4];
-                        if (KEEP_ROWS && !__any(rA != r_rows || rB != r_rows)) {
+                        // The kept rows are rewritten IN PLACE, in a block of its own, when both steps moved to the same other row;
+                        // the trip that straddles the move (step A on one row pair, step B on the next) selects per step and leaves
+                        // them alone.  (Written as "either path assigns R0 / RD" the compiler put nine register copies on the common
+                        // path to merge the two definitions: 5 % of a 6-D state's vector instructions.)
+                        bool kept = KEEP_ROWS && !__any(rA != r_rows || rB != r_rows);
+                        if (KEEP_ROWS && !kept && !__any(rA != rB)) {
+                            const bool up = rA != 0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float f0 = up ? F[1][q] : F[0][q];
+                                const float f1 = up ? F[2][q] : F[1][q];
+                                R0[q] = f0;
+                                RD[q] = f1 - f0;
+                            }
+                            r_rows = rA;
+                            kept = true;
+                        }
+                        if (kept) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
                                 X2[q] = __builtin_elementwise_fma(t2, (f2){RD[q], RD[q]}, (f2){R0[q], R0[q]});
@@ -695,10 +713,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                                 const f2 f1 = {upA ? F[2][q] : F[1][q], upB ? F[2][q] : F[1][q]};
                                 const f2 d = f1 - f0;
                                 X2[q] = __builtin_elementwise_fma(t2, d, f0);
-                                R0[q] = f0.y;
-                                RD[q] = d.y;
                             }
-                            r_rows = rB;
                         }
                         // The two halves of every packed instruction are the two STEPS (A, B) of one control: the per-step
                         // quantities (cost so far, E0, dE) are register pairs as they come out of the lerps above, the
@@ -717,20 +732,57 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                             const f2 toty = (g2 + (f2){r2.y, r2.y}) + __builtin_elementwise_fma((f2){t.y, t.y}, Dy, Ey);
                             t = lds_f2(my_t + t_ahead(p) * 256);                 // next pair
                             r2 = lds_f2(s_r2 + p + 1);
-                            mA = __builtin_fminf(mA, __builtin_fminf(totx.x, toty.x));      // v_min3_f32
-                            mB = __builtin_fminf(mB, __builtin_fminf(totx.y, toty.y));
+                            // left-leaning chains: the instruction selector folds min(min(m, x), y) into ONE v_min3_f32 per pair; written
+                            // min(m, min(x, y)) it pairs the inner minima of two pairs instead (3 instructions per two values)
+                            mA = __builtin_fminf(__builtin_fminf(mA, totx.x), toty.x);
+                            mB = __builtin_fminf(__builtin_fminf(mB, totx.y), toty.y);
                         };
                         int p = 0;
                         const int pa = jc >> 1;                                  // pairs wholly in the first cell
-#pragma unroll 2
-                        for (; p < pa; ++p) control_pair(p, Ea, Da, Ea, Da);
-                        if ((jc & 1) && jc < m_in) {                             // the change falls on a pair's second control
-                            control_pair(p, Ea, Da, Eb, Db);
-                            ++p;
-                        }
                         const int nfull = m_in >> 1;
+#ifndef HJB_K3_UNROLLED_PAIRS
+#define HJB_K3_UNROLLED_PAIRS 1
+#endif
+                        if (HJB_K3_UNROLLED_PAIRS && PRE && npairs == kPairsUnrolled) {
+                            // The window modes' usual sweep (11 or 12 inner controls = 6 pairs; C3, the 6-D grids): the pair loop written
+                            // out STRAIGHT-LINE for the trip's shape - how many full pairs (5 / 6), how many of them lie wholly in the
+                            // first cell, whether the wave's one cell change splits a pair: one scalar jump per trip picks the sequence.
+                            // With the pair number a compile-time constant the LDS rows of (t, r) are read at immediate offsets from two
+                            // fixed address registers, and with no branch inside the sequence nothing is copied at a join: 8 vector
+                            // instructions per pair and step pair (6 packed + 2 v_min3) instead of ~10.5.
+                            auto pairs_fixed = [&](auto NFc, auto PAc, auto STc) __attribute__((always_inline)) {
+                                constexpr int NF = decltype(NFc)::value, PA = decltype(PAc)::value;
+                                constexpr bool ST = decltype(STc)::value;
+#pragma unroll
+                                for (int q = 0; q < NF; ++q) {
+                                    if (q < PA) control_pair(q, Ea, Da, Ea, Da);
+                                    else if (ST && q == PA) control_pair(q, Ea, Da, Eb, Db);
+                                    else control_pair(q, Eb, Db, Eb, Db);
+                                }
+                            };
+                            // (wave-uniform by construction - jc comes from ballots; readfirstlane says so to the compiler - and a scalar
+                            // of THIS trip: one jump, not a chain of hoisted lane masks)
+                            int sel = __builtin_amdgcn_readfirstlane(nfull * 32 + (pa < nfull ? pa : nfull) * 2 + (((jc & 1) && jc < m_in) ? 1 : 0));
+                            asm volatile("" : "+s"(sel));
+#define HJB_PF(NF, PA, ST) case (NF) * 32 + (PA) * 2 + (ST): pairs_fixed(std::integral_constant<int, NF>{}, std::integral_constant<int, PA>{}, std::integral_constant<bool, (ST) != 0>{}); break;
+                            switch (sel) {
+                                HJB_PF(5, 0, 0) HJB_PF(5, 0, 1) HJB_PF(5, 1, 0) HJB_PF(5, 1, 1) HJB_PF(5, 2, 0) HJB_PF(5, 2, 1)
+                                HJB_PF(5, 3, 0) HJB_PF(5, 3, 1) HJB_PF(5, 4, 0) HJB_PF(5, 4, 1) HJB_PF(5, 5, 0)
+                                HJB_PF(6, 0, 0) HJB_PF(6, 0, 1) HJB_PF(6, 1, 0) HJB_PF(6, 1, 1) HJB_PF(6, 2, 0) HJB_PF(6, 2, 1)
+                                HJB_PF(6, 3, 0) HJB_PF(6, 3, 1) HJB_PF(6, 4, 0) HJB_PF(6, 4, 1) HJB_PF(6, 5, 0) HJB_PF(6, 5, 1) HJB_PF(6, 6, 0)
+                                default: break;            // unreachable: npairs == 6 means 5 or 6 full pairs
+                            }
+#undef HJB_PF
+                        } else {
 #pragma unroll 2
-                        for (; p < nfull; ++p) control_pair(p, Eb, Db, Eb, Db);
+                            for (; p < pa; ++p) control_pair(p, Ea, Da, Ea, Da);
+                            if ((jc & 1) && jc < m_in) {                         // the change falls on a pair's second control
+                                control_pair(p, Ea, Da, Eb, Db);
+                                ++p;
+                            }
+#pragma unroll 2
+                            for (; p < nfull; ++p) control_pair(p, Eb, Db, Eb, Db);
+                        }
                         if (m_in & 1) {                                          // the last control of an odd sweep, alone
                             const bool second = jc < m_in;                       // (wave-uniform) it lies in the second cell
                             const f2 El = second ? Eb : Ea, Dl = second ? Db : Da;
@@ -825,6 +877,34 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 f2 t = my_t[0];
                 f2 r2 = s_r2[0];
                 int p = 0;
+                if (HJB_K3_UNROLLED_PAIRS && PRE && UX == 0u && npairs == kPairsUnrolled) {
+                    // The window modes' usual sweep, one step (the last of an odd step count): as in the two-step trip above the six
+                    // control pairs run STRAIGHT-LINE for the wave's one cell change at control jc - pairs below jc >> 1 in the first
+                    // cell, the pair jc splits (jc odd) half and half, the rest in the second cell; a padding control (odd counts)
+                    // carries an infinite r and never wins.  One scalar jump per step, LDS rows at immediate offsets.
+                    auto step_fixed = [&](auto PAc, auto STc) __attribute__((always_inline)) {
+                        constexpr int PA = decltype(PAc)::value;
+                        constexpr bool ST = decltype(STc)::value;
+#pragma unroll
+                        for (int q = 0; q < kPairsUnrolled; ++q) {
+                            const f2 dv = q < PA ? (f2){dea, dea} : ((ST && q == PA) ? (f2){dea, deb} : (f2){deb, deb});
+                            const f2 ev = q < PA ? (f2){e0a, e0a} : ((ST && q == PA) ? (f2){e0a, e0b} : (f2){e0b, e0b});
+                            const f2 tot = (go2 + r2) + __builtin_elementwise_fma(t, dv, ev);
+                            t = lds_f2(my_t + t_ahead(q) * 256);
+                            r2 = lds_f2(s_r2 + q + 1);
+                            ibest = __builtin_fminf(__builtin_fminf(ibest, tot.x), tot.y);
+                        }
+                    };
+                    int sel1 = __builtin_amdgcn_readfirstlane(jc < 2 * kPairsUnrolled ? jc : 2 * kPairsUnrolled);      // (jc >> 1) * 2 + (jc & 1)
+                    asm volatile("" : "+s"(sel1));
+#define HJB_SF(J) case (J): step_fixed(std::integral_constant<int, (J) / 2>{}, std::integral_constant<bool, ((J) & 1) != 0>{}); break;
+                    switch (sel1) {
+                        HJB_SF(1) HJB_SF(2) HJB_SF(3) HJB_SF(4) HJB_SF(5) HJB_SF(6) HJB_SF(7) HJB_SF(8) HJB_SF(9) HJB_SF(10) HJB_SF(11) HJB_SF(12)
+                        default: break;            // unreachable: 1 <= jc (bit 0 of the crossing mask is never set)
+                    }
+#undef HJB_SF
+                    p = npairs;
+                }
                 while (p < npairs) {
                     const unsigned int rest = PU >> p;
                     const int pstop = rest ? p + __builtin_ctz(rest) : npairs;   // next pair with a crossing
@@ -834,7 +914,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         const f2 tot = (go2 + r2) + __builtin_elementwise_fma(t, dev, e0v);
                         t = lds_f2(my_t + t_ahead(p) * 256);         // next pair's rows
                         r2 = lds_f2(s_r2 + p + 1);
-                        ibest = __builtin_fminf(ibest, __builtin_fminf(tot.x, tot.y));            // v_min3_f32
+                        ibest = __builtin_fminf(__builtin_fminf(ibest, tot.x), tot.y);            // v_min3_f32
                     }
                     if (p < npairs) {                                // a pair in which some lane changes cell
                         const int jb = 2 * p;
@@ -855,7 +935,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         de = dey;
                         t = my_t[t_ahead(p) * 256];
                         r2 = s_r2[p + 1];
-                        ibest = __builtin_fminf(ibest, __builtin_fminf(tot.x, tot.y));
+                        ibest = __builtin_fminf(__builtin_fminf(ibest, tot.x), tot.y);
                         ++p;
                     }
                 }
