@@ -237,7 +237,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     const int m_o0 = N->m_o0, m_o1 = N->m_o1;
     int js[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) js[a] = (int)P->jstride[a];
+    for (int a = 0; a < D; ++a) js[a] = a == 0 ? 1 : (int)P->jstride[a];      // (axis 0 is contiguous by construction: a literal 1 lets a corner's
+                                                                               //  axis-0 neighbour be an immediate offset of the same address)
     const int inner_sz = (int)P->inner;
     f2 *my_t = s_t + threadIdx.x;
     // the weights row read ahead of pair p (beyond the last pair: the padding row, or - without one - the last row again)
@@ -753,12 +754,40 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                             auto pairs_fixed = [&](auto NFc, auto PAc, auto STc) __attribute__((always_inline)) {
                                 constexpr int NF = decltype(NFc)::value, PA = decltype(PAc)::value;
                                 constexpr bool ST = decltype(STc)::value;
+                                // (t, r) of a pair are read TWO pairs ahead (a ring of three: the window modes' units compile to 113
+                                // VGPRs without the SLP vectoriser, there is room): an LDS read gets ~16 vector instructions to land
+                                f2 tr[3], rr[3];
+                                tr[0] = t;
+                                rr[0] = r2;
+                                tr[1] = lds_f2(my_t + 256);
+                                rr[1] = lds_f2(s_r2 + 1);
 #pragma unroll
                                 for (int q = 0; q < NF; ++q) {
-                                    if (q < PA) control_pair(q, Ea, Da, Ea, Da);
-                                    else if (ST && q == PA) control_pair(q, Ea, Da, Eb, Db);
-                                    else control_pair(q, Eb, Db, Eb, Db);
+                                    constexpr int kLast = kPairsUnrolled - 1;
+                                    const int qn = q + 2 < kLast ? q + 2 : kLast;              // (compile-time after unrolling)
+#ifndef HJB_K3_PREFETCH2
+#define HJB_K3_PREFETCH2 0
+#endif
+                                    if (HJB_K3_PREFETCH2) {
+                                        tr[(q + 2) % 3] = lds_f2(my_t + qn * 256);
+                                        rr[(q + 2) % 3] = lds_f2(s_r2 + (q + 2 < kPairsUnrolled ? q + 2 : kPairsUnrolled));
+                                    } else if (q > 0) {                  // (A/B: one pair ahead, as the loops do)
+                                        const int q1 = q + 1 < kLast ? q + 1 : kLast;
+                                        tr[(q + 1) % 3] = lds_f2(my_t + q1 * 256);
+                                        rr[(q + 1) % 3] = lds_f2(s_r2 + q + 1);
+                                    }
+                                    const f2 tc = tr[q % 3], rc = rr[q % 3];
+                                    const bool bx = !(q < PA), by = !(q < PA) || (ST && q == PA);   // second cell: x / y control
+                                    const f2 Ex = (q < PA || (ST && q == PA)) ? Ea : Eb, Dx = (q < PA || (ST && q == PA)) ? Da : Db;
+                                    const f2 Ey = q < PA ? Ea : Eb, Dy = q < PA ? Da : Db;
+                                    (void)bx; (void)by;
+                                    const f2 totx = (g2 + (f2){rc.x, rc.x}) + __builtin_elementwise_fma((f2){tc.x, tc.x}, Dx, Ex);
+                                    const f2 toty = (g2 + (f2){rc.y, rc.y}) + __builtin_elementwise_fma((f2){tc.y, tc.y}, Dy, Ey);
+                                    mA = __builtin_fminf(__builtin_fminf(mA, totx.x), toty.x);
+                                    mB = __builtin_fminf(__builtin_fminf(mB, totx.y), toty.y);
                                 }
+                                t = tr[NF % 3];                                                  // row NF: an odd sweep's last control
+                                r2 = rr[NF % 3];
                             };
                             // (wave-uniform by construction - jc comes from ballots; readfirstlane says so to the compiler - and a scalar
                             // of THIS trip: one jump, not a chain of hoisted lane masks)

@@ -7,10 +7,13 @@ namespace hjb {
 
 int stage_packed2_f32(const StageArgs &a, int mode);
 int stage_packed2_f16(const StageArgs &a, int mode);
+int stage_packed2w_f32(const StageArgs &a, int mode);       // the window modes (2, 3, 5, 6): units of their own, compiled
+int stage_packed2w_f16(const StageArgs &a, int mode);       // without the SLP vectoriser (stage_packed2_impl.h)
 
 int stage_packed2(const StageArgs &a, int mode) {
-    if (a.dtype == HJB_F32) return stage_packed2_f32(a, mode);
-    if (a.dtype == HJB_F16S) return stage_packed2_f16(a, mode);
+    const bool window = mode == 2 || mode == 3 || mode == 5 || mode == 6;
+    if (a.dtype == HJB_F32) return window ? stage_packed2w_f32(a, mode) : stage_packed2_f32(a, mode);
+    if (a.dtype == HJB_F16S) return window ? stage_packed2w_f16(a, mode) : stage_packed2_f16(a, mode);
     return 1;                        // float32 arithmetic only
 }
 

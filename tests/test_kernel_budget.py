@@ -162,16 +162,18 @@ def test_packed2_occupancy_budgets():
     waves per SIMD, `amdgpu_waves_per_eu`), the three-plane window modes of the 6-D grids must stay within 128 (the LDS they
     save buys a fourth workgroup per CU only then)."""
     import tempfile
+    import __graft_entry__ as g
+    got = {}
     with tempfile.TemporaryDirectory() as d:
-        asm = "%s/p2.s" % d
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
-                            "-I%s/include" % ROOT, "-o", asm,
-                            "%s/optimal-control-dynamic-programming_amd/csrc/stage_packed2_f32.hip" % ROOT],
-                           capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-3000:]
-        text = open(asm).read()
-    got = dict((m[0], (int(m[1]), int(m[2]))) for m in re.findall(
-        r"\.name:\s+_ZN3hjb16k_backup_packed2IfLi(\d+ELi\d+)E\S*\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text))
+        for unit in ("stage_packed2_f32.hip", "stage_packed2w_f32.hip"):      # plain / C2 modes; window modes (own flags)
+            asm = "%s/p2.s" % d
+            r = subprocess.run([HIPCC, *g.HIPCC_FLAGS, *g.UNIT_FLAGS.get(unit, []), "-S", "--cuda-device-only",
+                                "-I%s/include" % ROOT, "-o", asm, "%s/optimal-control-dynamic-programming_amd/csrc/%s" % (ROOT, unit)],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            text = open(asm).read()
+            got.update((m[0], (int(m[1]), int(m[2]))) for m in re.findall(
+                r"\.name:\s+_ZN3hjb16k_backup_packed2IfLi(\d+ELi\d+)E\S*\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text))
     assert got["3ELi4"][0] <= 96 and got["3ELi1"][0] <= 96, got          # C2 modes: five waves per SIMD
     assert got["3ELi4"][1] <= 2, got                                       # ... with next to nothing in scratch
     for key in ("6ELi5", "6ELi6"):                                          # three-plane window: four waves per SIMD, no spill

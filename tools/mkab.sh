@@ -14,7 +14,8 @@ mkdir -p build/ab/$N
 rm -f build/ab/$N/*.o
 C=optimal-control-dynamic-programming_amd/csrc
 for f in $UNITS; do
-  /opt/rocm/bin/hipcc $FLAGS -Iinclude -I$C "$@" -c $C/$f.hip -o build/ab/$N/$f.o &
+  UF=$(python3 -c "import __graft_entry__ as g; print(' '.join(g.UNIT_FLAGS.get('$f.hip', [])))")       # the unit's own flags
+  /opt/rocm/bin/hipcc $FLAGS $UF -Iinclude -I$C "$@" -c $C/$f.hip -o build/ab/$N/$f.o &
 done
 wait
 OBJS=""
