@@ -213,6 +213,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             for (int i = threadIdx.x; i < m_in; i += blockDim.x) s_b[i] = static_cast<const float *>(tb.data)[i * tb.stride_in];
         for (int p = threadIdx.x; p <= npairs; p += blockDim.x) {
             f2 x = {INFINITY, INFINITY};          // padding controls: infinite cost, never selected
+            if (p == npairs) x = (f2){-0.0f, -0.0f};   // the row after the last pair (read ahead, never used as a control) doubles as the
+                                                      // "no level-1 cost term" slot of the two-step trips: g + (-0) == g bit for bit
             if (2 * p < m_in) x.x = static_cast<const float *>(tr.data)[(2 * p) * tr.stride_in];
             if (2 * p + 1 < m_in) x.y = static_cast<const float *>(tr.data)[(2 * p + 1) * tr.stride_in];
             s_r2[p] = x;
@@ -534,10 +536,12 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             }
         };
 
-        int uo = 0;
         i2v l0_nx = {0, 0};                   // window modes: the level-0 axis' entry, fetched one o0 step ahead
         if constexpr (PRE) l0_nx = atab[AX_A][aoff[AX_A]];
-        for (int o0 = 0; o0 < m_o0; ++o0) {
+#ifndef HJB_K3_PROBE
+#define HJB_K3_PROBE 0
+#endif
+        for (int o0 = 0; o0 < (HJB_K3_PROBE == 2 ? 0 : m_o0); ++o0) {
             // ---- level 0 ------------------------------------------------------------
             if constexpr (PRE) {
                 cell[AX_A] = l0_nx.x;
@@ -557,6 +561,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     }
                 }
             }
+            const int uo0 = o0 * m_o1;                 // (o0, o1) step number = uo0 + o1: scalar, never a vector register
             float go0 = gpre;
             if (cl0_present) {
                 const float x = cterm(CL0, o0, 0);
@@ -641,6 +646,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 if (!cl1_present) return go0;
                 return go0_l1 + cterm(CL1, o0, o1);
             };
+            // ... of steps o1 and o1 + 1 as a pair: the two LDS reads are issued at the top of a trip and added where the sweep starts
+            // (an absent term reads the -0 row of s_r2: no branch, no merge)
+            const float *l1_row = cl1_present ? s_ot + cl_off[1] + o0 * cl_c0[1] : reinterpret_cast<const float *>(s_r2 + npairs);
+            const int l1_step = cl1_present ? cl_c1[1] : 0;
+            auto level1_terms2 = [&](int o1) -> f2 { return (f2){l1_row[o1 * l1_step], l1_row[(o1 + 1) * l1_step]}; };
             i2v e_nx2 = {0, 0};                   // ... and the entry after it: a two-step trip consumes two
             if constexpr (HIER) {
                 e_nx = tb1[0];
@@ -666,42 +676,43 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     // (the window modes only: at the C2 modes' 96-register budget the eight kept values cost nine spills to
                     // scratch - 40 MB of write-back per C2 stage - and buy nothing measurable there)
                     constexpr bool KEEP_ROWS = PRE;
-                    int r_rows = -1;                                             // the r the kept rows were selected for
+                    int cell_rows = -1;                                          // the level-1 cell the kept rows were selected for (none yet)
                     float R0[4], RD[4];
-                    while (o1 + 1 < m_o1) {
-                        const i2v eA = e_nx, eB = e_nx2;
-                        const int rA = eA.x - c1min, rB = eB.x - c1min;
-                        if (__any(((unsigned int)rA | (unsigned int)rB) > 1u)) break;   // outside the window: e_nx, g_nx still belong to o1
-                        const float gA = g_nx, gB = level1_cost(o1 + 1);
-                        if (o1 + 2 < m_o1) {
-                            e_nx = tb1[(o1 + 2) * tb1_step];
-                            g_nx = level1_cost(o1 + 2);
-                        }
-                        if (o1 + 3 < m_o1) e_nx2 = tb1[(o1 + 3) * tb1_step];
+                    // the two steps' entries are carried from trip to trip and reloaded IN PLACE once the trip has used them (index clamped
+                    // to the last step: no test, nothing to merge): no "next" copies to rotate at the end of a trip
+                    i2v eA = e_nx, eB = e_nx2;
+                    const int o1_last = m_o1 - 1;
+                    while (HJB_K3_PROBE != 1 && o1 + 1 < m_o1) {
                         // (E0, dE) of the first / second last-axis cell, as {step A, step B} pairs.  The two prepared rows a step
                         // lerps between, R0 = F[r] and RD = F[r+1] - F[r], are kept from trip to trip (r moves 0 -> 1 at most
-                        // once over an o1 sweep when the axis' next value grows with the control): while every lane's r of both
-                        // steps is the one the rows were selected for, the lerps are 4 packed fmas instead of 16 selects +
-                        // 4 packed subtractions + 4 packed fmas.  Same f1 - f0, same fma: same bits.
+                        // once over an o1 sweep when the axis' next value grows with the control): while every lane's cell of both
+                        // steps is the one the rows were selected for - two compares; that also says "inside the window" - the
+                        // lerps are 4 packed fmas instead of 16 selects + 4 packed subtractions + 4 packed fmas.  Same f1 - f0, same
+                        // fma: same bits.
+                        const f2 c2 = level1_terms2(o1);
+                        bool kept = KEEP_ROWS && !__any(eA.x != cell_rows || eB.x != cell_rows);
+                        const int rA = eA.x - c1min, rB = eB.x - c1min;
+                        if (!kept) {
+                            if (__any(((unsigned int)rA | (unsigned int)rB) > 1u)) break;   // outside the window: eA still belongs to o1
+                            // The kept rows are rewritten IN PLACE, in a block of its own, when both steps sit on the same row;
+                            // the trip that straddles a move (step A on one row pair, step B on the next) selects per step and leaves
+                            // them alone.  (Written as "either path assigns R0 / RD" the compiler put nine register copies on the common
+                            // path to merge the two definitions: 5 % of a 6-D state's vector instructions.)
+                            if (KEEP_ROWS && !__any(rA != rB)) {
+                                const bool up = rA != 0;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float f0 = up ? F[1][q] : F[0][q];
+                                    const float f1 = up ? F[2][q] : F[1][q];
+                                    R0[q] = f0;
+                                    RD[q] = f1 - f0;
+                                }
+                                cell_rows = eA.x;
+                                kept = true;
+                            }
+                        }
                         const f2 t2 = {__int_as_float(eA.y), __int_as_float(eB.y)};
                         f2 X2[4];
-                        // The kept rows are rewritten IN PLACE, in a block of its own, when both steps moved to the same other row;
-                        // the trip that straddles the move (step A on one row pair, step B on the next) selects per step and leaves
-                        // them alone.  (Written as "either path assigns R0 / RD" the compiler put nine register copies on the common
-                        // path to merge the two definitions: 5 % of a 6-D state's vector instructions.)
-                        bool kept = KEEP_ROWS && !__any(rA != r_rows || rB != r_rows);
-                        if (KEEP_ROWS && !kept && !__any(rA != rB)) {
-                            const bool up = rA != 0;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float f0 = up ? F[1][q] : F[0][q];
-                                const float f1 = up ? F[2][q] : F[1][q];
-                                R0[q] = f0;
-                                RD[q] = f1 - f0;
-                            }
-                            r_rows = rA;
-                            kept = true;
-                        }
                         if (kept) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
@@ -716,49 +727,40 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                                 X2[q] = __builtin_elementwise_fma(t2, d, f0);
                             }
                         }
+                        {
+                            const int oa = o1 + 2 < o1_last ? o1 + 2 : o1_last, ob = o1 + 3 < o1_last ? o1 + 3 : o1_last;
+                            eA = tb1[oa * tb1_step];
+                            eB = tb1[ob * tb1_step];
+                        }
                         // The two halves of every packed instruction are the two STEPS (A, B) of one control: the per-step
                         // quantities (cost so far, E0, dE) are register pairs as they come out of the lerps above, the
                         // per-control ones (t_j, r_j) are broadcast by the instruction's operand selects, so nothing has to be
                         // rearranged; a control pair is 6 packed instructions + 2 v_min3.  UX == 0 leaves at most ONE cell
                         // change in the sweep, the whole wave's, at control jc: controls before it use the first cell, the
                         // others the second - three straight loops, no per-pair tests.
-                        const f2 g2 = {gA, gB};
                         const f2 Ea = X2[0], Da = X2[1] - X2[0], Eb = X2[2], Db = X2[3] - X2[2];
+                        const f2 g2 = (f2){go0_l1, go0_l1} + c2;                 // cost so far of {step A, step B}
                         float mA = INFINITY, mB = INFINITY;
-                        f2 t = my_t[0];
-                        f2 r2 = s_r2[0];
-                        auto control_pair = [&](int p, const f2 &Ex, const f2 &Dx, const f2 &Ey, const f2 &Dy)
-                                                __attribute__((always_inline)) {
-                            const f2 totx = (g2 + (f2){r2.x, r2.x}) + __builtin_elementwise_fma((f2){t.x, t.x}, Dx, Ex);
-                            const f2 toty = (g2 + (f2){r2.y, r2.y}) + __builtin_elementwise_fma((f2){t.y, t.y}, Dy, Ey);
-                            t = lds_f2(my_t + t_ahead(p) * 256);                 // next pair
-                            r2 = lds_f2(s_r2 + p + 1);
-                            // left-leaning chains: the instruction selector folds min(min(m, x), y) into ONE v_min3_f32 per pair; written
-                            // min(m, min(x, y)) it pairs the inner minima of two pairs instead (3 instructions per two values)
-                            mA = __builtin_fminf(__builtin_fminf(mA, totx.x), toty.x);
-                            mB = __builtin_fminf(__builtin_fminf(mB, totx.y), toty.y);
-                        };
-                        int p = 0;
                         const int pa = jc >> 1;                                  // pairs wholly in the first cell
                         const int nfull = m_in >> 1;
 #ifndef HJB_K3_UNROLLED_PAIRS
 #define HJB_K3_UNROLLED_PAIRS 1
 #endif
                         if (HJB_K3_UNROLLED_PAIRS && PRE && npairs == kPairsUnrolled) {
-                            // The window modes' usual sweep (11 or 12 inner controls = 6 pairs; C3, the 6-D grids): the pair loop written
-                            // out STRAIGHT-LINE for the trip's shape - how many full pairs (5 / 6), how many of them lie wholly in the
-                            // first cell, whether the wave's one cell change splits a pair: one scalar jump per trip picks the sequence.
-                            // With the pair number a compile-time constant the LDS rows of (t, r) are read at immediate offsets from two
-                            // fixed address registers, and with no branch inside the sequence nothing is copied at a join: 8 vector
-                            // instructions per pair and step pair (6 packed + 2 v_min3) instead of ~10.5.
-                            auto pairs_fixed = [&](auto NFc, auto PAc, auto STc) __attribute__((always_inline)) {
+                            // The window modes' usual sweep (11 or 12 inner controls = 6 pair rows; C3, the 6-D grids): the sweep written
+                            // out STRAIGHT-LINE for the trip's shape - 11 controls (5 pairs + one alone) or 12 (6 pairs), how many pairs
+                            // lie wholly in the first cell, whether the wave's one cell change splits a pair or falls on the control that
+                            // stands alone: one scalar jump per trip picks the sequence.  With the pair number a compile-time constant the
+                            // LDS rows of (t, r) are read at immediate offsets from two fixed address registers, and with no branch inside
+                            // the sequence nothing is copied at a join: 8 vector instructions per pair and step pair (6 packed + 2 v_min3)
+                            // instead of ~10.5, and the control that stands alone costs 3 packed + 2 v_min with its cell picked at compile time.
+                            auto pairs_fixed = [&](auto NFc, auto PAc, auto STc, auto LSc) __attribute__((always_inline)) {
                                 constexpr int NF = decltype(NFc)::value, PA = decltype(PAc)::value;
-                                constexpr bool ST = decltype(STc)::value;
-                                // (t, r) of a pair are read TWO pairs ahead (a ring of three: the window modes' units compile to 113
-                                // VGPRs without the SLP vectoriser, there is room): an LDS read gets ~16 vector instructions to land
+                                constexpr bool ST = decltype(STc)::value, LS = decltype(LSc)::value;
+                                // (t, r) of a pair row are read one row ahead, into a ring of registers the unrolled sequence names statically
                                 f2 tr[3], rr[3];
-                                tr[0] = t;
-                                rr[0] = r2;
+                                tr[0] = lds_f2(my_t);
+                                rr[0] = lds_f2(s_r2);
                                 tr[1] = lds_f2(my_t + 256);
                                 rr[1] = lds_f2(s_r2 + 1);
 #pragma unroll
@@ -768,41 +770,68 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #ifndef HJB_K3_PREFETCH2
 #define HJB_K3_PREFETCH2 0
 #endif
-                                    if (HJB_K3_PREFETCH2) {
+                                    if (HJB_K3_PREFETCH2) {              // (A/B: two rows ahead - slower, r04_k3_experiments.log)
                                         tr[(q + 2) % 3] = lds_f2(my_t + qn * 256);
                                         rr[(q + 2) % 3] = lds_f2(s_r2 + (q + 2 < kPairsUnrolled ? q + 2 : kPairsUnrolled));
-                                    } else if (q > 0) {                  // (A/B: one pair ahead, as the loops do)
-                                        const int q1 = q + 1 < kLast ? q + 1 : kLast;
-                                        tr[(q + 1) % 3] = lds_f2(my_t + q1 * 256);
+                                    } else if (q > 0 && q + 1 <= kLast) {
+                                        tr[(q + 1) % 3] = lds_f2(my_t + (q + 1) * 256);
                                         rr[(q + 1) % 3] = lds_f2(s_r2 + q + 1);
                                     }
                                     const f2 tc = tr[q % 3], rc = rr[q % 3];
-                                    const bool bx = !(q < PA), by = !(q < PA) || (ST && q == PA);   // second cell: x / y control
                                     const f2 Ex = (q < PA || (ST && q == PA)) ? Ea : Eb, Dx = (q < PA || (ST && q == PA)) ? Da : Db;
                                     const f2 Ey = q < PA ? Ea : Eb, Dy = q < PA ? Da : Db;
-                                    (void)bx; (void)by;
                                     const f2 totx = (g2 + (f2){rc.x, rc.x}) + __builtin_elementwise_fma((f2){tc.x, tc.x}, Dx, Ex);
                                     const f2 toty = (g2 + (f2){rc.y, rc.y}) + __builtin_elementwise_fma((f2){tc.y, tc.y}, Dy, Ey);
                                     mA = __builtin_fminf(__builtin_fminf(mA, totx.x), toty.x);
                                     mB = __builtin_fminf(__builtin_fminf(mB, totx.y), toty.y);
                                 }
-                                t = tr[NF % 3];                                                  // row NF: an odd sweep's last control
-                                r2 = rr[NF % 3];
+                                if constexpr (NF < kPairsUnrolled) {                             // 11 controls: the last one stands alone (row NF, first half)
+                                    constexpr bool second = PA < NF || LS;                       // ... in the second cell when the change came before or at it
+                                    const f2 tc = tr[NF % 3], rc = rr[NF % 3];
+                                    const f2 El = second ? Eb : Ea, Dl = second ? Db : Da;
+                                    const f2 totx = (g2 + (f2){rc.x, rc.x}) + __builtin_elementwise_fma((f2){tc.x, tc.x}, Dl, El);
+                                    mA = __builtin_fminf(mA, totx.x);
+                                    mB = __builtin_fminf(mB, totx.y);
+                                }
                             };
                             // (wave-uniform by construction - jc comes from ballots; readfirstlane says so to the compiler - and a scalar
                             // of THIS trip: one jump, not a chain of hoisted lane masks)
-                            int sel = __builtin_amdgcn_readfirstlane(nfull * 32 + (pa < nfull ? pa : nfull) * 2 + (((jc & 1) && jc < m_in) ? 1 : 0));
+                            int sel = __builtin_amdgcn_readfirstlane(nfull * 64 + (pa < nfull ? pa : nfull) * 4 + (((jc & 1) && jc < m_in) ? 2 : 0)
+                                                                     + (((m_in & 1) && jc == m_in - 1) ? 1 : 0));
                             asm volatile("" : "+s"(sel));
-#define HJB_PF(NF, PA, ST) case (NF) * 32 + (PA) * 2 + (ST): pairs_fixed(std::integral_constant<int, NF>{}, std::integral_constant<int, PA>{}, std::integral_constant<bool, (ST) != 0>{}); break;
+#define HJB_PF(NF, PA, ST, LS) case (NF) * 64 + (PA) * 4 + (ST) * 2 + (LS): pairs_fixed(std::integral_constant<int, NF>{}, std::integral_constant<int, PA>{}, \
+                                       std::integral_constant<bool, (ST) != 0>{}, std::integral_constant<bool, (LS) != 0>{}); break;
+                            if (HJB_K3_PROBE == 3) {
+                                sel = -1;
+                                mA = __builtin_fminf(Ea.x + Da.x, Eb.x + Db.x) + g2.x;
+                                mB = __builtin_fminf(Ea.y + Da.y, Eb.y + Db.y) + g2.y;
+                            }
                             switch (sel) {
-                                HJB_PF(5, 0, 0) HJB_PF(5, 0, 1) HJB_PF(5, 1, 0) HJB_PF(5, 1, 1) HJB_PF(5, 2, 0) HJB_PF(5, 2, 1)
-                                HJB_PF(5, 3, 0) HJB_PF(5, 3, 1) HJB_PF(5, 4, 0) HJB_PF(5, 4, 1) HJB_PF(5, 5, 0)
-                                HJB_PF(6, 0, 0) HJB_PF(6, 0, 1) HJB_PF(6, 1, 0) HJB_PF(6, 1, 1) HJB_PF(6, 2, 0) HJB_PF(6, 2, 1)
-                                HJB_PF(6, 3, 0) HJB_PF(6, 3, 1) HJB_PF(6, 4, 0) HJB_PF(6, 4, 1) HJB_PF(6, 5, 0) HJB_PF(6, 5, 1) HJB_PF(6, 6, 0)
-                                default: break;            // unreachable: npairs == 6 means 5 or 6 full pairs
+                                HJB_PF(5, 0, 0, 0) HJB_PF(5, 0, 1, 0) HJB_PF(5, 1, 0, 0) HJB_PF(5, 1, 1, 0) HJB_PF(5, 2, 0, 0) HJB_PF(5, 2, 1, 0)
+                                HJB_PF(5, 3, 0, 0) HJB_PF(5, 3, 1, 0) HJB_PF(5, 4, 0, 0) HJB_PF(5, 4, 1, 0) HJB_PF(5, 5, 0, 0) HJB_PF(5, 5, 0, 1)
+                                HJB_PF(6, 0, 0, 0) HJB_PF(6, 0, 1, 0) HJB_PF(6, 1, 0, 0) HJB_PF(6, 1, 1, 0) HJB_PF(6, 2, 0, 0) HJB_PF(6, 2, 1, 0)
+                                HJB_PF(6, 3, 0, 0) HJB_PF(6, 3, 1, 0) HJB_PF(6, 4, 0, 0) HJB_PF(6, 4, 1, 0) HJB_PF(6, 5, 0, 0) HJB_PF(6, 5, 1, 0)
+                                HJB_PF(6, 6, 0, 0)
+                                default:                   // npairs == 6 means 5 or 6 full pairs, and the other three fields follow from jc
+                                    if (HJB_K3_PROBE != 3) __builtin_unreachable();
+                                    break;
                             }
 #undef HJB_PF
                         } else {
+                            f2 t = my_t[0];
+                            f2 r2 = s_r2[0];
+                            auto control_pair = [&](int p, const f2 &Ex, const f2 &Dx, const f2 &Ey, const f2 &Dy)
+                                                    __attribute__((always_inline)) {
+                                const f2 totx = (g2 + (f2){r2.x, r2.x}) + __builtin_elementwise_fma((f2){t.x, t.x}, Dx, Ex);
+                                const f2 toty = (g2 + (f2){r2.y, r2.y}) + __builtin_elementwise_fma((f2){t.y, t.y}, Dy, Ey);
+                                t = lds_f2(my_t + t_ahead(p) * 256);                 // next pair
+                                r2 = lds_f2(s_r2 + p + 1);
+                                // left-leaning chains: the instruction selector folds min(min(m, x), y) into ONE v_min3_f32 per pair; written
+                                // min(m, min(x, y)) it pairs the inner minima of two pairs instead (3 instructions per two values)
+                                mA = __builtin_fminf(__builtin_fminf(mA, totx.x), toty.x);
+                                mB = __builtin_fminf(__builtin_fminf(mB, totx.y), toty.y);
+                            };
+                            int p = 0;
 #pragma unroll 2
                             for (; p < pa; ++p) control_pair(p, Ea, Da, Ea, Da);
                             if ((jc & 1) && jc < m_in) {                         // the change falls on a pair's second control
@@ -811,22 +840,28 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                             }
 #pragma unroll 2
                             for (; p < nfull; ++p) control_pair(p, Eb, Db, Eb, Db);
+                            if (m_in & 1) {                                      // the last control of an odd sweep, alone
+                                const bool second = jc < m_in;                   // (wave-uniform) it lies in the second cell
+                                const f2 El = second ? Eb : Ea, Dl = second ? Db : Da;
+                                const f2 totx = (g2 + (f2){r2.x, r2.x}) + __builtin_elementwise_fma((f2){t.x, t.x}, Dl, El);
+                                mA = __builtin_fminf(mA, totx.x);
+                                mB = __builtin_fminf(mB, totx.y);
+                            }
                         }
-                        if (m_in & 1) {                                          // the last control of an odd sweep, alone
-                            const bool second = jc < m_in;                       // (wave-uniform) it lies in the second cell
-                            const f2 El = second ? Eb : Ea, Dl = second ? Db : Da;
-                            const f2 totx = (g2 + (f2){r2.x, r2.x}) + __builtin_elementwise_fma((f2){t.x, t.x}, Dl, El);
-                            mA = __builtin_fminf(mA, totx.x);
-                            mB = __builtin_fminf(mB, totx.y);
-                        }
+                        const int uo = uo0 + o1;
                         if (uo == 0 || mA < best) { best = mA; best_uo = uo; }
                         if (mB < best) { best = mB; best_uo = uo + 1; }
                         o1 += 2;
-                        uo += 2;
                     }
+                    e_nx = eA;                                                   // the one-step loop below takes over at o1
+                    if (o1 < m_o1) g_nx = level1_cost(o1);
                 }
             }
-            for (; o1 < m_o1; ++o1, ++uo) {
+            if (HJB_K3_PROBE == 1) {
+                for (int rb = 0; rb < (HIER ? 3 : 1); ++rb) for (int q = 0; q < 4; ++q) best = __builtin_fminf(best, F[rb][q]);
+            }
+            for (; HJB_K3_PROBE != 1 && o1 < m_o1; ++o1) {
+                const int uo = uo0 + o1;
                 // ---- level 1: (E0, dE) of the two last-axis cells this state visits ----------
                 float e0a, dea, e0b, deb;
                 if constexpr (HIER) {
