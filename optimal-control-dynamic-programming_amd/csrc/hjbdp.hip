@@ -1231,7 +1231,9 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
 // within three times the chip's 5120 wave slots (5 waves per SIMD) and every part keeps >= 12 steps (a part starts by
 // priming: about a step and a half of extra gathers).  Measured on one middle rank of an 8-GPU run of C4 (15 planes =
 // 3600 columns, profiles/r02_rank_slab_timing.log): 1 / 2 / 4 / 8 parts -> 0.270 / 0.249 / 0.233 / 0.235 ms per stage;
-// a boundary strip (240 columns) lasts 15 steps instead of 120; the whole grid (28800 columns) keeps one part.
+// a boundary strip (240 columns) lasts 15 steps instead of 120.  Round 4, whole grids (launches far beyond the wave slots): parts of
+// ~60 steps beat one long column by 1-2 % on every shape tried (120^4: 1 / 2 / 3 parts 1.674 / 1.640 / 1.647 ms; 160 steps: 1.551 /
+// 1.527 / 1.516; 80 steps: equal; profiles/r04_c4_split.log) - so a column is also cut into round(n1 / 60) parts.
 void colsweep_split(Handle *h) {
     const DParams &P = h->hp;
     DColSweep &CSh = h->hcs;
@@ -1243,6 +1245,7 @@ void colsweep_split(Handle *h) {
     if (S <= 0) {
         S = 1;
         while (S < 8 && waves * S * 2 <= 3 * 5120 && n1 / (S * 2) >= 12) S *= 2;
+        S = std::max(S, std::min(8, (n1 + 30) / 60));
     }
     CSh.split = std::max(1, std::min(S, std::max(1, n1)));
 }

@@ -665,6 +665,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                 return b;
             };
             int o1 = 0;
+            // (the window modes only: at the C2 modes' 96-register budget the eight kept values cost nine spills to
+            // scratch - 40 MB of write-back per C2 stage - and buy nothing measurable there)
+            constexpr bool KEEP_ROWS = PRE;
+            int cell_rows = -1;                                          // the level-1 cell the kept rows were selected for (none yet)
+            float R0[4], RD[4];
             // ---- hierarchical modes, TWO (o0, o1) steps per trip --------------------------------------------
             // When every cell change of the wave is a wave-uniform first crossing (UX == 0: the C2 and attitude
             // shapes) and both steps stay inside the prepared window, steps o1 and o1+1 share one pass over the
@@ -673,11 +678,6 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             // same first-minimum.  Anything else falls through to the one-step loop below.
             if constexpr (HIER) {
                 if (UX == 0u && !slow_a) {
-                    // (the window modes only: at the C2 modes' 96-register budget the eight kept values cost nine spills to
-                    // scratch - 40 MB of write-back per C2 stage - and buy nothing measurable there)
-                    constexpr bool KEEP_ROWS = PRE;
-                    int cell_rows = -1;                                          // the level-1 cell the kept rows were selected for (none yet)
-                    float R0[4], RD[4];
                     // the two steps' entries are carried from trip to trip and reloaded IN PLACE once the trip has used them (index clamped
                     // to the last step: no test, nothing to merge): no "next" copies to rotate at the end of a trip
                     i2v eA = e_nx, eB = e_nx2;
@@ -763,6 +763,10 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                                 rr[0] = lds_f2(s_r2);
                                 tr[1] = lds_f2(my_t + 256);
                                 rr[1] = lds_f2(s_r2 + 1);
+                                // (a marker that differs per sequence: the four reads above may be hoisted in front of the jump, the arithmetic
+                                // below may not - hoisted, its {t, t} operand pairs are built with moves in the jump's block instead of being
+                                // folded into the packed instructions' operand selects: 6 moves per trip)
+                                asm volatile("; trip shape %2" : "+v"(tr[0]), "+v"(tr[1]) : "n"(NF * 64 + PA * 4 + (ST ? 2 : 0) + (LS ? 1 : 0)));
 #pragma unroll
                                 for (int q = 0; q < NF; ++q) {
                                     constexpr int kLast = kPairsUnrolled - 1;
@@ -873,7 +877,14 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         g_nx = level1_cost(o1 + 1);
                     }
                     const int r = cell[AX_B] - c1min;
-                    if ((r == 0 || r == 1) && !slow_a) {                 // inside the prepared 2-cell window
+                    if (KEEP_ROWS && !__any(cell[AX_B] != cell_rows)) {  // the rows the trips kept (hence inside the window): 4 fmas
+                        const float t1 = tw[AX_B];
+                        float X[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) X[q] = __builtin_fmaf(t1, RD[q], R0[q]);
+                        e0a = X[0]; dea = X[1] - X[0];
+                        e0b = X[2]; deb = X[3] - X[2];
+                    } else if ((r == 0 || r == 1) && !slow_a) {          // inside the prepared 2-cell window
                         const bool up = r != 0;
                         const float t1 = tw[AX_B];
                         float X[4];

@@ -54,6 +54,6 @@ for v in variants:
         print(label, "variant", v, "refused:", e)
         continue
     b = spec.nS * spec.nU * out["stages_done"]
-    print("%s variant %d (ran %d): %.3f ms/stage, %.3e backups/s (halo %d/%d) sumJ %.9e" % (
-        label, v, info["kernel_variant"], out["sweep_ms"] / out["stages_done"], b / (out["sweep_ms"] * 1e-3),
+    print("%s grid %s: %d workgroups, variant %d (ran %d): %.4f ms/stage, %.3e backups/s (halo %d/%d) sumJ %.9e" % (
+        label, "x".join(str(len(k)) for k in spec.knots), info["grid"], v, info["kernel_variant"], out["sweep_ms"] / out["stages_done"], b / (out["sweep_ms"] * 1e-3),
         info["halo_needed_lo"], info["halo_needed_hi"], float(out["J"].astype(np.float64).sum())), flush=True)
