@@ -25,6 +25,8 @@ with hjbdp.Backup(pspec) as bk:
         bk.set_option("variant", variant)
     if os.environ.get("WINDOW"):
         bk.set_option("window_planes", int(os.environ["WINDOW"]))
+    if os.environ.get("LDS_PAD"):                # extra LDS per workgroup: 16384 leaves three workgroups per CU instead of four
+        bk.set_option("lds_pad", int(os.environ["LDS_PAD"]))
     print(bk.info(), "packed2_mode", bk.get_option("packed2_mode"), flush=True)
     bk.solve(1)
     out = bk.solve(stages)
