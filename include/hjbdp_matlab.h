@@ -37,6 +37,10 @@ int32_t hjb_solve_flat(void *handle, int32_t n_stages, int32_t monitor_period, d
                        int32_t *stopped_early, double *sweep_ms);
 /* one stage: [F.Values, idx] = min(J_stage + F(x_next...), [], ctrl_dim)  (Dynamic_Solver.m:207-210) */
 int32_t hjb_backup_stage(void *handle, const void *J_next, void *J_out, void *idx_out);
+/* ... on device buffers (hjb_device_malloc below), asynchronous: the entry point of a host that keeps its own `for k` loop
+ * (hjbdp_solve.m 'on_stage'); stream NULL = the default stream.  hjb_check_device_status synchronises and reports a left slab. */
+int32_t hjb_backup_stage_device(void *handle, const void *dJ_next, void *dJ_out, void *d_idx_out, void *stream);
+int32_t hjb_check_device_status(void *handle, void *stream);
 int32_t hjb_get_info_flat(void *handle, int64_t *out8);
 int32_t hjb_set_option(void *handle, const char *key, int64_t value);
 int32_t hjb_get_option(void *handle, const char *key, int64_t *value);

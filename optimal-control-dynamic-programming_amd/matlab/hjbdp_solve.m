@@ -38,6 +38,10 @@ function out = hjbdp_solve(prob, n_stages, varargin)
 %   'labels' (default 'int32'; 'uint8' | 'uint16' | 'auto'): storage class of the argmin labels inside the library and on
 %   the way back (hjbdp.h HJB_IDX_*; 'auto' = the narrowest that holds prod(m)): Solver_pos_att's U_Optimal_id has 9 values.
 %   out.idx is converted to double either way (MATLAB's min returns double indices).
+%   'on_stage' (default []; a function handle, single device): the caller KEEPS ITS OWN `for k` LOOP - the stage loop below runs in
+%   MATLAB on device-resident buffers (hjb_device_malloc / hjb_backup_stage_device: one asynchronous launch per stage, J never
+%   crosses PCIe between stages, unlike hjb_backup_stage on host arrays) and calls stop = on_stage(k_s) after stage k_s is
+%   enqueued (k_s = n_stages .. 1 as in Dynamic_Solver.m:86); a true return value ends the sweep.  No monitor, no keep_stages.
 %   out: J (final values), idx (1-based argmin labels), and with keep_stages J_stages / idx_stages
 %        [nS x n_stages] with stage k_s in column k_s, stages_done, stopped_early, sweep_ms.
 %
@@ -53,6 +57,7 @@ function out = hjbdp_solve(prob, n_stages, varargin)
     addParameter(p, 'monitor_single', false);
     addParameter(p, 'double_cost', false);
     addParameter(p, 'labels', 'int32');
+    addParameter(p, 'on_stage', []);
     parse(p, varargin{:});
     o = p.Results;
     L = 'libhjbdp';
@@ -135,8 +140,34 @@ function out = hjbdp_solve(prob, n_stages, varargin)
         if o.keep_stages
             Js = libpointer(ptr, zeros(nS * n_stages, 1, cls));  Is = libpointer(iptr, zeros(nS * n_stages, 1, icls));
         end
-        check(calllib(L, 'hjb_solve_flat', hv, int32(n_stages), int32(o.monitor_period), o.monitor_tol, term, Jf, If, Js, Is, ...
-                      done, early, ms), hv, 'handle');
+        if isempty(o.on_stage)
+            check(calllib(L, 'hjb_solve_flat', hv, int32(n_stages), int32(o.monitor_period), o.monitor_tol, term, Jf, If, Js, Is, ...
+                          done, early, ms), hv, 'handle');
+        else
+            % the caller's own stage loop on device buffers (the `for k_s = n_stages:-1:1` of Dynamic_Solver.m:86-102)
+            if o.keep_stages || o.monitor_period > 0, error('hjbdp:on_stage', 'on_stage runs without keep_stages and monitor'); end
+            dev = int32(o.devices);
+            jbytes = int64(nS * (4 + 4 * ~prob.single));  ibytes = int64(nS * numel(typecast(cast(0, icls), 'uint8')));
+            dJ = {libpointer('voidPtrPtr'), libpointer('voidPtrPtr')};  dI = libpointer('voidPtrPtr');
+            check(calllib(L, 'hjb_device_malloc', dev, jbytes, dJ{1}), hv, 'handle');
+            free1 = onCleanup(@() calllib(L, 'hjb_device_free', dev, dJ{1}.Value));
+            check(calllib(L, 'hjb_device_malloc', dev, jbytes, dJ{2}), hv, 'handle');
+            free2 = onCleanup(@() calllib(L, 'hjb_device_free', dev, dJ{2}.Value));
+            check(calllib(L, 'hjb_device_malloc', dev, ibytes, dI), hv, 'handle');
+            free3 = onCleanup(@() calllib(L, 'hjb_device_free', dev, dI.Value));
+            if isempty(term), term = zeros(nS, 1, cls); end
+            check(calllib(L, 'hjb_device_copy', dev, dJ{1}.Value, term, jbytes, int32(0)), hv, 'handle');     % HJB_COPY_H2D
+            cur = 1;  t0 = tic;  nd = 0;
+            for k_s = n_stages:-1:1
+                check(calllib(L, 'hjb_backup_stage_device', hv, dJ{cur}.Value, dJ{3 - cur}.Value, dI.Value, []), hv, 'handle');
+                cur = 3 - cur;  nd = nd + 1;
+                if o.on_stage(k_s), break; end
+            end
+            check(calllib(L, 'hjb_check_device_status', hv, []), hv, 'handle');       % synchronises; a query that left the grid
+            ms.Value = 1e3 * toc(t0);  done.Value = int32(nd);  early.Value = int32(nd < n_stages);
+            check(calllib(L, 'hjb_device_copy', dev, Jf, dJ{cur}.Value, jbytes, int32(1)), hv, 'handle');      % HJB_COPY_D2H
+            check(calllib(L, 'hjb_device_copy', dev, If, dI.Value, ibytes, int32(1)), hv, 'handle');
+        end
     else
         if o.keep_stages, error('hjbdp:multi', 'keep_stages needs a single device'); end
         check(calllib(L, 'hjb_create_multi_from', bv, int32(numel(o.devices)), int32(o.devices), h), bv, 'builder');

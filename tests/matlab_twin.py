@@ -9,6 +9,7 @@ constructors (hjbdp/solver_*.py restate the reference constructors).  tests/test
 compares with the Python mirrors (which are oracle-checked); tests/test_abi.py checks every calllib in the .m files against
 the header and that this file calls exactly the functions hjbdp_solve.m calls."""
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -20,7 +21,7 @@ def T(dims, data):
 
 
 def hjbdp_solve(lib, prob, n_stages, keep_stages=False, monitor_period=0, monitor_tol=0.0, devices=0, fast_axes=False,
-                double_tables=False, monitor_single=False, labels="int32", double_cost=False):
+                double_tables=False, monitor_single=False, labels="int32", double_cost=False, on_stage=None):
     D, Cn = len(prob["knots"]), len(prob["m"])
     cls, dt = (np.float32, 0) if prob["single"] else (np.float64, 1)
     n = [len(k) for k in prob["knots"]]
@@ -96,9 +97,37 @@ def hjbdp_solve(lib, prob, n_stages, keep_stages=False, monitor_period=0, monito
                 if keep_stages:
                     Js = np.zeros(nS * n_stages, dtype=cls)
                     Is = np.zeros(nS * n_stages, dtype=icls)
-                check(lib.hjb_solve_flat(h, n_stages, monitor_period, float(monitor_tol), None if term is None else term.ctypes.data,
-                                         Jf.ctypes.data, If.ctypes.data, None if Js is None else Js.ctypes.data,
-                                         None if Is is None else Is.ctypes.data, C.byref(done), C.byref(early), C.byref(ms)), h, "handle")
+                if on_stage is None:
+                    check(lib.hjb_solve_flat(h, n_stages, monitor_period, float(monitor_tol), None if term is None else term.ctypes.data,
+                                             Jf.ctypes.data, If.ctypes.data, None if Js is None else Js.ctypes.data,
+                                             None if Is is None else Is.ctypes.data, C.byref(done), C.byref(early), C.byref(ms)), h, "handle")
+                else:       # the caller's own stage loop on device buffers
+                    if keep_stages or monitor_period > 0:
+                        raise ValueError("on_stage runs without keep_stages and monitor")
+                    dev = int(devices)
+                    jbytes, ibytes = nS * (4 if prob["single"] else 8), nS * np.dtype(icls).itemsize
+                    dJ, dI = [C.c_void_p(), C.c_void_p()], C.c_void_p()
+                    try:
+                        check(lib.hjb_device_malloc(dev, jbytes, C.byref(dJ[0])), h, "handle")
+                        check(lib.hjb_device_malloc(dev, jbytes, C.byref(dJ[1])), h, "handle")
+                        check(lib.hjb_device_malloc(dev, ibytes, C.byref(dI)), h, "handle")
+                        if term is None:
+                            term = np.zeros(nS, dtype=cls)
+                        check(lib.hjb_device_copy(dev, dJ[0], term.ctypes.data, jbytes, 0), h, "handle")
+                        cur, nd, t0 = 0, 0, time.time()
+                        for k_s in range(n_stages, 0, -1):
+                            check(lib.hjb_backup_stage_device(h, dJ[cur], dJ[1 - cur], dI, None), h, "handle")
+                            cur, nd = 1 - cur, nd + 1
+                            if on_stage(k_s):
+                                break
+                        check(lib.hjb_check_device_status(h, None), h, "handle")
+                        ms.value, done.value, early.value = 1e3 * (time.time() - t0), nd, int(nd < n_stages)
+                        check(lib.hjb_device_copy(dev, Jf.ctypes.data, dJ[cur], jbytes, 1), h, "handle")
+                        check(lib.hjb_device_copy(dev, If.ctypes.data, dI, ibytes, 1), h, "handle")
+                    finally:
+                        for q in (dJ[0], dJ[1], dI):
+                            if q:
+                                lib.hjb_device_free(dev, q)
             finally:
                 lib.hjb_destroy(h)
         else:

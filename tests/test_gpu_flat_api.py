@@ -364,6 +364,17 @@ def test_matlab_shim_sequences_solver_position(env):
     # ... and on two "devices" of this process (hjb_create_multi_from / hjb_solve_multi_flat)
     out2 = mt.hjbdp_solve(lib, mt.position_channel_prob(ref, 0), 40, devices=[0, 0])
     assert np.array_equal(out2["J"], sp.F_values[0]) and np.array_equal(out2["idx"], sp.U_idx[0])
+    # ... and with the caller keeping its own `for k` loop on device buffers (hjbdp_solve.m 'on_stage': hjb_device_malloc /
+    # hjb_backup_stage_device / hjb_check_device_status / hjb_device_copy): the same bits, every stage seen, early stop honoured
+    seen = []
+    out3 = mt.hjbdp_solve(lib, mt.position_channel_prob(ref, 0), 40, on_stage=lambda k: seen.append(k) or False)
+    assert seen == list(range(40, 0, -1)) and out3["stages_done"] == 40 and not out3["stopped_early"]
+    assert np.array_equal(out3["J"], sp.F_values[0]) and np.array_equal(out3["idx"], sp.U_idx[0])
+    sp7 = hjbdp.Solver_position()
+    sp7.simplified_run(n_stages=7)
+    out4 = mt.hjbdp_solve(lib, mt.position_channel_prob(ref, 0), 40, on_stage=lambda k: k == 34)       # stages 40 .. 34: seven
+    assert out4["stages_done"] == 7 and out4["stopped_early"]
+    assert np.array_equal(out4["J"], sp7.F_values[0]) and np.array_equal(out4["idx"], sp7.U_idx[0])
 
 
 @pytest.mark.order(8)
