@@ -165,10 +165,13 @@ __device__ __forceinline__ float contract_df(const TJ *__restrict__ Jn, int off,
 //   3  mode 2 with D == 6 and the three leading axes driven by HJB_MODEL_QUAT_EULER321 (their next value is
 //      computed per state instead of read from nS-sized tables) and 64-bit state indexing: C3, 51^6 states.
 // Same lerp order (axis 0 first ... last axis last) -> same bits in every mode.
+#ifndef HJB_K3_M1_WAVES
+#define HJB_K3_M1_WAVES 5
+#endif
 template <typename TJ, int D, int MODE>
 // The C2 modes are held to 96 VGPRs = five waves per SIMD (ten values spilled; 1.40 -> 1.35 ms per stage on C2; six waves
 // = 80 VGPRs spill 44 and run 1.7x slower); the window modes sit at three workgroups per CU by LDS whatever the registers.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 4 || MODE == 1) ? 5 : ((MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1))))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 4 || MODE == 1) ? HJB_K3_M1_WAVES : ((MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1))))
 k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, const TJ *__restrict__ Jn,
                  TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     constexpr int DM = D > 1 ? D - 1 : 1;
@@ -191,7 +194,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     // W3P (any D >= 4): the host has checked that the inner control moves the last axis by less than one cell per step, so the second cell
     // a sweep enters is a neighbour of the first and the window needs 3 last-axis planes, not 4: 27 entries - with no padding
     // row in the weights 40 KB of LDS per workgroup on the 11-torque attitude grids, i.e. FOUR workgroups per CU instead of three
-    constexpr int kPairsUnrolled = 6;                      // the pair count the window modes' sweep is written out for
+    constexpr int kPairsUnrolled = M1 ? 11 : 6;            // the pair-row count the two-step trips' sweep is written out for: the window modes' 11 / 12
+                                                           // inner controls (6-D attitude grids, C3); modes 1 / 4: 21 (C2's 21^3 controls)
     constexpr int kWin = PRE ? (W3P ? 27 : 36) : 0;
     constexpr int kWq = W3P ? 3 : 4;                        // window planes
     float *my_w = reinterpret_cast<float *>(smem_raw) + threadIdx.x;
@@ -746,7 +750,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #ifndef HJB_K3_UNROLLED_PAIRS
 #define HJB_K3_UNROLLED_PAIRS 1
 #endif
-                        if (HJB_K3_UNROLLED_PAIRS && PRE && npairs == kPairsUnrolled) {
+                        if (HJB_K3_UNROLLED_PAIRS && (PRE || (M1 && (m_in & 1))) && npairs == kPairsUnrolled) {
                             // The window modes' usual sweep (11 or 12 inner controls = 6 pair rows; C3, the 6-D grids): the sweep written
                             // out STRAIGHT-LINE for the trip's shape - 11 controls (5 pairs + one alone) or 12 (6 pairs), how many pairs
                             // lie wholly in the first cell, whether the wave's one cell change splits a pair or falls on the control that
@@ -810,15 +814,27 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                                 mA = __builtin_fminf(Ea.x + Da.x, Eb.x + Db.x) + g2.x;
                                 mB = __builtin_fminf(Ea.y + Da.y, Eb.y + Db.y) + g2.y;
                             }
-                            switch (sel) {
-                                HJB_PF(5, 0, 0, 0) HJB_PF(5, 0, 1, 0) HJB_PF(5, 1, 0, 0) HJB_PF(5, 1, 1, 0) HJB_PF(5, 2, 0, 0) HJB_PF(5, 2, 1, 0)
-                                HJB_PF(5, 3, 0, 0) HJB_PF(5, 3, 1, 0) HJB_PF(5, 4, 0, 0) HJB_PF(5, 4, 1, 0) HJB_PF(5, 5, 0, 0) HJB_PF(5, 5, 0, 1)
-                                HJB_PF(6, 0, 0, 0) HJB_PF(6, 0, 1, 0) HJB_PF(6, 1, 0, 0) HJB_PF(6, 1, 1, 0) HJB_PF(6, 2, 0, 0) HJB_PF(6, 2, 1, 0)
-                                HJB_PF(6, 3, 0, 0) HJB_PF(6, 3, 1, 0) HJB_PF(6, 4, 0, 0) HJB_PF(6, 4, 1, 0) HJB_PF(6, 5, 0, 0) HJB_PF(6, 5, 1, 0)
-                                HJB_PF(6, 6, 0, 0)
-                                default:                   // npairs == 6 means 5 or 6 full pairs, and the other three fields follow from jc
-                                    if (HJB_K3_PROBE != 3) __builtin_unreachable();
-                                    break;
+                            if constexpr (M1) {                                // 21 controls: ten full pairs + one control alone
+                                switch (sel) {
+                                    HJB_PF(10, 0, 0, 0) HJB_PF(10, 0, 1, 0) HJB_PF(10, 1, 0, 0) HJB_PF(10, 1, 1, 0) HJB_PF(10, 2, 0, 0) HJB_PF(10, 2, 1, 0)
+                                    HJB_PF(10, 3, 0, 0) HJB_PF(10, 3, 1, 0) HJB_PF(10, 4, 0, 0) HJB_PF(10, 4, 1, 0) HJB_PF(10, 5, 0, 0) HJB_PF(10, 5, 1, 0)
+                                    HJB_PF(10, 6, 0, 0) HJB_PF(10, 6, 1, 0) HJB_PF(10, 7, 0, 0) HJB_PF(10, 7, 1, 0) HJB_PF(10, 8, 0, 0) HJB_PF(10, 8, 1, 0)
+                                    HJB_PF(10, 9, 0, 0) HJB_PF(10, 9, 1, 0) HJB_PF(10, 10, 0, 0) HJB_PF(10, 10, 0, 1)
+                                    default:
+                                        if (HJB_K3_PROBE != 3) __builtin_unreachable();
+                                        break;
+                                }
+                            } else {
+                                switch (sel) {
+                                    HJB_PF(5, 0, 0, 0) HJB_PF(5, 0, 1, 0) HJB_PF(5, 1, 0, 0) HJB_PF(5, 1, 1, 0) HJB_PF(5, 2, 0, 0) HJB_PF(5, 2, 1, 0)
+                                    HJB_PF(5, 3, 0, 0) HJB_PF(5, 3, 1, 0) HJB_PF(5, 4, 0, 0) HJB_PF(5, 4, 1, 0) HJB_PF(5, 5, 0, 0) HJB_PF(5, 5, 0, 1)
+                                    HJB_PF(6, 0, 0, 0) HJB_PF(6, 0, 1, 0) HJB_PF(6, 1, 0, 0) HJB_PF(6, 1, 1, 0) HJB_PF(6, 2, 0, 0) HJB_PF(6, 2, 1, 0)
+                                    HJB_PF(6, 3, 0, 0) HJB_PF(6, 3, 1, 0) HJB_PF(6, 4, 0, 0) HJB_PF(6, 4, 1, 0) HJB_PF(6, 5, 0, 0) HJB_PF(6, 5, 1, 0)
+                                    HJB_PF(6, 6, 0, 0)
+                                    default:               // npairs == 6 means 5 or 6 full pairs, and the other three fields follow from jc
+                                        if (HJB_K3_PROBE != 3) __builtin_unreachable();
+                                        break;
+                                }
                             }
 #undef HJB_PF
                         } else {
