@@ -172,9 +172,26 @@ def test_packed2_occupancy_budgets():
                                capture_output=True, text=True)
             assert r.returncode == 0, r.stderr[-3000:]
             text = open(asm).read()
+            if unit == "stage_packed2_f32.hip":
+                text_c2 = text
             got.update((m[0], (int(m[1]), int(m[2]))) for m in re.findall(
                 r"\.name:\s+_ZN3hjb16k_backup_packed2IfLi(\d+ELi\d+)E\S*\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text))
     assert got["3ELi4"][0] <= 96 and got["3ELi1"][0] <= 96, got          # C2 modes: five waves per SIMD
-    assert got["3ELi4"][1] <= 2, got                                       # ... with next to nothing in scratch
+    # ... with little in scratch (round 4: the 22 straight-line sweeps of the 21-control trip cost 11 spilled registers) and NOTHING of it
+    # inside the two-step trip loop (loop depth 3: state chunk > o0 step > trip), where a scratch access per trip would cost what C3's
+    # pass-loop experiment showed (profiles/r04_k3_experiments.log)
+    assert got["3ELi4"][1] <= 16, got
+    body = text_c2[text_c2.index("_ZN3hjb16k_backup_packed2IfLi3ELi4"):]
+    body = body[body.index("\n_ZN3hjb16k_backup_packed2IfLi3ELi4") + 1:] if "\n_ZN3hjb16k_backup_packed2IfLi3ELi4" in body else body
+    body = body[:body.index("s_endpgm")]
+    depth, deep = 0, []
+    for ln in body.splitlines():
+        m = re.match(r"^\.LBB\d+_\d+:\s*(;.*)?$", ln)
+        if m:
+            d = re.search(r"Depth=(\d+)", m.group(1) or "")
+            depth = int(d.group(1)) if d else 0
+        elif "scratch_" in ln and depth >= 3:
+            deep.append(ln.strip())
+    assert not deep, deep[:5]
     for key in ("6ELi5", "6ELi6"):                                          # three-plane window: four waves per SIMD, no spill
         assert got[key][0] <= 128 and got[key][1] == 0, got
