@@ -741,10 +741,12 @@ int build(Handle *h, const hjb_problem *p) {
             for (int k = P.n_cost_prefix; k < P.n_cost; ++k) ln = ln && (p->cost_terms[k].mask & smask) == 0;
             h->row_lean_ok = ln;
         }
-        // worth it when rows fill the 64-lane waves (>= 70 % of the lanes live) and the grid is large enough for one
-        // wave per row to fill the chip (C4 120^4: 1.9x over variant 5 in the lean form; 60^4: 1.4x)
+        // worth it when rows fill a fair part of the 64-lane waves (C4 120^4: 1.9x over variant 5 in the lean form; 60^4: 1.4x).  Round 4
+        // measured the small and odd-sized pos-att grids too (profiles/r04_small_grids.log): the reference's own 30x30x20x15 (47 % of
+        // the lanes live, 2.7e5 states) 17.9 against 22.2 us per stage, 33x64x48x32 (52 %) 134 against 170 us, 80x80x60x40 (63 %) 0.52
+        // against 0.79 ms - rounds 1 - 3 asked for 70 % and 2^20 states and left those on variant 5
         const double lane_use = (double)p->n[0] / (64.0 * (double)((p->n[0] + 63) / 64));
-        h->row_auto = rw && lane_use >= 0.7 && h->n_owned >= ((int64_t)1 << 20);
+        h->row_auto = rw && lane_use >= 0.45;
     }
     if (p->model) {
         if (!(h->packed_mode && (h->packed_pre == 3 || h->packed_pre == 6)))
@@ -1245,6 +1247,9 @@ void colsweep_split(Handle *h) {
     if (S <= 0) {
         S = 1;
         while (S < 8 && waves * S * 2 <= 3 * 5120 && n1 / (S * 2) >= 12) S *= 2;
+        // launches below one round of the wave slots (the reference's own 30x30x20x15 grid: 450 columns of 20 steps): parts as short as
+        // five steps still pay - 31.3 / 18.7 / 12.8 us per stage in 1 / 2 / 4 parts (profiles/r04_small_grids.log)
+        while (S < 8 && waves * S * 2 <= 4096 && n1 / (S * 2) >= 5) S *= 2;
         S = std::max(S, std::min(8, (n1 + 30) / 60));
     }
     CSh.split = std::max(1, std::min(S, std::max(1, n1)));
