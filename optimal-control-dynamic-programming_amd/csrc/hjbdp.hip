@@ -746,7 +746,9 @@ int build(Handle *h, const hjb_problem *p) {
         // the lanes live, 2.7e5 states) 17.9 against 22.2 us per stage, 33x64x48x32 (52 %) 134 against 170 us, 80x80x60x40 (63 %) 0.52
         // against 0.79 ms - rounds 1 - 3 asked for 70 % and 2^20 states and left those on variant 5
         const double lane_use = (double)p->n[0] / (64.0 * (double)((p->n[0] + 63) / 64));
-        h->row_auto = rw && lane_use >= 0.45;
+        // (the lean form only - control terms of the cost over controls alone; with a materialised (state, control) cost table, the
+        // mirrors' cost_mode 'exact', the row kernel takes 31 us per stage on that grid against the tabled kernel's 22: the old rule stays)
+        h->row_auto = rw && ((h->row_lean_ok && lane_use >= 0.45) || (lane_use >= 0.7 && h->n_owned >= ((int64_t)1 << 20)));
     }
     if (p->model) {
         if (!(h->packed_mode && (h->packed_pre == 3 || h->packed_pre == 6)))
