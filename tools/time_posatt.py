@@ -12,7 +12,7 @@ stages = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 variants = [int(v) for v in sys.argv[3:]] or [5]
 order = os.environ.get("ORDER")
 pa = hjbdp.Solver_pos_att()
-pa.cost_mode = "terms"
+pa.cost_mode = os.environ.get("COST", "terms")          # COST=exact | f64 | terms
 if n:
     pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = n
 for k in ("x", "v", "t", "w"):          # N_X / N_V / N_T / N_W override one axis
