@@ -59,7 +59,18 @@ constexpr int kCsMMax = 6;      // member slots per group: 3 per window pair
 constexpr int kCsNW = 3;        // window knots per group
 constexpr int kCsUMax = 16;     // controls
 constexpr int kCsMaxCu = kLeanMaxCu;
-constexpr int kCsFlush = 20;    // results are parked in LDS and written out every kCsFlush steps
+// Results are parked in LDS and written out every kCsFlush steps.  16 steps (25 KB of LDS per workgroup, was 20 steps / 30 KB) leave room
+// for SIX workgroups per CU, and the usual cost shape (FASTCOST, float32 J storage; with five groups: group axis 2 only - axis 3 would spill seven
+// registers, the binary16 form fifteen)
+// fits 80 registers: six waves per SIMD instead of five, C4 1.686 -> 1.655 ms
+// on one box (profiles/r04_c4_experiments.log).  A/B: -DHJB_CS_FLUSH=20 -DHJB_CS_WAVES=5.
+#ifndef HJB_CS_FLUSH
+#define HJB_CS_FLUSH 16
+#endif
+#ifndef HJB_CS_WAVES
+#define HJB_CS_WAVES 6
+#endif
+constexpr int kCsFlush = HJB_CS_FLUSH;
 constexpr int kCsDppLanes = 60; // states per wave in the one-load form (+ a halo lane + a spare lane pair + 1)
 // The plan of one (i2, i3), 32-bit words:
 //   [0] halo violation flag | groups << 8   [1 + g] byte offset of group g's first corner row
@@ -265,7 +276,8 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
 #endif
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP, bool C64 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
-    HJB_CS_UNROLL2 ? 4 : ((DPP && NG <= 5 && !C64) ? 5 : 1), HJB_CS_UNROLL2 ? 4 : ((DPP && NG <= 5 && !C64) ? 5 : 4))))
+    HJB_CS_UNROLL2 ? 4 : ((DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 1),
+    HJB_CS_UNROLL2 ? 4 : ((DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 4))))
 k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
                   const TJ *__restrict__ Jn, TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");

@@ -2,8 +2,8 @@
 
 K10 (kernels_colsweep.h) issues its corner-row gathers from inline asm and waits for them by count; between a gather and
 its wait the compiler believes the destination register already holds its value, so it must never have a reason to
-move or spill one - and the kernel's speed rests on five waves per SIMD.  Both come down to: the headline
-instantiations fit 96 VGPRs without a spill and without scratch memory."""
+move or spill one - and the kernel's speed rests on six waves per SIMD (round 4; five before).  Both come down to: the headline
+instantiations fit 80 VGPRs with at most one loop-invariant in scratch, touched outside the step body only."""
 import re
 import shutil
 import subprocess
@@ -40,16 +40,20 @@ def cs_asm(tmp_path_factory):
     return asm.read_text()
 
 
-def test_column_sweep_kernels_fit_five_waves_without_spills(cs_asm):
+def test_column_sweep_kernels_fit_six_waves(cs_asm):
     text = cs_asm
     kernels = re.findall(r"\.name:\s+(\S*k_backup_colsweep\S*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
     assert len(kernels) == 4, [k[0] for k in kernels]
+    # round 4: the usual cost shape runs at SIX waves per SIMD (80 registers, 25 KB of LDS per workgroup); at that bound the compiler
+    # keeps ONE loop-invariant in scratch, stored before the step loop and reloaded where the parked results are written out (every
+    # kCsFlush steps) - never between a gather and its wait (test_gathers_in_flight_are_never_touched below)
     for name, vgprs, spills in kernels:
-        assert int(vgprs) <= 96 and int(spills) == 0, (name, vgprs, spills)
-    assert all(int(x) == 0 for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))
+        six = "IffLi2ELi5E" in name or "IffLi3ELi4E" in name       # float32 J, (group axis 2, five groups) / (axis 3, four groups): six waves
+        assert int(vgprs) <= (80 if six else 96) and int(spills) <= (1 if six else 0), (name, vgprs, spills, kernels)
+    assert all(int(x) <= 8 for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))
     # scalar registers may overflow into lanes of a vector register (v_writelane / v_readlane: no memory involved) - a few
     assert all(int(x) <= 8 for x in re.findall(r"\.sgpr_spill_count:\s+(\d+)", text))
-    assert "scratch_" not in text
+    assert text.count("scratch_") <= 3 * len(kernels), text.count("scratch_")
 
 
 def _kernel_bodies(text):
