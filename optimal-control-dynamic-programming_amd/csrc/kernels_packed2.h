@@ -751,8 +751,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #define HJB_K3_UNROLLED_PAIRS 1
 #endif
                         if (HJB_K3_UNROLLED_PAIRS && (PRE || (M1 && (m_in & 1))) && npairs == kPairsUnrolled) {
-                            // The window modes' usual sweep (11 or 12 inner controls = 6 pair rows; C3, the 6-D grids): the sweep written
-                            // out STRAIGHT-LINE for the trip's shape - 11 controls (5 pairs + one alone) or 12 (6 pairs), how many pairs
+                            // The usual sweeps - the window modes' 11 or 12 inner controls (6 pair rows; C3, the 6-D grids) and modes 1 / 4's 21
+                            // (11 pair rows; C2) - are written out STRAIGHT-LINE for the trip's shape - the full pairs (+ one control alone), how many pairs
                             // lie wholly in the first cell, whether the wave's one cell change splits a pair or falls on the control that
                             // stands alone: one scalar jump per trip picks the sequence.  With the pair number a compile-time constant the
                             // LDS rows of (t, r) are read at immediate offsets from two fixed address registers, and with no branch inside
