@@ -1232,7 +1232,7 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
 }
 
 // Variant 7: in how many parts (waves) a column is swept (DColSweep::split).  Automatic: doubled while the launch stays
-// within three times the chip's 5120 wave slots (5 waves per SIMD) and every part keeps >= 12 steps (a part starts by
+// within five times the chip's 6144 wave slots (6 waves per SIMD) and every part keeps >= 12 steps (a part starts by
 // priming: about a step and a half of extra gathers).  Measured on one middle rank of an 8-GPU run of C4 (15 planes =
 // 3600 columns, profiles/r02_rank_slab_timing.log): 1 / 2 / 4 / 8 parts -> 0.270 / 0.249 / 0.233 / 0.235 ms per stage;
 // a boundary strip (240 columns) lasts 15 steps instead of 120.  Round 4, whole grids (launches far beyond the wave slots): parts of
@@ -1248,7 +1248,9 @@ void colsweep_split(Handle *h) {
     int S = h->cs_split;
     if (S <= 0) {
         S = 1;
-        while (S < 8 && waves * S * 2 <= 3 * 5120 && n1 / (S * 2) >= 12) S *= 2;
+        // (five rounds of the 6144 wave slots at six waves per SIMD; rounds 2 - 3 said three rounds of 5120: a middle rank of a 4-GPU run of
+        // C4 - 7200 columns - in 2 / 3 / 4 parts 0.430 / 0.419 / 0.416 ms fused, 0.456 / 0.440 / 0.438 with its strips beside the interior)
+        while (S < 8 && waves * S * 2 <= 5 * 6144 && n1 / (S * 2) >= 12) S *= 2;
         // launches below one round of the wave slots (the reference's own 30x30x20x15 grid: 450 columns of 20 steps): parts as short as
         // five steps still pay - 31.3 / 18.7 / 12.8 us per stage in 1 / 2 / 4 parts (profiles/r04_small_grids.log)
         while (S < 8 && waves * S * 2 <= 4096 && n1 / (S * 2) >= 5) S *= 2;
