@@ -224,6 +224,12 @@ const char *hjb_version(void);
 const char *hjb_status_string(int32_t status);
 /* number of visible HIP devices, or 0 */
 int32_t hjb_device_count(void);
+/* Fault injection for the test suite (NOT for production hosts): an explicit in-process call - the library never reads
+ * the environment to change behaviour.  Keys: "fail_tab64_scratch" (value != 0: the float64 table build's scratch
+ * allocation fails, so that hjb_create's refusal of an unservable HJB_TAB_F64 problem can be tested),
+ * "fail_tabled_alloc" (the (cell, t) table allocation of the table-driven kernels fails: HJB_COST_F64's refusal),
+ * "rccl_only_env" (the RCCL loader tries $HJBDP_RCCL_LIB only: a host without librccl). */
+int32_t hjb_test_hook(const char *key, int64_t value);
 
 /* Threading: a handle is not thread-safe - drive each handle from one host thread.  DIFFERENT handles may be
  * driven from different threads at the same time (each hjb_solve runs on its handle's own HIP stream): this is how
@@ -426,6 +432,12 @@ const char *hjb_rank_last_error(hjb_rank r);
  * lower halo - so the RCCL calls, pointers, counts and stream ordering run on a box with a single GPU.  Option
  * "xfer_delay_us" (emulation only, tools/emulate_ranks.py): a spin of that many microseconds on the transfer stream behind
  * every exchange, standing in for link latency the one-GPU loopback does not have.
+ * Option "monitor_single" (the reference's typing, Solver_pos_att.m:276-282): hjb_rank_sweep forms `e = fsum50 - fsum50_prev`
+ * and `abs(e) < tol` in single precision, as hjb_solve does.  The SUM itself: at world == 1 the library's stated float32
+ * tree (= hjb_solve's, bit for bit); over several ranks each rank's planes are summed in float64 over a fixed tree and
+ * the all-reduce adds the ranks in its own order - reproducible for one world size, NOT bit-identical to the one-device
+ * sum, so a stop decision within rounding of `tol` can fall one monitor period apart.
+ * A host without librccl: hjb_rank_comm_unique_id / hjb_rank_comm_init return HJB_E_UNSUPPORTED with the loader's message.
  * tools/bench_ranks.cpp is a C++ driver on these calls (one process per GPU, no Python). */
 int32_t hjb_rank_comm_unique_id(void *id128_out);
 int32_t hjb_rank_comm_init(hjb_rank r, const void *id128);

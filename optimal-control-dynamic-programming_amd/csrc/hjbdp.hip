@@ -33,6 +33,7 @@
 #include "kernels_tile2d.h"
 #include "kernels_colsweep.h"
 #include "kernels_colcoop.h"
+#include <atomic>
 #include "kernels_probe.h"
 #include "kernels_prep_mfma.h"
 #include "kernels_reduce.h"
@@ -47,6 +48,9 @@ namespace {
 constexpr int kGraphStages = 32;   // even: a replay starts and ends in dJ[0]
 
 thread_local std::string g_last_error;
+std::atomic<int> g_test_fail_tab64_scratch{0};      // hjb_test_hook("fail_tab64_scratch", v): fault injection for the tests
+std::atomic<int> g_test_fail_tabled_alloc{0};       // hjb_test_hook("fail_tabled_alloc", v): the (cell, t) table allocation fails
+std::atomic<int> g_test_rccl_only_env{0};           // hjb_test_hook("rccl_only_env", v): the loader tries $HJBDP_RCCL_LIB only (a host without librccl)
 // Handles may be driven from different host threads (one thread per handle).  HIP stream capture is fragile
 // against "unsafe" calls made elsewhere in the process while it records (device-wide synchronisation, synchronous
 // copies, allocation): a capture takes this lock exclusively, every such call takes it shared.  Kernel launches,
@@ -791,10 +795,10 @@ int launch_prep_any(Handle *h, int D, int grid, int a, const int32_t *dsz, int64
     if constexpr (std::is_same<T, float>::value) {
         if (h->tab64) {
             void *tmp = nullptr;
-            // test hook: HJBDP_TEST_FAIL_TAB64_SCRATCH=1 makes this allocation fail (tests/test_gpu_types.py checks that
-            // hjb_create then fails instead of handing out a handle on float32 queries)
-            const char *tf = getenv("HJBDP_TEST_FAIL_TAB64_SCRATCH");
-            if ((tf && tf[0] == '1') || hipMalloc(&tmp, (size_t)n * sizeof(TabEntry<double>)) != hipSuccess) return fail(h, HJB_E_NOMEM, "float64 table build: scratch of %lld entries", (long long)n);
+            // fault injection: hjb_test_hook("fail_tab64_scratch", 1) - an explicit call from inside the process, never the
+            // environment - makes this allocation fail (tests/test_gpu_types.py checks that hjb_create then fails instead of
+            // handing out a handle on float32 queries)
+            if (g_test_fail_tab64_scratch.load() || hipMalloc(&tmp, (size_t)n * sizeof(TabEntry<double>)) != hipSuccess) return fail(h, HJB_E_NOMEM, "float64 table build: scratch of %lld entries", (long long)n);
             launch_prep_t<double>(D, grid, h->dp64, a, dsz, n, (TabEntry<double> *)tmp);
             hipLaunchKernelGGL(k_tab_narrow, dim3(grid), dim3(256), 0, nullptr, (const TabEntry<double> *)tmp, tab, n);
             const hipError_t e1 = hipDeviceSynchronize();
@@ -830,6 +834,7 @@ int ensure_tabled_t(Handle *h) {
         void *dsz_d = nullptr, *tab = nullptr;
         int st3 = upload(h, dsz, &dsz_d);
         if (st3) return st3;
+        if (g_test_fail_tabled_alloc.load()) return fail(h, HJB_E_NOMEM, "(cell, t) table of axis %d: allocation failed (test hook)", a);
         st3 = dev_alloc(h, (size_t)h->dom_entries[a] * sizeof(TabEntry<T>), &tab);
         if (st3) return st3;
         const int grid = (int)std::min<int64_t>((h->dom_entries[a] + 255) / 256, 65536);
@@ -1435,7 +1440,7 @@ void choose_launch(Handle *h) {
     if ((h->variant == 5 || h->variant == 6) && (h->launch_status = ensure_tabled(h)) != HJB_OK) {
         // a float64-table handle never falls back to a kernel that evaluates the float32 copies of its terms:
         // it keeps its variant and every launch reports the build's status (hjb_create fails on it)
-        if (!h->tab64) h->variant = 0;
+        if (!h->tab64 && !h->cost64) h->variant = 0;          // ... and neither does a float64-cost handle (kernels 5 / 7 only)
     }
     h->block = 256;
     h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
@@ -1700,6 +1705,15 @@ extern "C" {
 
 const char *hjb_version(void) { return "hjbdp 0.1.0 (gfx950)"; }
 
+// Fault injection for the test suite, by explicit call only (the environment never changes what the library does).
+int32_t hjb_test_hook(const char *key, int64_t value) {
+    if (!key) return fail(nullptr, HJB_E_INVALID, "hjb_test_hook: null key");
+    if (!strcmp(key, "fail_tab64_scratch")) { g_test_fail_tab64_scratch.store(value != 0); return HJB_OK; }
+    if (!strcmp(key, "fail_tabled_alloc")) { g_test_fail_tabled_alloc.store(value != 0); return HJB_OK; }
+    if (!strcmp(key, "rccl_only_env")) { g_test_rccl_only_env.store(value != 0); return HJB_OK; }
+    return fail(nullptr, HJB_E_INVALID, "hjb_test_hook: unknown key '%s'", key);
+}
+
 const char *hjb_status_string(int32_t s) {
     switch (s) {
         case HJB_OK: return "ok";
@@ -1842,10 +1856,15 @@ int32_t hjb_create(const hjb_problem *p, int32_t device, hjb_handle *out) {
     }
     for (int k = 0; k < HJB_MAX_TERMS; ++k) h->prob.cost_terms[k].data = nullptr;
     choose_launch(h);
-    if (h->tab64 && (h->launch_status != HJB_OK || h->variant < 5)) {
-        // the caller asked for float64 queries: a handle that cannot serve them is not handed out
+    const bool tab64_bad = h->tab64 && (h->launch_status != HJB_OK || h->variant < 5);
+    const bool cost64_bad = h->cost64 && (h->launch_status != HJB_OK || (h->variant != 5 && h->variant != 7));
+    if (tab64_bad || cost64_bad) {
+        // the caller asked for float64 queries / a float64 stage cost: a handle that cannot serve them is not handed out
         st = h->launch_status != HJB_OK ? h->launch_status : HJB_E_UNSUPPORTED;
-        if (h->err.empty()) (void)fail(h, st, "table_dtype HJB_TAB_F64: the (cell, t) tables could not be built; table_dtype = HJB_TAB_DEFAULT (Python: table_dtype=None) runs float32 queries");
+        if (h->err.empty()) {
+            if (tab64_bad) (void)fail(h, st, "table_dtype HJB_TAB_F64: the (cell, t) tables could not be built; table_dtype = HJB_TAB_DEFAULT (Python: table_dtype=None) runs float32 queries");
+            else (void)fail(h, st, "cost_dtype HJB_COST_F64: the tables of the kernels that serve it (5, 7) could not be built (status %d); cost_dtype = HJB_COST_DEFAULT sums the cost terms in float32", h->launch_status);
+        }
         g_last_error = h->err;
         if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
         for (void *d : h->allocs) (void)hipFree(d);
@@ -3187,6 +3206,7 @@ struct hjb_rank_s {
     bool loopback = false;
     int dtype = HJB_F32, up_needs = 0, dn_needs = 0;
     int64_t xfer_delay_ticks = 0;     // option "xfer_delay_us": a spin of that length behind every exchange (link-latency emulation)
+    bool monitor_single = false;      // option "monitor_single": hjb_rank_sweep's monitor in single precision (see there)
 };
 
 static int rfail(hjb_rank r, int code, const char *fmt, ...) {
@@ -3340,6 +3360,7 @@ int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value) {
         }
         return HJB_OK;
     }
+    if (!strcmp(key, "monitor_single")) r->monitor_single = value != 0;      // ... and on to the handles (hjb_rank_get_option reads it there)
     Handle *hs[4] = {r->whole, r->part[0], r->part[1], r->part[2]};
     for (Handle *h : hs)
         if (h) {
@@ -3437,14 +3458,20 @@ constexpr int kNcclUint8 = 1, kNcclFloat64 = 8, kNcclSum = 0;      // rccl.h: nc
 bool rccl_load() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.lib) return true;
-    const char *names[] = {getenv("HJBDP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const bool only_env = g_test_rccl_only_env.load() != 0;
+    const char *names[] = {getenv("HJBDP_RCCL_LIB"), only_env ? nullptr : "librccl.so.1", only_env ? nullptr : "librccl.so",
+                           only_env ? nullptr : "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
     for (const char *n : names) {
         if (!n || !n[0]) continue;
         lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (lib) break;
     }
-    if (!lib) { g_rccl.why = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return false; }
+    if (!lib) {
+        const char *e = dlerror();        // ONE call: dlerror() clears the error state, a second call returns NULL
+        g_rccl.why = std::string("dlopen(librccl.so.1): ") + (e ? e : "not found");
+        return false;
+    }
     auto sym = [&](const char *name) -> void * {
         void *f = dlsym(lib, name);
         if (!f) g_rccl.why = std::string("librccl lacks ") + name;
@@ -3515,10 +3542,14 @@ int32_t hjb_rank_comm_init(hjb_rank r, const void *id128) {
     memcpy(id.internal, id128, sizeof id.internal);
     // loopback (option "comm_loopback", the one-GPU transport test): a communicator of ONE rank, both neighbours = this rank
     RCCL_TRY(r, g_rccl.CommInitRank(&r->comm, r->loopback ? 1 : r->world, id, r->loopback ? 0 : r->rank));
-    RANKH_TRY(r, hipStreamCreateWithFlags(&r->xfer, hipStreamNonBlocking));
-    RANKH_TRY(r, hipEventCreateWithFlags(&r->xready, hipEventDisableTiming));
-    RANKH_TRY(r, hipMalloc((void **)&r->d_partials, sizeof(double) * 2 * kReduceBlocks));
-    RANKH_TRY(r, hipMalloc((void **)&r->d_sums, sizeof(double) * 2));
+    hipError_t e = hipStreamCreateWithFlags(&r->xfer, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->xready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_partials, sizeof(double) * 2 * kReduceBlocks);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_sums, sizeof(double) * 2);
+    if (e != hipSuccess) {          // leave nothing half-built: a retry must not be refused with "already has a communicator"
+        rank_comm_release(r);
+        return rfail(r, e == hipErrorOutOfMemory ? HJB_E_NOMEM : HJB_E_DEVICE, "hjb_rank_comm_init: %s", hipGetErrorString(e));
+    }
     return HJB_OK;
 }
 
@@ -3577,7 +3608,12 @@ int32_t hjb_rank_monitor_sums(hjb_rank r, const void *dJ, const void *d_idx, voi
     hipStream_t cs = (hipStream_t)compute_stream;
     const size_t plane_b = (size_t)r->inner * r->esz;
     const int64_t n = r->inner * (int64_t)(r->end - r->begin);
-    if (launch_monitor_sums(r->dtype, false, (const char *)dJ + plane_b * r->hlo, d_idx, (int32_t)r->isz, n, r->d_partials, r->d_sums, cs) != HJB_OK)
+    // option "monitor_single" at world == 1: the library's stated float32 tree over the whole grid, exactly hjb_solve's sum.
+    // Over several ranks a float32 running sum in one fixed order does not exist: each rank sums its planes in float64 (fixed
+    // tree) and the all-reduce adds the ranks in ITS order - reproducible for a given world size, not bit-identical to
+    // hjb_solve's sum; hjb_rank_sweep then forms the difference and the comparison in single (below).
+    const bool single_tree = r->monitor_single && r->world == 1 && !r->loopback && r->dtype != HJB_F64;
+    if (launch_monitor_sums(r->dtype, single_tree, (const char *)dJ + plane_b * r->hlo, d_idx, (int32_t)r->isz, n, r->d_partials, r->d_sums, cs) != HJB_OK)
         return rfail(r, HJB_E_DEVICE, "monitor reduction launch failed");
     if (!d_idx) RANKH_TRY(r, hipMemsetAsync(r->d_sums + 1, 0, sizeof(double), cs));
     RCCL_TRY(r, g_rccl.AllReduce(r->d_sums, r->d_sums, 2, kNcclFloat64, kNcclSum, r->comm, cs));
@@ -3598,12 +3634,13 @@ int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, dou
     RANKH_TRY(r, hipSetDevice(r->device));
     hipStream_t cs = (hipStream_t)compute_stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    RANKH_TRY(r, hipEventCreate(&e0));
-    RANKH_TRY(r, hipEventCreate(&e1));
-    RANKH_TRY(r, hipEventRecord(e0, cs));
     void *J[2] = {dJ0, dJ1};
     int cur = 0, done = 0, early = 0, st = HJB_OK;
     double fprev = 0.0;
+    // Solver_pos_att.m:276-282 with a single fsum50: the difference and `abs(e) < tol` are single-precision (hjb_solve's rule)
+    const bool msingle = r->monitor_single && r->dtype != HJB_F64;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, cs) != hipSuccess)
+        st = rfail(r, HJB_E_DEVICE, "sweep: event set-up failed: %s", hipGetErrorString(hipGetLastError()));
     for (int k_s = n_stages; k_s >= 1 && !st; --k_s) {
         st = hjb_rank_step(r, J[cur], J[1 - cur], d_idx, compute_stream);
         if (st) break;
@@ -3613,9 +3650,9 @@ int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, dou
             double sums[2];
             st = hjb_rank_monitor_sums(r, J[cur], d_idx, compute_stream, sums);
             if (st) break;
-            const double e = sums[0] - fprev;
+            const double e = msingle ? (double)((float)sums[0] - (float)fprev) : sums[0] - fprev;
             fprev = sums[0];
-            if (std::fabs(e) < monitor_tol) { early = 1; break; }
+            if (msingle ? (std::fabs((float)e) < (float)monitor_tol) : (std::fabs(e) < monitor_tol)) { early = 1; break; }
         }
     }
     if (!st) {
@@ -3626,8 +3663,8 @@ int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, dou
         if (sweep_ms) *sweep_ms = ms;
         if (!st) st = hjb_rank_check_status(r, compute_stream);
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e0) (void)hipEventDestroy(e0);      // one exit: the events never leak
+    if (e1) (void)hipEventDestroy(e1);
     if (stages_done) *stages_done = done;
     if (stopped_early) *stopped_early = early;
     if (final_in_0) *final_in_0 = cur == 0;

@@ -138,6 +138,7 @@ SYMBOLS = {
     "hjb_version": (C.c_char_p, []),
     "hjb_status_string": (C.c_char_p, [C.c_int32]),
     "hjb_device_count": (C.c_int32, []),
+    "hjb_test_hook": (C.c_int32, [C.c_char_p, C.c_int64]),
     "hjb_create": (C.c_int32, [C.POINTER(hjb_problem), C.c_int32, C.POINTER(C.c_void_p)]),
     "hjb_destroy": (C.c_int32, [C.c_void_p]),
     "hjb_last_error": (C.c_char_p, [C.c_void_p]),

@@ -44,6 +44,14 @@ def lib(abi):
         l.orc_backup_states.restype = C.c_int
         l.orc_backup_states.argtypes = [C.POINTER(abi.hjb_problem), C.POINTER(C.c_void_p), C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_int]
+        l.orc_backup_states_from_J.restype = C.c_int
+        l.orc_backup_states_from_J.argtypes = [C.POINTER(abi.hjb_problem), C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_void_p, C.c_int]
+        l.orc_backup_states_touch.restype = C.c_int
+        l.orc_backup_states_touch.argtypes = [C.POINTER(abi.hjb_problem), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]
+        l.orc_backup_states_sparse.restype = C.c_int
+        l.orc_backup_states_sparse.argtypes = [C.POINTER(abi.hjb_problem), C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         l.orc_canon_eval.restype = None
         l.orc_canon_eval.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         l.orc_monitor_sums.restype = C.c_int
@@ -77,6 +85,60 @@ def backup_states(abi, spec, jsep, states, nthreads=0):
                              nthreads or l.orc_max_threads())
     if st != 0:
         raise RuntimeError("orc_backup_states status %d" % st)
+    return J, idx
+
+
+def backup_states_from_J(abi, spec, J_next, states, nthreads=0):
+    """Backup of the listed whole-grid states from a whole-grid float32 J_next held by the host - the deep-sweep check:
+    the GPU's own previous stage, downloaded.  -> (J[k], idx[k])."""
+    l = lib(abi)
+    p, keep = spec.to_c()
+    Jn = np.ascontiguousarray(np.asarray(J_next, dtype=np.float32).reshape(-1, order="F"))
+    if Jn.size != spec.nS:
+        raise ValueError("J_next must hold the whole grid")
+    st_ = np.ascontiguousarray(states, dtype=np.int64)
+    J = np.empty(len(st_), dtype=np.float32)
+    idx = np.empty(len(st_), dtype=np.int32)
+    st = l.orc_backup_states_from_J(C.byref(p), Jn.ctypes.data, st_.ctypes.data, len(st_), J.ctypes.data, idx.ctypes.data,
+                                    nthreads or l.orc_max_threads())
+    if st != 0:
+        raise RuntimeError("orc_backup_states_from_J status %d" % st)
+    return J, idx
+
+
+def backup_states_touch(abi, spec, states, nthreads=0):
+    """Sorted unique offsets of every J_next element the backups of the listed states read (all controls, all corners)."""
+    l = lib(abi)
+    p, keep = spec.to_c()
+    st_ = np.ascontiguousarray(states, dtype=np.int64)
+    cap = spec.nU << spec.D
+    out = []
+    step = max(1, (256 << 20) // (8 * cap))                 # 256 MB of offsets at a time
+    for i in range(0, len(st_), step):
+        part = st_[i:i + step]
+        rec = np.empty(len(part) * cap, dtype=np.int64)
+        st = l.orc_backup_states_touch(C.byref(p), part.ctypes.data, len(part), rec.ctypes.data, cap, nthreads or l.orc_max_threads())
+        if st != 0:
+            raise RuntimeError("orc_backup_states_touch status %d" % st)
+        out.append(np.unique(rec))
+    return np.unique(np.concatenate(out)) if out else np.empty(0, dtype=np.int64)
+
+
+def backup_states_sparse(abi, spec, keys, vals, states, nthreads=0):
+    """Backup of the listed states from J_next sampled at `keys` (sorted offsets, backup_states_touch) = `vals`:
+    the checker for a J_next that lives on the device only (C3).  -> (J[k], idx[k])."""
+    l = lib(abi)
+    p, keep = spec.to_c()
+    k = np.ascontiguousarray(keys, dtype=np.int64)
+    v = np.ascontiguousarray(vals, dtype=np.float32)
+    assert k.size == v.size and np.all(k[1:] > k[:-1])
+    st_ = np.ascontiguousarray(states, dtype=np.int64)
+    J = np.empty(len(st_), dtype=np.float32)
+    idx = np.empty(len(st_), dtype=np.int32)
+    st = l.orc_backup_states_sparse(C.byref(p), k.ctypes.data, v.ctypes.data, k.size, st_.ctypes.data, len(st_),
+                                    J.ctypes.data, idx.ctypes.data, nthreads or l.orc_max_threads())
+    if st != 0:
+        raise RuntimeError("orc_backup_states_sparse status %d" % st)
     return J, idx
 
 

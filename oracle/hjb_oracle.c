@@ -153,11 +153,34 @@ static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float
     out3[2] = canon_atan2f(2.0f * (x5 * x4 + x7 * x6), ((x7 * x7 - x6 * x6) - x5 * x5) + x4 * x4);   /* :488-489 */
 }
 
+/* J_next given as a SAMPLE of a device-resident array (grids whose J does not fit the host: C3's 51^6).  Two passes:
+ * rec != NULL records, per listed state, the offset of every corner every control touches (cap = nU * 2^D slots per
+ * state; values read as 0); keys / vals (sorted offsets + the values the caller gathered there) then serve the real pass. */
+typedef struct {
+    const int64_t *keys;
+    const float *vals;
+    int64_t nkeys;
+    int64_t *rec;
+    int64_t cap;
+} sparse_j;
+
+static inline float sparse_get(const sparse_j *sp, int64_t off, int *miss) {
+    int64_t lo = 0, hi = sp->nkeys - 1;
+    while (lo <= hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sp->keys[mid] == off) return sp->vals[mid];
+        if (sp->keys[mid] < off) lo = mid + 1; else hi = mid - 1;
+    }
+    *miss = 1;
+    return 0.f;
+}
+
 #define DEFINE_BACKUP(T, NAME, FMA)                                                                   \
     static int NAME(const hjb_problem *p, const T *Jn, T *Jout, int32_t *idx_out, int nthreads,        \
-                    const int64_t *sel, int64_t nsel, const T *const *jsep) {                          \
+                    const int64_t *sel, int64_t nsel, const T *const *jsep, const sparse_j *sp) {      \
         /* sel != NULL: only the listed (whole-grid) states, outputs compact [nsel];                  \
-           jsep != NULL: J_next(i) = ((jsep[0][i0] + jsep[1][i1]) + ...) instead of an array */        \
+           jsep != NULL: J_next(i) = ((jsep[0][i0] + jsep[1][i1]) + ...) instead of an array;          \
+           sp != NULL (with sel): J_next sampled / offsets recorded, see sparse_j */                   \
         const int D = p->D, C = p->C;                                                                  \
         const int tab64 = p->table_dtype == HJB_TAB_F64 && sizeof(T) == 4;                             \
         const int cost64 = p->cost_dtype == HJB_COST_F64 && sizeof(T) == 4;   /* Solver_pos_att.m:800-801 */ \
@@ -266,6 +289,8 @@ static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float
                     int64_t off = base;                                                                \
                     for (int a = 0; a < D; ++a)                                                        \
                         if (c & (1 << a)) off += jstride[a];                                           \
+                    if (sp && sp->rec) { sp->rec[it * sp->cap + (u << D) + c] = off; v[c] = 0; continue; } \
+                    if (sp) { int miss = 0; v[c] = (T)sparse_get(sp, off, &miss); if (miss) err = 2; continue; } \
                     if (!jsep) { v[c] = Jn[off]; continue; }                                           \
                     T sv = 0;                                                                          \
                     for (int a = 0; a < D; ++a) {                                                      \
@@ -315,7 +340,7 @@ static void model_quat_next(const hjb_problem *p, const int *gi, float w1, float
             if (idx_out) idx_out[sel ? it : ls] = (int32_t)(best_label + p->index_base);               \
         }                                                                                              \
         for (int a = 0; a < D; ++a) { free(knots[a]); free(rdx[a]); }                                  \
-        return err ? HJB_E_HALO : HJB_OK;                                                              \
+        return err == 2 ? HJB_E_INVALID : err ? HJB_E_HALO : HJB_OK;                                   \
     }
 
 DEFINE_BACKUP(float, backup_f32, fmaf)
@@ -555,13 +580,13 @@ int orc_backup_stage(const hjb_problem *p, const void *J_next, void *J_out, int3
         float *a = (float *)malloc(sizeof(float) * (ne > 0 ? ne : 1)), *b = (float *)malloc(sizeof(float) * (ne > 0 ? ne : 1));
         if (!a || !b) { free(a); free(b); return HJB_E_NOMEM; }
         for (int64_t i = 0; i < ne; ++i) { a[i] = h2f(((const uint16_t *)J_next)[i]); b[i] = h2f(((const uint16_t *)J_out)[i]); }
-        st = backup_f32(p, a, b, idx_out, nthreads, NULL, 0, NULL);
+        st = backup_f32(p, a, b, idx_out, nthreads, NULL, 0, NULL, NULL);
         for (int64_t i = 0; i < ne; ++i) ((uint16_t *)J_out)[i] = f2h(b[i]);
         free(a); free(b);
         return st;
     }
-    if (p->dtype == HJB_F32) return backup_f32(p, (const float *)J_next, (float *)J_out, idx_out, nthreads, NULL, 0, NULL);
-    return backup_f64(p, (const double *)J_next, (double *)J_out, idx_out, nthreads, NULL, 0, NULL);
+    if (p->dtype == HJB_F32) return backup_f32(p, (const float *)J_next, (float *)J_out, idx_out, nthreads, NULL, 0, NULL, NULL);
+    return backup_f64(p, (const double *)J_next, (double *)J_out, idx_out, nthreads, NULL, 0, NULL, NULL);
 }
 
 /* the same backup by the AVX2 row-vectorised form (float32 arithmetic only) */
@@ -590,7 +615,46 @@ int orc_backup_states(const hjb_problem *p, const float *const *jsep, const int6
     int st = validate(p);
     if (st) return st;
     if (p->dtype != HJB_F32 || p->slab_begin || p->slab_end) return HJB_E_UNSUPPORTED;
-    return backup_f32(p, NULL, J_out, idx_out, nthreads, states, nstates, jsep);
+    return backup_f32(p, NULL, J_out, idx_out, nthreads, states, nstates, jsep, NULL);
+}
+
+/* Backup of a LIST of whole-grid states from a whole-grid J_next array held by the host (a deep-sweep check: the GPU's OWN
+ * previous stage, downloaded; 24^6 floats are 764 MB).  HJB_F32, no slab.  Outputs compact. */
+int orc_backup_states_from_J(const hjb_problem *p, const float *J_next, const int64_t *states, int64_t nstates,
+                             float *J_out, int32_t *idx_out, int nthreads) {
+    int st = validate(p);
+    if (st) return st;
+    if (p->dtype != HJB_F32 || p->slab_begin || p->slab_end) return HJB_E_UNSUPPORTED;
+    return backup_f32(p, J_next, J_out, idx_out, nthreads, states, nstates, NULL, NULL);
+}
+
+/* The same for a J_next that exists on the device only (C3: 70 GB).  Pass 1 (orc_backup_states_touch): offsets[k * cap + j],
+ * cap = nU * 2^D, = every J_next element state k's backup reads (duplicates included).  The caller gathers the unique,
+ * sorted offsets from the device (hjb_device_gather) and pass 2 (orc_backup_states_sparse) performs the backup on them;
+ * an offset missing from `keys` is an error (HJB_E_INVALID), never a silent zero. */
+int orc_backup_states_touch(const hjb_problem *p, const int64_t *states, int64_t nstates, int64_t *offsets, int64_t cap,
+                            int nthreads) {
+    int st = validate(p);
+    if (st) return st;
+    if (p->dtype != HJB_F32 || p->slab_begin || p->slab_end) return HJB_E_UNSUPPORTED;
+    int64_t nU = 1;
+    for (int c = 0; c < p->C; ++c) nU *= p->m[c];
+    if (cap != (nU << p->D)) return HJB_E_INVALID;
+    float *J = (float *)malloc(sizeof(float) * (size_t)(nstates > 0 ? nstates : 1));
+    if (!J) return HJB_E_NOMEM;
+    sparse_j sp = {NULL, NULL, 0, offsets, cap};
+    st = backup_f32(p, NULL, J, NULL, nthreads, states, nstates, NULL, &sp);
+    free(J);
+    return st;
+}
+
+int orc_backup_states_sparse(const hjb_problem *p, const int64_t *keys, const float *vals, int64_t nkeys,
+                             const int64_t *states, int64_t nstates, float *J_out, int32_t *idx_out, int nthreads) {
+    int st = validate(p);
+    if (st) return st;
+    if (p->dtype != HJB_F32 || p->slab_begin || p->slab_end) return HJB_E_UNSUPPORTED;
+    sparse_j sp = {keys, vals, nkeys, NULL, 0};
+    return backup_f32(p, NULL, J_out, idx_out, nthreads, states, nstates, NULL, &sp);
 }
 
 /* hjb_solve_opts.monitor_single: MATLAB's sum(F_gI.Values(:)) of a single array (Solver_pos_att.m:274) is a

@@ -193,3 +193,204 @@ def test_attitude_simplified_reference_grid_200_stages_whole_grid(env):
                 out = bk.solve(200, keep_J=True, keep_idx=True)
             assert np.array_equal(out["J_stages"], ref["J_stages"])
             assert np.array_equal(out["idx_stages"], ref["idx_stages"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The 6-D attitude model (BASELINE configs[2]): attitude-control/Solver_attitude.m:261-300 (the stage loop),
+# :384-411 (calculate_J_U_opt_state_M: the 3-level min cascade), :413-506 (the next-state tables).
+# ---------------------------------------------------------------------------------------------------------------------
+def _attitude_asv(hjbdp, h):
+    """Solver_attitude at the size the reference can actually run - the .asv revision's 11^3 (w) x 10^3 (angles) states x
+    3^3 torques (Solver_attitude.asv:97,104), its T_final = 1, h = 0.05 -> 19 stages (:116-122,167)."""
+    sa = hjbdp.Solver_attitude(n_mesh_w=11, n_mesh_q=10)
+    sa.h = h
+    return sa
+
+
+@pytest.mark.order(4)
+@pytest.mark.watchdog(900)
+@pytest.mark.parametrize("h", [0.05, 0.005])
+def test_attitude_run_reference_size_19_stages_whole_grid(env, h):
+    """Row a11 at the only size the reference can run: Solver_attitude.run on 11^3 x 10^3 x 27 over its 19 stages, EVERY
+    state of EVERY stage (J and labels, bit for bit) against the oracle's sweep, in the three forms the library serves it:
+    the reference's axis order (w1, w2, w3, yaw, pitch, roll - the general table kernel), relabelled with the angles first
+    (K3's window modes on tabulated next angles) and with the on-the-fly quaternion model (the kernel mode C3 runs).
+    h = 0.05 is the .asv's step: a torque step moves w by 1.1 - 1.3 cells, so sweeps cross several cells and leave the
+    prepared window (four-plane window modes 2 / 3, synchronous far-cell gathers); h = 0.005 is the committed .m's step
+    (three-plane window modes 5 / 6)."""
+    hjbdp, _abi, c_oracle = env
+    sa = _attitude_asv(hjbdp, h)
+    full = sa.build_spec_full()
+    relab, to_old = hjbdp.permute_state_axes(full, sa.AXIS_ORDER)
+    model = sa.build_spec_model()
+    assert full.n == (11, 11, 11, 10, 10, 10) and relab.n == model.n == (10, 10, 10, 11, 11, 11) and full.nU == 27
+    modes = {}
+    finals = {}
+    for name, spec in (("reference_order", full), ("relabelled", relab), ("on_the_fly", model)):
+        if name == "reference_order" and h != 0.05:
+            continue                                                 # the table kernel's paths do not depend on the step: once
+        with hjbdp.Backup(spec) as bk:
+            inf = bk.info()
+            modes[name] = (inf["kernel_variant"], bk.get_option("packed2_mode"))
+            out = bk.solve(19, keep_J=True, keep_idx=True)
+        ref = c_oracle.sweep(_abi, spec, 19, keep_J=True, keep_idx=True)
+        assert out["stages_done"] == 19
+        bad = np.flatnonzero((out["J_stages"] != ref["J_stages"]).any(axis=0))
+        assert bad.size == 0, (name, "J differs in stage columns", bad)
+        bad = np.flatnonzero((out["idx_stages"] != ref["idx_stages"]).any(axis=0))
+        assert bad.size == 0, (name, "labels differ in stage columns", bad)
+        assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+        assert np.all(np.isfinite(out["J"])) and out["J"].min() >= 0
+        assert len(np.unique(out["idx_stages"])) >= 20, name        # (nearly) every torque triple is optimal somewhere: a real argmin
+        finals[name] = out
+    assert h != 0.05 or modes["reference_order"][0] != 4             # not the relabelled kernel
+    assert modes["relabelled"] == (4, 2 if h == 0.05 else 5), modes
+    assert modes["on_the_fly"] == (4, 3 if h == 0.05 else 6), modes
+    # the three forms compute one function: equal to rounding (lerp order / polynomial atan2 differ), same policy almost everywhere
+    base = "reference_order" if h == 0.05 else "relabelled"
+    a, ia = finals[base]["J"], finals[base]["idx"]
+    if base == "relabelled":
+        a, ia = to_old(a), to_old(ia)
+    for name in ("relabelled", "on_the_fly"):
+        b = to_old(finals[name]["J"])
+        assert np.max(np.abs(a - b)) <= 1e-4 * np.max(np.abs(a)), name
+        assert np.mean(ia == to_old(finals[name]["idx"])) > 0.99, name
+    # the mirror's run() is that sweep (U_i_Opt = U_vector(idx), :296-298)
+    sa.run(n_stages=19, relabel=True)
+    assert np.array_equal(sa.F_values.reshape(-1, order="F"), to_old(finals["relabelled"]["J"]))
+    lab = (sa.U_idx[0] - 1) + 3 * (sa.U_idx[1] - 1) + 9 * (sa.U_idx[2] - 1) + 1
+    assert np.array_equal(lab.reshape(-1, order="F"), to_old(finals["relabelled"]["idx"]))
+
+
+def _sample_6d(spec, rng, n_random, cells_of_last=None):
+    """A sample of linear state indices: random states, every grid corner, edge mid-points, both sides of 256-state chunk
+    boundaries (K3's unit of work) and of plane boundaries, the first and the last state."""
+    n = np.array(spec.n, dtype=np.int64)
+    stride = np.concatenate([[1], np.cumprod(n[:-1])])
+    lin = lambda cs: int(np.dot(np.array(cs, dtype=np.int64), stride))
+    pts = [lin([(c >> a) & 1 and n[a] - 1 for a in range(6)]) for c in range(64)]                 # the 64 corners
+    pts += [lin([n[a] // 2 if a != b else e for a in range(6)]) for b in range(6) for e in (0, n[b] - 1)]   # face centres
+    chunks = rng.integers(1, spec.nS // 256, 40)
+    pts += [int(c) * 256 + d for c in chunks for d in (-1, 0)]
+    planes = rng.integers(1, n[5], 6)
+    pts += [int(p) * int(stride[5]) + d for p in planes for d in (-1, 0)]
+    pts += [0, spec.nS - 1]
+    return np.unique(np.concatenate([rng.integers(0, spec.nS, n_random), np.array(pts, dtype=np.int64)]))
+
+
+def _states_leaving_the_window(spec, pool):
+    """Of the pool, the states whose innermost-control sweep of the last axis (w3 + h(c w1 w2 + U3 / J3), :425) visits
+    three or more cells for at least one (U1, U2): their steps leave K3's two-cell window (the synchronous gather path)."""
+    n = np.array(spec.n, dtype=np.int64)
+    idx = np.stack(np.unravel_index(pool, spec.n, order="F"), axis=0)
+    k = np.asarray(spec.knots[5], dtype=np.float32)
+    base, t3 = spec.next_terms[5][0].data, spec.next_terms[5][1].data            # (w3), (w1, w2, U3)
+    q = (np.asarray(base, dtype=np.float32)[idx[5]][:, None] + np.asarray(t3, dtype=np.float32)[idx[3], idx[4], :]).astype(np.float32)
+    cell = np.clip(np.searchsorted(k, q, side="right") - 1, 0, n[5] - 2)
+    return pool[(cell.max(axis=1) - cell.min(axis=1)) >= 2]
+
+
+@pytest.mark.order(5)
+@pytest.mark.watchdog(900)
+@pytest.mark.parametrize("form,h", [("on_the_fly", 0.005), ("tabulated", 0.005), ("on_the_fly", 0.03)])
+def test_6d_24_pow_6_five_stages_deep(env, form, h):
+    """The 6-D model on 24^6 = 1.9e8 states x 11^3 torques, FIVE stages deep from a zero terminal cost (the reference's
+    start, :271-279), device-resident ping-pong.  After every stage the oracle recomputes >= 10^4 sampled states of stage k
+    from the GPU's OWN stage k+1 (downloaded, 764 MB) - corners, faces, both sides of chunk and plane boundaries, random
+    states and, for the coarse-step case, hundreds of states whose torque sweep leaves the two-cell window - bit for bit.
+    h = 0.03: a torque step moves w3 by 0.36 of a cell (three-plane window still admitted), the sweep of 11 spans 3.6 cells."""
+    hjbdp, _abi, c_oracle = env
+    sa = hjbdp.Solver_attitude(n_mesh_w=24, n_mesh_q=24)
+    sa.U_vector = np.linspace(-0.11, 0.11, 11)
+    sa.h = h
+    if form == "tabulated":
+        spec0, _ = hjbdp.permute_state_axes(sa.build_spec_full(), sa.AXIS_ORDER)
+    else:
+        spec0 = sa.build_spec_model()
+    spec = hjbdp.ProblemSpec(spec0.knots, spec0.m, spec0.next_terms, spec0.cost_terms, dtype=np.float32, index_base=spec0.index_base,
+                             model=spec0.model, idx_dtype="auto")
+    assert spec.nS == 24 ** 6 and spec.nU == 1331 and spec.idx_np_dtype == np.uint16
+    rng = np.random.default_rng(2406)
+    sel = _sample_6d(spec, rng, 10000)
+    far = _states_leaving_the_window(spec, rng.integers(0, spec.nS, 200000))
+    if h >= 0.03:
+        assert far.size > 1000
+        sel = np.unique(np.concatenate([sel, far[:2000]]))
+    else:
+        assert far.size == 0                                    # the committed step: every sweep stays within two cells
+    assert sel.size >= 10000
+    dA, dB = hjbdp.DeviceBuffer(spec.nS * 4), hjbdp.DeviceBuffer(spec.nS * 4)
+    dI = hjbdp.DeviceBuffer(spec.nS * 2)
+    try:
+        with hjbdp.Backup(spec) as bk:
+            assert bk.info()["kernel_variant"] == 4
+            assert bk.get_option("packed2_mode") == (6 if form == "on_the_fly" else 5)
+            J_prev = np.zeros(spec.nS, dtype=np.float32)
+            dA.upload(J_prev)
+            src, dst = dA, dB
+            labels_seen = set()
+            for stage in range(5):
+                bk.backup_stage_device(src, dst, dI)
+                bk.check_device_status()
+                Jr, ir = c_oracle.backup_states_from_J(_abi, spec, J_prev, sel)
+                Jg, ig = dst.gather(np.float32, sel), dI.gather(np.uint16, sel)
+                bad = np.flatnonzero(Jg != Jr)
+                assert bad.size == 0, (stage, "J", sel[bad[:5]], Jg[bad[:5]], Jr[bad[:5]])
+                bad = np.flatnonzero(ig != ir)
+                assert bad.size == 0, (stage, "labels", sel[bad[:5]], ig[bad[:5]], ir[bad[:5]])
+                labels_seen.update(np.unique(ig).tolist())
+                J_prev = dst.download(np.float32)
+                assert np.array_equal(J_prev[sel], Jg)
+                src, dst = dst, src
+            assert np.all(np.isfinite(J_prev)) and J_prev.min() >= 0 and J_prev.max() > 0
+            assert len(labels_seen) > 100                       # stage 5 of a real sweep: many distinct torque triples win
+    finally:
+        dA.free(); dB.free(); dI.free()
+
+
+@pytest.mark.order(6)
+@pytest.mark.watchdog(900)
+def test_c3_full_size_second_stage_from_the_gpus_own_output(env):
+    """BASELINE C3 (51^6 x 11^3, 176 GB resident) TWO stages deep: stage 1 from a separable cost-to-go, stage 2 from the
+    GPU's own stage-1 output - a min over 1331 torque triples, not separable - written over the separable buffer.  The
+    oracle lists every element of stage 1 the sampled states' backups read (all controls x 64 corners), those elements are
+    gathered from the device (hjb_device_gather) and the oracle performs the backup on that sample; J and labels of stage 2
+    must agree bit for bit.  Stage 1 itself is pinned on the same sample by the separable checker."""
+    hjbdp, _abi, c_oracle = env
+    free, total = hjbdp.device_mem_info(0)
+    if free < 190 * 2 ** 30:
+        pytest.skip("needs 190 GB of free HBM, have %.0f GB" % (free / 2 ** 30))
+    sa = hjbdp.Solver_attitude(n_mesh_w=51, n_mesh_q=51)
+    sa.U_vector = np.linspace(-0.11, 0.11, 11)
+    spec0 = sa.build_spec_model()
+    spec = hjbdp.ProblemSpec(spec0.knots, spec0.m, spec0.next_terms, spec0.cost_terms, dtype=np.float32, index_base=spec0.index_base,
+                             model=spec0.model, idx_dtype="auto")
+    assert spec.nS == 51 ** 6 and spec.nU == 1331 and spec.idx_np_dtype == np.uint16
+    rng = np.random.default_rng(5102)
+    vecs = [(rng.random(n) * (1.0 + a)).astype(np.float32) for a, n in enumerate(spec.n)]
+    sel = _sample_6d(spec, rng, 300)
+    sel = np.unique(np.concatenate([sel, [2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32, 2 ** 33 + 255, 2 ** 33 + 256, 2 ** 34 - 1]]))
+    dA, dB = hjbdp.DeviceBuffer(spec.nS * 4), hjbdp.DeviceBuffer(spec.nS * 4)
+    dI = hjbdp.DeviceBuffer(spec.nS * 2)
+    try:
+        with hjbdp.Backup(spec) as bk:
+            assert bk.info()["kernel_variant"] == 4 and bk.get_option("packed2_mode") == 6
+            bk.fill_separable(vecs, dA)
+            bk.backup_stage_device(dA, dB, dI)                  # stage 1: separable -> dB
+            bk.check_device_status()
+            J1r, i1r = c_oracle.backup_states(_abi, spec, vecs, sel)
+            assert np.array_equal(dB.gather(np.float32, sel), J1r) and np.array_equal(dI.gather(np.uint16, sel), i1r)
+            bk.backup_stage_device(dB, dA, dI)                  # stage 2: the GPU's own stage 1 -> dA (over the separable fill)
+            bk.check_device_status()
+        keys = c_oracle.backup_states_touch(_abi, spec, sel)
+        assert keys.size > 64 * sel.size // 8 and keys.max() < spec.nS
+        vals = dB.gather(np.float32, keys)
+        J2r, i2r = c_oracle.backup_states_sparse(_abi, spec, keys, vals, sel)
+        J2g, i2g = dA.gather(np.float32, sel), dI.gather(np.uint16, sel)
+        bad = np.flatnonzero(J2g != J2r)
+        assert bad.size == 0, ("J", sel[bad[:5]], J2g[bad[:5]], J2r[bad[:5]])
+        bad = np.flatnonzero(i2g != i2r)
+        assert bad.size == 0, ("labels", sel[bad[:5]], i2g[bad[:5]], i2r[bad[:5]])
+        assert not np.array_equal(J2g, J1r)                    # a second stage happened
+    finally:
+        dA.free(); dB.free(); dI.free()

@@ -478,6 +478,16 @@ def test_rank_create_from_builder_equals_struct_form(env):
         assert lib.hjb_rank_destroy(r) == _abi.HJB_OK
 
 
+def _rccl_unique_id(lib, _abi):
+    """The 128-byte id of a new communicator, or skip: a host without librccl gets HJB_E_UNSUPPORTED (include/hjbdp.h)."""
+    uid = (C.c_char * 128)()
+    st = lib.hjb_rank_comm_unique_id(uid)
+    if st == _abi.HJB_E_UNSUPPORTED:
+        pytest.skip("RCCL is not available here: %s" % (lib.hjb_rank_last_error(None) or b"").decode())
+    assert st == _abi.HJB_OK, lib.hjb_rank_last_error(None)
+    return uid
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_rccl_transport_inside_the_library_loopback(env, overlap):
     """hjb_rank_comm_init / hjb_rank_exchange / hjb_rank_step / hjb_rank_monitor_sums: the RCCL calls of a middle rank
@@ -497,8 +507,7 @@ def test_rccl_transport_inside_the_library_loopback(env, overlap):
     owned, hlo, hhi = rk.end - rk.begin, rk.halo_lo, rk.halo_hi
     planes = owned + hlo + hhi
     rk.set_option("comm_loopback", 1)
-    uid = (C.c_char * 128)()
-    assert lib.hjb_rank_comm_unique_id(uid) == _abi.HJB_OK, lib.hjb_rank_last_error(None)
+    uid = _rccl_unique_id(lib, _abi)
     assert lib.hjb_rank_comm_init(rk._r, uid) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
     assert lib.hjb_rank_transfer_stream(rk._r)
     rng = np.random.default_rng(5)
@@ -540,11 +549,19 @@ def test_rank_sweep_whole_loop_in_the_library(env):
     term = random_terminal(spec, 4)
     rk = hjbdp.core.RankSlab(spec, 0, 0, 1)
     lib = rk.lib
-    uid = (C.c_char * 128)()
-    assert lib.hjb_rank_comm_unique_id(uid) == _abi.HJB_OK, lib.hjb_rank_last_error(None)
+    uid = _rccl_unique_id(lib, _abi)
     assert lib.hjb_rank_comm_init(rk._r, uid) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
-    for tol in (0.0, 1e30):                                   # never stops / stops at the first monitor point
-        ref = c_oracle.sweep(_abi, spec, 9, terminal=term, monitor_period=3, monitor_tol=tol)
+    assert lib.hjb_rank_comm_init(rk._r, uid) == _abi.HJB_E_INVALID          # one communicator per rank
+    # the reference's typing of the monitor (Solver_pos_att.m:274-282: single sum, single difference, single comparison) at
+    # the margin: a tolerance one float32 ulp above the second monitor point's |e| stops there, |e| itself does not ('<')
+    events = []
+    with hjbdp.Backup(spec) as bk:
+        bk.solve(9, terminal=term, monitor_period=3, monitor_tol=0.0, monitor_single=True, progress=lambda k, e, e2, sec: events.append(e))
+    e2nd = np.float32(abs(events[1]))
+    cases = [(0.0, False), (1e30, False), (float(np.nextafter(e2nd, np.float32(np.inf))), True), (float(e2nd), True)]
+    for tol, single in cases:                                 # never stops / stops at the first monitor point / the margin
+        rk.set_option("monitor_single", 1 if single else 0)
+        ref = c_oracle.sweep(_abi, spec, 9, terminal=term, monitor_period=3, monitor_tol=tol, monitor_single=single)
         with hjbdp.DeviceBuffer(spec.nS * 4) as d0, hjbdp.DeviceBuffer(spec.nS * 4) as d1, hjbdp.DeviceBuffer(spec.nS * rk.idx_bytes) as dI:
             d0.upload(term)
             done, early, in0, ms = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
@@ -567,6 +584,7 @@ def test_cpp_rank_driver_matches_the_python_path(env):
     import subprocess
     hjbdp, _abi, c_oracle = env
     import bench
+    _rccl_unique_id(hjbdp.load_library(), _abi)                # skips on a host without librccl
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run(["bash", str(root / "tools" / "build_bench_ranks.sh")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]

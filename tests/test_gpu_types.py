@@ -243,16 +243,47 @@ def test_tab64_table_build_failure_is_loud(env, monkeypatch):
     and a message that names the remedy.  (it used to fall back to the generic kernel silently.)"""
     hjbdp, _abi, c_oracle = env
     spec = _pos_att_spec(hjbdp, (30, 12, 10, 9), np.float64, idx_dtype="auto")
-    monkeypatch.setenv("HJBDP_TEST_FAIL_TAB64_SCRATCH", "1")
-    with pytest.raises(hjbdp.HjbError) as ei:
-        hjbdp.Backup(spec)
-    assert ei.value.status == _abi.HJB_E_NOMEM and "scratch" in str(ei.value)
-    # float32 queries are not affected by the hook, and without it the float64 build works
-    with hjbdp.Backup(_pos_att_spec(hjbdp, (30, 12, 10, 9), None, idx_dtype="auto")) as bk:
-        assert bk.info()["table_dtype"] == _abi.HJB_TAB_DEFAULT
+    lib = hjbdp.load_library()
+    monkeypatch.setenv("HJBDP_TEST_FAIL_TAB64_SCRATCH", "1")       # the environment does nothing (ADVICE round 4)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["table_dtype"] == _abi.HJB_TAB_F64
     monkeypatch.delenv("HJBDP_TEST_FAIL_TAB64_SCRATCH")
+    assert lib.hjb_test_hook(b"no_such_key", 1) == _abi.HJB_E_INVALID
+    assert lib.hjb_test_hook(b"fail_tab64_scratch", 1) == _abi.HJB_OK
+    try:
+        with pytest.raises(hjbdp.HjbError) as ei:
+            hjbdp.Backup(spec)
+        assert ei.value.status == _abi.HJB_E_NOMEM and "scratch" in str(ei.value)
+        # float32 queries are not affected by the hook, and without it the float64 build works
+        with hjbdp.Backup(_pos_att_spec(hjbdp, (30, 12, 10, 9), None, idx_dtype="auto")) as bk:
+            assert bk.info()["table_dtype"] == _abi.HJB_TAB_DEFAULT
+    finally:
+        assert lib.hjb_test_hook(b"fail_tab64_scratch", 0) == _abi.HJB_OK
     with hjbdp.Backup(spec) as bk:
         assert bk.info()["table_dtype"] == _abi.HJB_TAB_F64 and bk.info()["kernel_variant"] >= 5
+
+
+def test_cost64_table_build_failure_is_loud(env):
+    """a HJB_COST_F64 handle whose tables cannot be built is not handed out on variant 0 (which would fail
+    every later launch with a message about kernels 5 and 7): hjb_create fails with the build's status."""
+    hjbdp, _abi, c_oracle = env
+    from problems import colsweep_problem
+    s0 = colsweep_problem(77, (70, 9, 8, 11), nU=9, gax=3, cost="fast", dtype=np.float64)
+    spec = hjbdp.ProblemSpec(s0.knots, s0.m, s0.next_terms, s0.cost_terms, dtype=np.float32, index_base=1, idx_dtype="auto",
+                             cost_dtype=np.float64)
+    s32 = hjbdp.ProblemSpec(s0.knots, s0.m, s0.next_terms, s0.cost_terms, dtype=np.float32, index_base=1, idx_dtype="auto")
+    lib = hjbdp.load_library()
+    assert lib.hjb_test_hook(b"fail_tabled_alloc", 1) == _abi.HJB_OK
+    try:
+        with pytest.raises(hjbdp.HjbError) as ei:
+            hjbdp.Backup(spec)
+        assert ei.value.status == _abi.HJB_E_NOMEM and "table" in str(ei.value)
+        with hjbdp.Backup(s32, variant=0) as bk:            # a float32-cost problem still gets the general kernel
+            assert bk.info()["kernel_variant"] == 0
+    finally:
+        assert lib.hjb_test_hook(b"fail_tabled_alloc", 0) == _abi.HJB_OK
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["cost_dtype"] == _abi.HJB_COST_F64 and bk.info()["kernel_variant"] in (5, 7)
 
 
 @pytest.mark.parametrize("j_storage", [None, np.float16])

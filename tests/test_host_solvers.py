@@ -173,6 +173,17 @@ def test_quaternion_model_restatement(orc):
     sel = rng.choice(mspec.nS, 300, replace=False)
     Js, Is = c_oracle.backup_states(_abi, mspec, vecs, sel)
     assert np.array_equal(Js, Jf[sel]) and np.array_equal(Is, If[sel])
+    # the deep-sweep checkers: listed states from a host-resident J_next, and from a SAMPLE of a J_next (touch -> gather -> sparse)
+    Jr = (rng.random(mspec.nS) * 3).astype(np.float32)
+    Jf, If = c_oracle.backup_stage(_abi, mspec, Jr)
+    Js, Is = c_oracle.backup_states_from_J(_abi, mspec, Jr, sel)
+    assert np.array_equal(Js, Jf[sel]) and np.array_equal(Is, If[sel])
+    keys = c_oracle.backup_states_touch(_abi, mspec, sel[:40])
+    assert keys.size < mspec.nS and keys.min() >= 0 and keys.max() < mspec.nS
+    Js, Is = c_oracle.backup_states_sparse(_abi, mspec, keys, Jr[keys], sel[:40])
+    assert np.array_equal(Js, Jf[sel[:40]]) and np.array_equal(Is, If[sel[:40]])
+    with pytest.raises(RuntimeError):                       # a missing sample is an error, never a silent zero
+        c_oracle.backup_states_sparse(_abi, mspec, keys[1:], Jr[keys[1:]], sel[:40])
     with pytest.raises(ValueError):
         hjbdp.permute_state_axes(mspec, (1, 0, 2, 3, 4, 5))
 
