@@ -1,4 +1,4 @@
-// hjbdp_launch.h - the seam between the host side of libhjbdp (hjbdp.hip) and the stage-kernel families, each
+// hjbdp_launch.h - the seam between the host side of libhjbdp (hjbdp_setup.hip: launch_stage) and the stage-kernel families, each
 // compiled in a translation unit of its own (stage_*.hip) so that a cold build runs them in parallel
 // (__graft_entry__.build()).  Plain arguments only: a family knows nothing of the handle.
 #pragma once

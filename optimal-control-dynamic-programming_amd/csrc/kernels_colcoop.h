@@ -18,7 +18,7 @@
 //     address + immediate offsets): no DPP, no constraint on the axis-0 cells, 64 states per wave.
 //
 // Arithmetic, plans and member slots are those of the column sweep (cs_group): bit-identical results.
-// Eligibility is decided on the host (hjbdp.hip::colcoop_plan): axis 1's cell must not depend on the window-axis index,
+// Eligibility is decided on the host (hjbdp_setup.hip::colcoop_plan): axis 1's cell must not depend on the window-axis index,
 // every workgroup's columns must fit the staged ranges, n0 must be a multiple of the staging load width.
 #pragma once
 #include "kernels_colsweep.h"

@@ -1,6 +1,6 @@
 // kernels_colsweep.h - variant 7: the column-sweep stage kernel for the pos-att shape (C4 / C5).
 //
-// Shape (checked on the host, hjbdp.hip::ensure_colsweep): D = 4, one control dim, and
+// Shape (checked on the host, hjbdp_setup.hip::ensure_colsweep): D = 4, one control dim, and
 //   * axes 0 and 1 do not depend on the control (pos-att with the axes relabelled (x, theta, v, w):
 //     x+ = x + h v over (x, v), theta+ = theta + h w over (theta, w) - Solver_pos_att.m:299-328);
 //     axis 0's cell does not depend on state dim 1, axis 1's cell does not depend on state dim 0;

@@ -82,11 +82,20 @@ class Solver_attitude:
         cost = [Term((0,), Qw * s_w ** 2), Term((1,), Qt * s_t ** 2), Term((2,), R * U ** 2)]   # :220
         return ProblemSpec([s_w, s_t], [len(U)], nxt, cost, dtype=np.float64, index_base=1), s_w, s_t
 
-    def simplified_run(self, n_stages=None):
+    def simplified_run(self, n_stages=None, keep_policy=False):
+        """keep_policy=True also leaves the policy of EVERY stage, as the reference's development script stores it
+        (attitude-control/test/test_simplified.m:102-104: `U1_Opt(:,:,k_s) = U_vector(U1_idx)`): self.U_Opt_stages[ch] is
+        the [n_w, n_t, n_stages] array of torque values with stage k_s in plane k_s - 1 (and self.U_idx_stages[ch] the
+        1-based labels), written by the stage kernel itself (hjb_solve_opts.idx_stages)."""
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
         self.F_values, self.U_idx, self.sweep_ms = [None] * 3, [None] * 3, [None] * 3
+        self.U_Opt_stages = self.U_idx_stages = None
         built = [self.build_spec_simplified(ch) for ch in range(3)]
-        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device)   # channels side by side
+        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device,   # channels side by side
+                                           keep_idx=bool(keep_policy))
+        if keep_policy:
+            self.U_idx_stages = [outs[ch]["idx_stages"].reshape(len(built[ch][1]), len(built[ch][2]), n_st, order="F") for ch in range(3)]
+            self.U_Opt_stages = [self.U_vector[ix - 1] for ix in self.U_idx_stages]
         for ch in range(3):
             spec, s_w, s_t = built[ch]
             out = outs[ch]

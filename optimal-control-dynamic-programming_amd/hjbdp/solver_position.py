@@ -89,12 +89,19 @@ class Solver_position:
         cost = [Term((0,), Qx * s_x ** 2), Term((1,), Qv * s_v ** 2), Term((2,), R * U ** 2)]  # :113
         return ProblemSpec([s_x, s_v], [len(U)], nxt, cost, dtype=np.float64, index_base=1), s_x, s_v
 
-    def simplified_run(self, n_stages=None):
-        """n_stages overrides N_stage-1 (tests)."""
+    def simplified_run(self, n_stages=None, keep_policy=False):
+        """n_stages overrides N_stage-1 (tests).  keep_policy=True also leaves every stage's policy - the per-stage store of
+        the reference's development scripts (attitude-control/test/test_simplified.m:102-104, `U1_Opt(:,:,k_s) =
+        U_vector(U1_idx)`; test/Dynamic_Solver.m:100 keeps u_star_idxs the same way): self.U_Opt_stages[ch] is
+        [n_x, n_v, n_stages] with stage k_s in plane k_s - 1, self.U_idx_stages[ch] the 1-based labels."""
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
         built = [self.build_spec(ch) for ch in range(3)]
         # the three channels are independent sweeps (:132-141 runs them in one loop body): in flight together
-        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device)
+        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device, keep_idx=bool(keep_policy))
+        self.U_Opt_stages = self.U_idx_stages = None
+        if keep_policy:
+            self.U_idx_stages = [outs[ch]["idx_stages"].reshape(len(built[ch][1]), len(built[ch][2]), n_st, order="F") for ch in range(3)]
+            self.U_Opt_stages = [np.asarray(self.U_vector, dtype=np.float64)[ix - 1] for ix in self.U_idx_stages]
         for ch in range(3):
             spec, s_x, s_v = built[ch]
             out = outs[ch]

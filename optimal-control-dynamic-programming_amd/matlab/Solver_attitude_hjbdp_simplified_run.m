@@ -1,4 +1,4 @@
-function obj = Solver_attitude_hjbdp_simplified_run(obj, varargin)
+function [obj, U_Opt_stages] = Solver_attitude_hjbdp_simplified_run(obj, varargin)
 %SOLVER_ATTITUDE_HJBDP_SIMPLIFIED_RUN  Drop-in body for Solver_attitude.simplified_run
 %   (attitude-control/Solver_attitude.m:196-259):
 %       sa = Solver_attitude;  Solver_attitude_hjbdp_simplified_run(sa);
@@ -7,13 +7,19 @@ function obj = Solver_attitude_hjbdp_simplified_run(obj, varargin)
 %   operands - w_next = W + dw(U) (RK4_w, every k = U/J), t_next = T + dt(W) (RK4_t, k's functions of W only),
 %   J_current = Qw w^2 + Qt theta^2 + R u^2 (:220) - and the stage loop (:236-247) runs in libhjbdp, in double.
 %   Optional name/value pairs are passed on to hjbdp_solve; 'n_stages' overrides N_stage - 1.
+%   [obj, U_Opt_stages] = ...(obj, 'keep_policy', true) also returns the policy of EVERY stage as the reference's
+%   development script keeps it (attitude-control/test/test_simplified.m:102-104, U1_Opt(:,:,k_s) = U_vector(U1_idx)):
+%   U_Opt_stages{ch} is [n_w, n_t, n_stages] with stage k_s in page k_s (hjbdp_solve 'keep_stages': the stage kernel
+%   writes every stage's labels straight into that array on the device).
 % NOT executed in the build image (no MATLAB); tested twin: hjbdp/solver_attitude.py::simplified_run (bit-exact
 % against the oracle at the reference's 1000 x 300 x 3 size, tests/test_gpu_deep.py); call sequence replayed through
 % ctypes by tests/test_gpu_flat_api.py::test_matlab_shim_sequences_attitude_simplified.
-    n_stages = obj.N_stage - 1;  rest = varargin;
-    for i = 1:2:numel(varargin)
-        if strcmp(varargin{i}, 'n_stages'), n_stages = varargin{i + 1};  rest([i, i + 1]) = [];  break; end
+    n_stages = obj.N_stage - 1;  rest = varargin;  keep_policy = false;  U_Opt_stages = cell(1, 3);
+    for i = numel(varargin) - 1:-2:1
+        if strcmp(varargin{i}, 'n_stages'), n_stages = varargin{i + 1};  rest([i, i + 1]) = [];  end
+        if strcmp(varargin{i}, 'keep_policy'), keep_policy = varargin{i + 1};  rest([i, i + 1]) = [];  end
     end
+    if keep_policy, rest = [rest, {'keep_stages', true}]; end
     %% mesh generation (:199-205)
     s_w = linspace(obj.w_min, obj.w_max, obj.n_mesh_w);
     s_t = {linspace(deg2rad(obj.yaw_min), deg2rad(obj.yaw_max), obj.n_mesh_t), ...
@@ -35,6 +41,7 @@ function obj = Solver_attitude_hjbdp_simplified_run(obj, varargin)
         prob.cost_terms = [T(1, Qw(ch) * s_w.^2), T(2, Qt(ch) * t.^2), T(3, R(ch) * U.^2)];
         out = hjbdp_solve(prob, n_stages, rest{:});               % :236-247
         pol = griddedInterpolant({s_w, t}, U(out.idx), 'nearest');    % :249-251
+        if keep_policy, U_Opt_stages{ch} = reshape(U(out.idx_stages), [numel(s_w), numel(t), n_stages]); end   % test_simplified.m:102-104
         switch ch
             case 1, obj.U1_Opt = pol;
             case 2, obj.U2_Opt = pol;

@@ -1,4 +1,4 @@
-function obj = Solver_position_hjbdp_simplified_run(obj, varargin)
+function [obj, U_Opt_stages] = Solver_position_hjbdp_simplified_run(obj, varargin)
 %SOLVER_POSITION_HJBDP_SIMPLIFIED_RUN  Drop-in body for Solver_position.simplified_run
 %   (position-control/Solver_position.m:94-150):
 %       sp = Solver_position;  Solver_position_hjbdp_simplified_run(sp);  get_optimal_path(sp)
@@ -9,10 +9,15 @@ function obj = Solver_position_hjbdp_simplified_run(obj, varargin)
 %   v_next = V + dv(U), J_current = Qx x^2 + Qv v^2 + R u^2, each evaluated left to right as MATLAB does - and the
 %   `for k_s = N_stage-1:-1:1` loop (:132-141) runs in libhjbdp (all double, as in the reference).
 %   Optional name/value pairs are passed on to hjbdp_solve ('devices', ...).  'n_stages' overrides N_stage - 1.
+%   [obj, U_Opt_stages] = ...(obj, 'keep_policy', true) also returns every stage's policy the way the reference's
+%   development scripts keep it (attitude-control/test/test_simplified.m:102-104, U1_Opt(:,:,k_s) = U_vector(U1_idx)):
+%   U_Opt_stages{ch} is [n_x, n_v, n_stages], stage k_s in page k_s (hjbdp_solve 'keep_stages').
 % NOT executed in the build image (no MATLAB); tested twin: hjbdp/solver_position.py (bit-exact against the oracle on
 % the reference's 201 x 201 x 3 grid, tests/test_gpu_solvers.py), and this file's call sequence is replayed through
 % ctypes by tests/test_gpu_flat_api.py::test_matlab_shim_sequences_solver_position.
-    [n_stages, rest] = take_n_stages(obj.N_stage - 1, varargin);
+    [n_stages, rest, keep_policy] = take_n_stages(obj.N_stage - 1, varargin);
+    U_Opt_stages = cell(1, 3);
+    if keep_policy, rest = [rest, {'keep_stages', true}]; end
     %% mesh generation (:97-104)
     s_x = {sym_linspace(obj, obj.x_min, obj.x_max, obj.n_mesh_x), ...
            sym_linspace(obj, obj.x_min, obj.x_max, obj.n_mesh_x), ...
@@ -40,6 +45,7 @@ function obj = Solver_position_hjbdp_simplified_run(obj, varargin)
         out = hjbdp_solve(prob, n_stages, rest{:});                % for k_s = N_stage-1:-1:1 (:132-141)
         U_idx = out.idx;                                           % [n_x, n_v], 1-based, first minimum
         pol = griddedInterpolant({x, v}, U(U_idx), 'nearest');     % :144-146
+        if keep_policy, U_Opt_stages{ch} = reshape(U(out.idx_stages), [numel(x), numel(v), n_stages]); end
         switch ch
             case 1, obj.U1_Opt = pol;
             case 2, obj.U2_Opt = pol;
@@ -49,9 +55,10 @@ function obj = Solver_position_hjbdp_simplified_run(obj, varargin)
     fprintf('stage calculation complete!\n')
 end
 
-function [n, rest] = take_n_stages(default, args)
-    n = default;  rest = args;
-    for i = 1:2:numel(args)
-        if strcmp(args{i}, 'n_stages'), n = args{i + 1};  rest([i, i + 1]) = [];  return; end
+function [n, rest, keep_policy] = take_n_stages(default, args)
+    n = default;  rest = args;  keep_policy = false;
+    for i = numel(args) - 1:-2:1
+        if strcmp(args{i}, 'n_stages'), n = args{i + 1};  rest([i, i + 1]) = [];  end
+        if strcmp(args{i}, 'keep_policy'), keep_policy = args{i + 1};  rest([i, i + 1]) = [];  end
     end
 end

@@ -351,7 +351,10 @@ def test_matlab_shim_sequences_solver_position(env):
     mt = _twin()
     lib = hjbdp.load_library()
     sp = hjbdp.Solver_position()
-    sp.simplified_run(n_stages=40)
+    sp.simplified_run(n_stages=40, keep_policy=True)
+    assert sp.U_Opt_stages[0].shape == (201, 201, 40) and np.array_equal(sp.U_idx_stages[1][:, :, 0], sp.U_idx[1])
+    orc = c_oracle.sweep(_abi, sp.build_spec(2)[0], 40, keep_idx=True)
+    assert np.array_equal(sp.U_idx_stages[2].reshape(-1, 40, order="F"), orc["idx_stages"])
     ref = hjbdp.Solver_position()
     for ch in range(3):
         prob = mt.position_channel_prob(ref, ch)
@@ -384,10 +387,20 @@ def test_matlab_shim_sequences_attitude_simplified(env):
     mt = _twin()
     lib = hjbdp.load_library()
     sa = hjbdp.Solver_attitude(n_mesh_t=60, n_mesh_w_simplified=140)
-    sa.simplified_run(n_stages=30)
+    sa.simplified_run(n_stages=30, keep_policy=True)
+    plain = hjbdp.Solver_attitude(n_mesh_t=60, n_mesh_w_simplified=140).simplified_run(n_stages=30)
+    assert plain.U_Opt_stages is None
     for ch in range(3):
-        out = mt.hjbdp_solve(lib, mt.attitude_simplified_prob(sa, ch), 30)
+        out = mt.hjbdp_solve(lib, mt.attitude_simplified_prob(sa, ch), 30, keep_stages=True)     # the shim's 'keep_policy'
         assert np.array_equal(out["J"], sa.F_values[ch]) and np.array_equal(out["idx"], sa.U_idx[ch])
+        assert np.array_equal(plain.F_values[ch], sa.F_values[ch]) and np.array_equal(plain.U_idx[ch], sa.U_idx[ch])
+        # every stage's policy (attitude-control/test/test_simplified.m:102-104): U_vector(U_idx) per stage, page k_s - 1
+        pol = sa.U_vector[out["idx_stages"].astype(int) - 1].reshape(140, 60, 30, order="F")
+        assert sa.U_Opt_stages[ch].shape == (140, 60, 30) and np.array_equal(pol, sa.U_Opt_stages[ch])
+        assert np.array_equal(sa.U_idx_stages[ch][:, :, 0], sa.U_idx[ch])                      # the last stage computed is k_s = 1
+        spec = sa.build_spec_simplified(ch)[0]
+        ref = c_oracle.sweep(_abi, spec, 30, keep_idx=True)
+        assert np.array_equal(sa.U_idx_stages[ch].reshape(-1, 30, order="F"), ref["idx_stages"])
 
 
 @pytest.mark.order(8)
