@@ -175,6 +175,11 @@ __device__ __forceinline__ void tie6(uint32_t (&r)[2][kCsNW]) {
     static_assert(kCsNW == 3, "six registers per group and neighbour");
     asm volatile("" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]));
 }
+typedef float cs_pair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tie3(cs_pair (&r)[kCsNW]) {       // the same for three row pairs (the copy-free roll)
+    static_assert(kCsNW == 3, "three window knots per group");
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
+}
 template <typename T, typename TJ> __device__ __forceinline__ T raw_to(uint32_t r) {
     if (sizeof(TJ) == 4) return __uint_as_float(r);
     return (T)__builtin_bit_cast(_Float16, (unsigned short)r);
@@ -268,16 +273,27 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
 
 // Five waves per SIMD (<= 96 VGPRs) for the one-load form with up to five groups - the C4 / C5 kernel, which the
 // register allocator otherwise leaves at 98; the wider forms take what they need.
-// HJB_CS_UNROLL2 (experiment, round 4; off): the step loop unrolled by two with the corner-row registers A swapping roles (the row
-// at knot c1 + 1 of one step is the row at knot c1 of the next: no copy of each new row into the old one's register - 15
-// v_mov_b64 per step) at four waves per SIMD.  profiles/r04_c4_experiments.log has the timing.
-#ifndef HJB_CS_UNROLL2
-#define HJB_CS_UNROLL2 0
+//
+// THE COPY-FREE ROLL (round 5; one-load form with float32 J storage, HJB_CS_ROLL2 = 0 builds the round-4 loop).  The A row at
+// knot c1 + 1 of one step is the A row at knot c1 of the next.  Written as `A[g][w] = an` after the axis-1 lerp, each of the 13
+// row pairs of a step cost a v_mov_b64 (7 % of the step's vector instructions): `an` cannot be formed in A's register, which the
+// lerp still reads.  Round 4's loop unrolled by two with two sets of A registers removed the copies and needed 128 VGPRs; left
+// to itself the allocator spreads the rows of a loop with two textual steps over twice the registers (and spills 173 at 80).
+// This form needs NO register beyond the round-4 loop's and leaves the allocator no choice: per (group, window knot) a step
+// holds two register pairs anyway - the pair the gather delivers and the previous step's A pair - and they SWAP ROLES every
+// step.  Step p: the gathered pair V[p] becomes the new A row in place (`an = fma(t0, next lane - own, own)` overwrites its
+// own operand), the old row V[1 - p] is read by the axis-1 lerp for the last time, and the NEXT step's gather is issued into
+// V[1 - p] - a "+v" operand of the gather's asm statement, so it lands in exactly the registers the old row occupied.  Two
+// textual copies of the step (kernels_colsweep_step.inc) with p = 0 / 1 make the names compile-time.  Rows only some columns
+// use keep their two pairs throughout, as before.  tests/test_kernel_budget.py holds the result to 80 VGPRs and to "no gather
+// destination is touched in flight".
+#ifndef HJB_CS_ROLL2
+#define HJB_CS_ROLL2 1
 #endif
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP, bool C64 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
-    HJB_CS_UNROLL2 ? 4 : ((DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 1),
-    HJB_CS_UNROLL2 ? 4 : ((DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 4))))
+    (DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 1,
+    (DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 4)))
 k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
                   const TJ *__restrict__ Jn, TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(sizeof(T) == 4, "float32 arithmetic");
@@ -431,7 +447,8 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     // rotation.  Results go to LDS and are written out every kCsFlush steps: on gfx9 loads and stores share one counter
     // and complete out of order with each other, so a pending store makes every wait for a load a full drain.
     constexpr int NGH = (NG + 1) / 2;
-    constexpr int NA = HJB_CS_UNROLL2 ? 2 : 1;               // sets of corner-row registers (two: they swap roles every step)
+    constexpr bool ROLL2 = DPP && sizeof(TJ) == 4 && HJB_CS_ROLL2 != 0;      // the copy-free roll (above): two textual steps per loop trip
+    constexpr int NA = ROLL2 ? 2 : 1;                        // ROLL2: two sets of row pairs, each in turn gather destination / new A rows and old A rows
     f2 A[NA][NG][NW];
 #pragma unroll
     for (int q = 0; q < NA; ++q)
@@ -458,7 +475,9 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     // which only the assembler rejects: tests/test_kernel_budget.py assembles the code object for that reason)
     nH0 = __builtin_amdgcn_readfirstlane(nH0);
     nH1 = __builtin_amdgcn_readfirstlane(nH1);
-    auto load_groups = [&](int g0, int g1, uint32_t vrow) __attribute__((always_inline)) {
+    // QQ (ROLL2): the set of row pairs that receives the rows - the one whose A rows have just been read for the last time
+    auto load_groups = [&](int g0, int g1, uint32_t vrow, auto QQ) __attribute__((always_inline)) {
+        constexpr int q = decltype(QQ)::value;
         uint32_t vb[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) vb[w] = voff0 + (vrow + (uint32_t)w * w_bytes);
@@ -472,6 +491,13 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                     if (w == 0 && !(ug & 1)) continue;                          // a pair is in use iff its first slot is
                     if (w == 2 && !(ug & (1 << (MM / 2)))) continue;
                     const uint32_t o = vb[w] + rog[g];
+                    if constexpr (ROLL2) {                   // into the registers of the old A row, by name: "+v"
+                        uint32_t r0 = __float_as_uint(A[q][g][w].x), r1 = __float_as_uint(A[q][g][w].y);
+                        asm volatile("global_load_dword %0, %1, %2" : "+v"(r0) : "v"(o), "s"(Jb00));
+                        asm volatile("global_load_dword %0, %1, %2" : "+v"(r1) : "v"(o), "s"(Jb10));
+                        A[q][g][w] = f2{__uint_as_float(r0), __uint_as_float(r1)};
+                        continue;
+                    }
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         rlo[g][k][w] = gather_async<sizeof(TJ)>(o, k ? Jb10 : Jb00);
@@ -482,12 +508,16 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         }
     };
     // wait until at most `younger` gathers (a multiple of LPK) are outstanding, then release groups [g0, g1) to the arithmetic
-    auto await_groups = [&](int g0, int g1, int younger) __attribute__((always_inline)) {
+    auto await_groups = [&](int g0, int g1, int younger, auto QQ) __attribute__((always_inline)) {
         wait_gathers_n<LPK>(younger);
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
-            tie6(rlo[g]);
-            if (!DPP) tie6(rhi[g]);
+            if constexpr (ROLL2) {
+                tie3(A[decltype(QQ)::value][g]);
+            } else {
+                tie6(rlo[g]);
+                if (!DPP) tie6(rhi[g]);
+            }
         }
     };
     static_assert(NG - (NG + 1) / 2 <= 3 && (NG + 1) / 2 <= 3, "await_groups counts up to nine younger window knots");
@@ -500,13 +530,15 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     // The arithmetic (cs_group) is written on PAIRS (lower, upper group row) of one window knot: v_pk_add_f32 /
     // v_pk_fma_f32 are IEEE per component, and with the pair as the unit of data no value has to be moved between registers.
     auto compute_groups = [&](int g0, int g1, auto PP) __attribute__((always_inline)) {
-        constexpr int po = decltype(PP)::value, pn = HJB_CS_UNROLL2 ? 1 - po : po;      // old / new set of this step
+        constexpr int pn = decltype(PP)::value, po = NA - 1 - pn;      // ROLL2: set pn holds the gathered rows and takes the new A rows, set po the old ones
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
             if (g < ngs) {
                 const f2 t0p = {t0, t0};
                 auto row0 = [&](int w) {
-                    const f2 l = {raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
+                    f2 l;
+                    if constexpr (ROLL2) l = A[pn][g][w];
+                    else l = f2{raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
                     const f2 d = DPP ? f2{lane_up_minus(l.x), lane_up_minus(l.y)}      // (next lane) - (own): one DPP subtraction each
                                      : f2{raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])} - l;
                     return __builtin_elementwise_fma(t0p, d, l);
@@ -533,27 +565,27 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     // header would make its first use INSIDE the loop a `vmcnt(0)` on every step - a drain of the gathers in flight.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" : "+v"(gcol), "+v"(t0), "+v"(voff0));
-    load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes);              // prologue: H0 of step 0
+    load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes, std::integral_constant<int, 0>{});      // prologue: H0 of step 0
     int slot = 0;                                            // LDS slot of this step's result (= i1 % kCsFlush)
-    if constexpr (HJB_CS_UNROLL2 != 0) {
+    if constexpr (ROLL2) {
         for (int i1 = i1b; i1 < i1e; ++i1) {
             {
-#define CS_PO 0
+#define CS_PN 0
 #include "kernels_colsweep_step.inc"
-#undef CS_PO
+#undef CS_PN
             }
             if (++i1 >= i1e) break;
             {
-#define CS_PO (NA - 1)
+#define CS_PN (NA - 1)
 #include "kernels_colsweep_step.inc"
-#undef CS_PO
+#undef CS_PN
             }
         }
     } else {
         for (int i1 = i1b; i1 < i1e; ++i1) {
-#define CS_PO 0
+#define CS_PN 0
 #include "kernels_colsweep_step.inc"
-#undef CS_PO
+#undef CS_PN
         }
     }
 }

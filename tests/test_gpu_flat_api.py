@@ -353,7 +353,7 @@ def test_matlab_shim_sequences_solver_position(env):
     sp = hjbdp.Solver_position()
     sp.simplified_run(n_stages=40, keep_policy=True)
     assert sp.U_Opt_stages[0].shape == (201, 201, 40) and np.array_equal(sp.U_idx_stages[1][:, :, 0], sp.U_idx[1])
-    orc = c_oracle.sweep(_abi, sp.build_spec(2)[0], 40, keep_idx=True)
+    orc = c_oracle.sweep(_abi, hjbdp.Solver_position().build_spec(2)[0], 40, keep_idx=True)     # a fresh object: the run updates n_mesh_x / n_mesh_v (:100,:104)
     assert np.array_equal(sp.U_idx_stages[2].reshape(-1, 40, order="F"), orc["idx_stages"])
     ref = hjbdp.Solver_position()
     for ch in range(3):
