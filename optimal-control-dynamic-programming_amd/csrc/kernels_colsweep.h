@@ -288,7 +288,7 @@ __device__ __forceinline__ void cs_group(int ug, int g, FA row0, const cs_f2 (&A
 // use keep their two pairs throughout, as before.  tests/test_kernel_budget.py holds the result to 80 VGPRs and to "no gather
 // destination is touched in flight".
 #ifndef HJB_CS_ROLL2
-#define HJB_CS_ROLL2 1
+#define HJB_CS_ROLL2 0
 #endif
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP, bool C64 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
@@ -447,7 +447,8 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     // rotation.  Results go to LDS and are written out every kCsFlush steps: on gfx9 loads and stores share one counter
     // and complete out of order with each other, so a pending store makes every wait for a load a full drain.
     constexpr int NGH = (NG + 1) / 2;
-    constexpr bool ROLL2 = DPP && sizeof(TJ) == 4 && HJB_CS_ROLL2 != 0;      // the copy-free roll (above): two textual steps per loop trip
+    constexpr bool TWO = DPP && sizeof(TJ) == 4 && HJB_CS_ROLL2 != 0;         // two textual steps per loop trip
+    constexpr bool ROLL2 = TWO && HJB_CS_ROLL2 != 2;                          // the copy-free roll (above); HJB_CS_ROLL2 = 2: two steps, round-4 registers (debugging)
     constexpr int NA = ROLL2 ? 2 : 1;                        // ROLL2: two sets of row pairs, each in turn gather destination / new A rows and old A rows
     f2 A[NA][NG][NW];
 #pragma unroll
@@ -492,9 +493,15 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
                     if (w == 2 && !(ug & (1 << (MM / 2)))) continue;
                     const uint32_t o = vb[w] + rog[g];
                     if constexpr (ROLL2) {                   // into the registers of the old A row, by name: "+v"
-                        uint32_t r0 = __float_as_uint(A[q][g][w].x), r1 = __float_as_uint(A[q][g][w].y);
+                        uint32_t r0, r1;
+#if HJB_CS_ROLL2 == 3
+                        r0 = __float_as_uint(A[q][g][w].x), r1 = __float_as_uint(A[q][g][w].y);      // the destinations TIED to the old row's registers: faults on the GPU (round 5, not understood); kept for the record
                         asm volatile("global_load_dword %0, %1, %2" : "+v"(r0) : "v"(o), "s"(Jb00));
                         asm volatile("global_load_dword %0, %1, %2" : "+v"(r1) : "v"(o), "s"(Jb10));
+#else
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(r0) : "v"(o), "s"(Jb00));
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(r1) : "v"(o), "s"(Jb10));
+#endif
                         A[q][g][w] = f2{__uint_as_float(r0), __uint_as_float(r1)};
                         continue;
                     }
@@ -567,7 +574,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     asm volatile("" : "+v"(gcol), "+v"(t0), "+v"(voff0));
     load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes, std::integral_constant<int, 0>{});      // prologue: H0 of step 0
     int slot = 0;                                            // LDS slot of this step's result (= i1 % kCsFlush)
-    if constexpr (ROLL2) {
+    if constexpr (TWO) {
         for (int i1 = i1b; i1 < i1e; ++i1) {
             {
 #define CS_PN 0
