@@ -268,17 +268,18 @@ def run_c3(args, steps, warmup, dev, n=51):
             "halo": (0, 0), "checksum": cs, "total_backups": spec.nS * spec.nU * steps, "walls": [wall]}
 
 
-def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=False, reps=1):
+def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=False, reps=1, transport=None):
     """Times `steps` stages of `workload` on this rank's slab, `reps` times over (each repetition bracketed by barriers;
     the MEDIAN repetition is reported, all of them are returned).  -> dict of measurements."""
     import torch
     from hjbdp.sharded import ShardedSweep
     n = {"c2": 101, "6d": 24}.get(workload, args.grid_n)
     spec, name = build_spec(workload, n_last=n * world if weak else None, n=args.grid_n)
-    sw = ShardedSweep(spec, rank, world, dev, overlap=not args.no_overlap, transport=args.transport)
+    sw = ShardedSweep(spec, rank, world, dev, overlap=not args.no_overlap, transport=transport or args.transport)
     if args.variant is not None:
         sw.set_option("variant", args.variant)
     info = sw.info()
+    info["comm_ranks"] = sw.comm_ranks()
     sw.set_terminal(None)
 
     def barrier():
@@ -483,6 +484,22 @@ def main():
         "roofline": rf,
         "checksum_sum_J": head["checksum"],
     }
+    if world > 1:
+        # BOTH halo transports in one run: the headline above ran `--transport`; the other one - the RCCL
+        # calls inside libhjbdp, or torch.distributed's P2P - sweeps the same grid here, and each leg carries the rank count its
+        # communicator ITSELF reports (ncclCommCount through the library / the process group's size), so that a first multi-GPU
+        # run verifies what it measured.  Equal checksums = the two transports delivered the same halo planes.
+        legs = {args.transport: head}
+        other = "lib" if args.transport == "torch" else "torch"
+        if args.backend == "nccl":
+            legs[other] = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist, reps=3, transport=other)
+        out["transports"] = {k: {"ms_per_step": r["wall"] * 1e3 / r["steps"], "value": r["total_backups"] / r["wall"],
+                                 "checksum_sum_J": r["checksum"], "comm_ranks": r["info"]["comm_ranks"],
+                                 "what": "RCCL inside libhjbdp (hjb_rank_step: ncclSend / ncclRecv on the library's transfer stream)"
+                                         if k == "lib" else "torch.distributed batch_isend_irecv (" + args.backend + ")"}
+                             for k, r in legs.items()}
+        out["transports"]["headline"] = args.transport
+        out["transports"]["checksums_equal"] = len({r["checksum"] for r in legs.values()}) == 1
     if not args.no_extras:
         if world == 1:
             others = {}

@@ -441,6 +441,9 @@ const char *hjb_rank_last_error(hjb_rank r);
  * tools/bench_ranks.cpp is a C++ driver on these calls (one process per GPU, no Python). */
 int32_t hjb_rank_comm_unique_id(void *id128_out);
 int32_t hjb_rank_comm_init(hjb_rank r, const void *id128);
+/* what the communicator itself reports (ncclCommCount / ncclCommUserRank; -1 where librccl lacks the query): lets a run
+ * verify that the ranks it timed were ranks of ONE communicator of the expected size */
+int32_t hjb_rank_comm_info(hjb_rank r, int32_t *n_ranks, int32_t *comm_rank);
 int32_t hjb_rank_exchange(hjb_rank r, void *dJ, void *compute_stream);
 void *hjb_rank_transfer_stream(hjb_rank r);
 int32_t hjb_rank_step(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream);

@@ -278,6 +278,8 @@ struct RcclApi {
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;          // optional: what the communicator itself reports (hjb_rank_comm_info)
+    int (*CommUserRank)(void *, int *) = nullptr;
     std::string why;
 };
 RcclApi g_rccl;
@@ -316,6 +318,8 @@ bool rccl_load() {
     a.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))sym("ncclRecv");
     a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
     a.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    a.CommCount = (int (*)(void *, int *))dlsym(lib, "ncclCommCount");
+    a.CommUserRank = (int (*)(void *, int *))dlsym(lib, "ncclCommUserRank");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv || !a.AllReduce ||
         !a.GetErrorString) {
         dlclose(lib);
@@ -379,6 +383,19 @@ int32_t hjb_rank_comm_init(hjb_rank r, const void *id128) {
         rank_comm_release(r);
         return rfail(r, e == hipErrorOutOfMemory ? HJB_E_NOMEM : HJB_E_DEVICE, "hjb_rank_comm_init: %s", hipGetErrorString(e));
     }
+    return HJB_OK;
+}
+
+// What the communicator ITSELF reports (ncclCommCount / ncclCommUserRank): a multi-GPU run verifies with it that the ranks it
+// timed were ranks of one communicator of the expected size (bench.py prints it).  -1 where librccl lacks the query.
+int32_t hjb_rank_comm_info(hjb_rank r, int32_t *n_ranks, int32_t *comm_rank) {
+    if (!r) return rfail(r, HJB_E_INVALID, "null argument");
+    if (!r->comm) return rfail(r, HJB_E_INVALID, "hjb_rank_comm_init first");
+    int n = -1, me = -1;
+    if (g_rccl.CommCount) RCCL_TRY(r, g_rccl.CommCount(r->comm, &n));
+    if (g_rccl.CommUserRank) RCCL_TRY(r, g_rccl.CommUserRank(r->comm, &me));
+    if (n_ranks) *n_ranks = n;
+    if (comm_rank) *comm_rank = me;
     return HJB_OK;
 }
 

@@ -193,6 +193,7 @@ SYMBOLS = {
     "hjb_rank_create_from": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "hjb_rank_comm_unique_id": (C.c_int32, [C.c_void_p]),
     "hjb_rank_comm_init": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "hjb_rank_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hjb_rank_exchange": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_rank_transfer_stream": (C.c_void_p, [C.c_void_p]),
     "hjb_rank_step": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

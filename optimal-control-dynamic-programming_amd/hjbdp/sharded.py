@@ -151,6 +151,21 @@ class ShardedSweep:
         return {"kernel_variant": rk.kernel_variant, "halo_needed_lo": rk.need_lo, "halo_needed_hi": rk.need_hi,
                 "idx_bytes": rk.idx_bytes, "split": rk.split}
 
+    def comm_ranks(self):
+        """The rank count the transport's communicator ITSELF reports: ncclCommCount through the library (transport "lib"),
+        the process group's size (transport "torch"); 1 without a communicator."""
+        if self.world == 1:
+            return 1
+        if self.transport == "lib" and self._rank is not None:
+            import ctypes as C
+            n, me = C.c_int32(-1), C.c_int32(-1)
+            self._rank._check(self._rank.lib.hjb_rank_comm_info(self._rank._r, C.byref(n), C.byref(me)))
+            if me.value not in (-1, self.rank):
+                raise RuntimeError("communicator rank %d != rank %d" % (me.value, self.rank))
+            return int(n.value)
+        import torch.distributed as dist
+        return int(dist.get_world_size(self.group))
+
     def set_option(self, key, value):
         self._rank.set_option(key, value)
 

@@ -523,6 +523,9 @@ def test_rccl_transport_inside_the_library_loopback(env, overlap):
     uid = _rccl_unique_id(lib, _abi)
     assert lib.hjb_rank_comm_init(rk._r, uid) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
     assert lib.hjb_rank_transfer_stream(rk._r)
+    nr, me = C.c_int32(-5), C.c_int32(-5)
+    assert lib.hjb_rank_comm_info(rk._r, C.byref(nr), C.byref(me)) == _abi.HJB_OK      # the loopback communicator: one rank, rank 0
+    assert (nr.value, me.value) in ((1, 0), (-1, -1))
     rng = np.random.default_rng(5)
     init = (rng.random((inner, planes)) * 3).astype(np.float32)
     with hjbdp.DeviceBuffer(init.nbytes) as dIn, hjbdp.DeviceBuffer(init.nbytes) as dOut, \

@@ -904,6 +904,11 @@ def test_two_rank_sharded_bench_matches_single_rank(env, overlap):
     assert a["config"]["kernel_variant"] == 7 and b["config"]["kernel_variant"] == 7
     assert abs(a["checksum_sum_J"] - b["checksum_sum_J"]) <= 1e-12 * abs(a["checksum_sum_J"])
     assert b["config"]["states_per_gpu"] * 2 == a["config"]["states_per_gpu"] == b["config"]["states"]
+    # the line says which transport carried the halos and how many ranks its communicator reports (under RCCL it also times the
+    # other transport - the RCCL calls inside libhjbdp - in the same run; two ranks on ONE device cannot form an RCCL communicator)
+    tr = b["transports"]
+    assert tr["headline"] == "torch" and tr["torch"]["comm_ranks"] == 2 and tr["checksums_equal"]
+    assert tr["torch"]["checksum_sum_J"] == b["checksum_sum_J"] and "transports" not in a
 
 
 F16 = [((9, 8), (3,), False), ((13, 11, 9), (4, 5), True), ((6, 5, 4, 5), (3, 4), False), ((7, 6), (70,), True)]
