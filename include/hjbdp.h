@@ -413,6 +413,12 @@ int32_t hjb_rank_create(const hjb_problem *problem, int32_t device, int32_t rank
 int32_t hjb_rank_create_from(hjb_builder b, int32_t device, int32_t rank, int32_t world, int32_t overlap, hjb_rank *out);
 int32_t hjb_rank_info(hjb_rank r, int32_t *out10);
 int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream);
+/* The stage with the boundary strips enqueued FIRST, behind what halo_stream holds (the previous exchange), and
+ * hjb_rank_wait_strips: `stream` waits for that stage's strips (*covered = 1 when they cover every plane a neighbour needs;
+ * 0: nothing is enqueued, the caller's exchange waits for the compute stream).  The pieces of hjb_rank_step_post (below) for a
+ * host that moves the halo planes itself: exchange dJ_out's boundary planes behind the strips, under the rest of the interior. */
+int32_t hjb_rank_stage_post(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream);
+int32_t hjb_rank_wait_strips(hjb_rank r, void *stream, int32_t *covered);
 int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value);
 int32_t hjb_rank_get_option(hjb_rank r, const char *key, int64_t *value);
 int32_t hjb_rank_check_status(hjb_rank r, void *stream);
@@ -447,6 +453,12 @@ int32_t hjb_rank_comm_info(hjb_rank r, int32_t *n_ranks, int32_t *comm_rank);
 int32_t hjb_rank_exchange(hjb_rank r, void *dJ, void *compute_stream);
 void *hjb_rank_transfer_stream(hjb_rank r);
 int32_t hjb_rank_step(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream);
+/* The stage in the order that hides the exchange: boundary strips FIRST (the halos of dJ_in arrived during the previous stage),
+ * the interior beside them, and the exchange of dJ_OUT's boundary planes as soon as the strips are done, under the rest of the
+ * interior.  Precondition: dJ_in's halos are valid - one hjb_rank_exchange(r, dJ_in, stream) before the first step; every step
+ * leaves dJ_out's halos filled (ordered for the next hjb_rank_step_post / the transfer stream / a device synchronisation).
+ * hjb_rank_sweep runs this form (option "post_exchange" 0: hjb_rank_step). */
+int32_t hjb_rank_step_post(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream);
 int32_t hjb_rank_monitor_sums(hjb_rank r, const void *dJ, const void *d_idx, void *compute_stream, double *sums2);
 int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, double monitor_tol, void *dJ0, void *dJ1, void *d_idx,
                        void *compute_stream, int32_t *stages_done, int32_t *stopped_early, int32_t *final_in_0, double *sweep_ms);

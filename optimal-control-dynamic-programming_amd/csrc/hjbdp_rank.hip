@@ -36,6 +36,8 @@ struct hjb_rank_s {
     int dtype = HJB_F32, up_needs = 0, dn_needs = 0;
     int64_t xfer_delay_ticks = 0;     // option "xfer_delay_us": a spin of that length behind every exchange (link-latency emulation)
     bool monitor_single = false;      // option "monitor_single": hjb_rank_sweep's monitor in single precision (see there)
+    hipEvent_t xdone = nullptr;       // recorded on the transfer stream behind every exchange (hjb_rank_step_post's strips wait for it)
+    bool post_exchange = true;        // option "post_exchange": hjb_rank_sweep runs hjb_rank_step_post (1, default) or hjb_rank_step (0)
 };
 
 static int rfail(hjb_rank r, int code, const char *fmt, ...) {
@@ -189,6 +191,7 @@ int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value) {
         }
         return HJB_OK;
     }
+    if (!strcmp(key, "post_exchange")) { r->post_exchange = value != 0; return HJB_OK; }      // hjb_rank_sweep: hjb_rank_step_post (1) / hjb_rank_step (0)
     if (!strcmp(key, "monitor_single")) r->monitor_single = value != 0;      // ... and on to the handles (hjb_rank_get_option reads it there)
     Handle *hs[4] = {r->whole, r->part[0], r->part[1], r->part[2]};
     for (Handle *h : hs)
@@ -216,7 +219,9 @@ int32_t hjb_rank_check_status(hjb_rank r, void *stream) {
     return HJB_OK;
 }
 
-int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream) {
+}  // extern "C"
+// strips_first: the boundary strips are enqueued before the interior (their halos are there already: hjb_rank_step_post)
+static int rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream, bool strips_first) {
     if (!r || !dJ_in || !dJ_out) return rfail(r, HJB_E_INVALID, "null argument");
     hipStream_t cs = (hipStream_t)compute_stream, hs = (hipStream_t)halo_stream;
     const size_t plane_b = (size_t)r->inner * r->esz;
@@ -247,8 +252,11 @@ int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx,
     RANK_TRY(hipEventRecord(r->fork, cs));
     for (int k = 1; k <= 2; ++k)
         if (r->part[k]) RANK_TRY(hipStreamWaitEvent(r->ss[k - 1], r->fork, 0));
-    int st = stage_part(0, cs);
-    if (st) return st;
+    int st = HJB_OK;
+    if (!strips_first) {
+        st = stage_part(0, cs);
+        if (st) return st;
+    }
     if (halos) RANK_TRY(hipEventRecord(r->halo, hs));
     for (int k = 1; k <= 2; ++k)
         if (r->part[k]) {
@@ -256,10 +264,44 @@ int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx,
             st = stage_part(k, r->ss[k - 1]);
             if (st) return st;
             RANK_TRY(hipEventRecord(r->sdone[k - 1], r->ss[k - 1]));
-            RANK_TRY(hipStreamWaitEvent(cs, r->sdone[k - 1], 0));
         }
+    if (strips_first) {
+        st = stage_part(0, cs);
+        if (st) return st;
+    }
+    for (int k = 1; k <= 2; ++k)
+        if (r->part[k]) RANK_TRY(hipStreamWaitEvent(cs, r->sdone[k - 1], 0));
     return HJB_OK;
 #undef RANK_TRY
+}
+extern "C" {
+
+int32_t hjb_rank_stage(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream) {
+    return rank_stage(r, dJ_in, dJ_out, d_idx, compute_stream, halo_stream, false);
+}
+
+// The pieces of hjb_rank_step_post for a host that moves the halo planes itself (hjbdp/sharded.py with torch.distributed):
+// hjb_rank_stage_post = the stage with the boundary strips enqueued FIRST, behind what halo_stream holds (the previous
+// exchange); hjb_rank_wait_strips makes `stream` wait for that stage's strips - the caller's exchange of dJ_out's boundary
+// planes goes there, under the rest of the interior.  out: *covered = 1 when the strips cover every plane a neighbour needs
+// (else the caller's exchange must wait for the whole stage: the compute stream).
+int32_t hjb_rank_stage_post(hjb_rank r, const void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream, void *halo_stream) {
+    return rank_stage(r, dJ_in, dJ_out, d_idx, compute_stream, halo_stream, true);
+}
+
+int32_t hjb_rank_wait_strips(hjb_rank r, void *stream, int32_t *covered) {
+    if (!r) return rfail(r, HJB_E_INVALID, "null argument");
+    const int owned = r->end - r->begin;
+    const int lo_w = r->part[1] ? r->need_lo : 0, hi_w = r->part[2] ? r->need_hi : 0;
+    const bool cover = r->part[0] && r->dn_needs <= (r->part[1] ? lo_w : (r->dn_needs ? 0 : owned)) &&
+                       r->up_needs <= (r->part[2] ? hi_w : (r->up_needs ? 0 : owned));
+    if (covered) *covered = cover ? 1 : 0;
+    if (!cover) return HJB_OK;
+    if (hipSetDevice(r->device) != hipSuccess) return rfail(r, HJB_E_DEVICE, "hipSetDevice failed");
+    for (int k = 0; k < 2; ++k)
+        if (r->part[k + 1] && hipStreamWaitEvent((hipStream_t)stream, r->sdone[k], 0) != hipSuccess) return rfail(r, HJB_E_DEVICE, "hipStreamWaitEvent failed");
+    if (hipStreamWaitEvent((hipStream_t)stream, r->fork, 0) != hipSuccess) return rfail(r, HJB_E_DEVICE, "hipStreamWaitEvent failed");
+    return HJB_OK;
 }
 
 // ---- RCCL inside the library: the halo exchange and the monitor's all-reduce of a rank, no torch, no MPI ------------------
@@ -354,6 +396,8 @@ static void rank_comm_release(hjb_rank r) {
     r->comm = nullptr;
     if (r->xfer) (void)hipStreamDestroy(r->xfer);
     if (r->xready) (void)hipEventDestroy(r->xready);
+    if (r->xdone) (void)hipEventDestroy(r->xdone);
+    r->xdone = nullptr;
     if (r->d_partials) (void)hipFree(r->d_partials);
     if (r->d_sums) (void)hipFree(r->d_sums);
     r->xfer = nullptr; r->xready = nullptr; r->d_partials = nullptr; r->d_sums = nullptr;
@@ -377,6 +421,8 @@ int32_t hjb_rank_comm_init(hjb_rank r, const void *id128) {
     RCCL_TRY(r, g_rccl.CommInitRank(&r->comm, r->loopback ? 1 : r->world, id, r->loopback ? 0 : r->rank));
     hipError_t e = hipStreamCreateWithFlags(&r->xfer, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->xready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->xdone, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(r->xdone, r->xfer);          // "no exchange pending"
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_partials, sizeof(double) * 2 * kReduceBlocks);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_sums, sizeof(double) * 2);
     if (e != hipSuccess) {          // leave nothing half-built: a retry must not be refused with "already has a communicator"
@@ -402,17 +448,15 @@ int32_t hjb_rank_comm_info(hjb_rank r, int32_t *n_ranks, int32_t *comm_rank) {
 // The halo exchange of dJ (this rank's haloed J buffer) on the library's transfer stream, ordered behind everything
 // `compute_stream` holds at the time of the call (the stage that wrote dJ).  Returns at once; hjb_rank_stage's halo_stream
 // argument = hjb_rank_transfer_stream(r) makes the boundary strips wait for it (hjb_rank_step does both).
-int32_t hjb_rank_exchange(hjb_rank r, void *dJ, void *compute_stream) {
-    if (!r || !dJ) return rfail(r, HJB_E_INVALID, "null argument");
-    if (!r->comm) return rfail(r, HJB_E_INVALID, "hjb_rank_comm_init first");
-    RANKH_TRY(r, hipSetDevice(r->device));
-    RANKH_TRY(r, hipEventRecord(r->xready, (hipStream_t)compute_stream));
-    RANKH_TRY(r, hipStreamWaitEvent(r->xfer, r->xready, 0));
+}  // extern "C"
+// the grouped send / recv of dJ's boundary planes on the transfer stream, which the caller has ordered behind the stage
+// (or the strips) that wrote them; xdone is recorded behind it
+static int rank_exchange_on_xfer(hjb_rank r, void *dJ) {
     const size_t plane_b = (size_t)r->inner * r->esz;
     const int owned = r->end - r->begin;
     char *J = (char *)dJ;
     const int dn = r->loopback ? 0 : r->rank - 1, up = r->loopback ? 0 : r->rank + 1;
-    if (!(r->dn_needs || r->hlo || r->up_needs || r->hhi)) return HJB_OK;
+    if (!(r->dn_needs || r->hlo || r->up_needs || r->hhi)) { RANKH_TRY(r, hipEventRecord(r->xdone, r->xfer)); return HJB_OK; }
     RCCL_TRY(r, g_rccl.GroupStart());
     int e1 = 0;
     // towards rank - 1: my lowest owned planes are its upper halo; its top planes are my lower halo
@@ -430,7 +474,18 @@ int32_t hjb_rank_exchange(hjb_rank r, void *dJ, void *compute_stream) {
     const int e2 = g_rccl.GroupEnd();
     if (e1 || e2) return rfail(r, HJB_E_DEVICE, "halo exchange: %s", g_rccl.GetErrorString(e1 ? e1 : e2));
     if (r->xfer_delay_ticks > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, r->xfer, (long long)r->xfer_delay_ticks);
+    RANKH_TRY(r, hipEventRecord(r->xdone, r->xfer));
     return HJB_OK;
+}
+extern "C" {
+
+int32_t hjb_rank_exchange(hjb_rank r, void *dJ, void *compute_stream) {
+    if (!r || !dJ) return rfail(r, HJB_E_INVALID, "null argument");
+    if (!r->comm) return rfail(r, HJB_E_INVALID, "hjb_rank_comm_init first");
+    RANKH_TRY(r, hipSetDevice(r->device));
+    RANKH_TRY(r, hipEventRecord(r->xready, (hipStream_t)compute_stream));
+    RANKH_TRY(r, hipStreamWaitEvent(r->xfer, r->xready, 0));
+    return rank_exchange_on_xfer(r, dJ);
 }
 
 void *hjb_rank_transfer_stream(hjb_rank r) { return r ? (void *)r->xfer : nullptr; }
@@ -443,6 +498,42 @@ int32_t hjb_rank_step(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *
         if (st) return st;
     }
     return hjb_rank_stage(r, dJ_in, dJ_out, d_idx, compute_stream, (r->world > 1 || r->loopback) ? (void *)r->xfer : nullptr);
+}
+
+// The same stage in the order that hides the exchange completely: a stage's boundary strips need the halos of ITS input,
+// and what the neighbours need next is this stage's strips' OUTPUT.  So: the strips first (their halos arrived during the
+// previous stage), the interior beside them, and the exchange of dJ_out's boundary planes on the transfer stream as soon as
+// the strips are done - it has the whole rest of the interior to complete, and the next stage starts with its halos in
+// place.  (hjb_rank_step exchanges dJ_in FIRST: its strips start an exchange late and the next stage's exchange cannot start
+// before they end.)  Precondition: dJ_in's halo planes are valid - ONE hjb_rank_exchange(r, dJ_in, compute_stream) before the
+// first step; every step leaves dJ_out's halos filled (the transfer may still be in flight when the call returns: the next
+// hjb_rank_step_post, hjb_rank_transfer_stream(r) or a device synchronisation orders behind it).  A rank whose neighbours need
+// planes its strips do not cover (need_lo != need_hi) sends after its interior; a rank without the split, after its one kernel.
+int32_t hjb_rank_step_post(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream) {
+    if (!r || !dJ_in || !dJ_out) return rfail(r, HJB_E_INVALID, "null argument");
+    const bool comm = r->world > 1 || r->loopback;
+    if (!comm) return rank_stage(r, dJ_in, dJ_out, d_idx, compute_stream, nullptr, false);
+    if (!r->comm) return rfail(r, HJB_E_INVALID, "hjb_rank_comm_init first");
+    RANKH_TRY(r, hipSetDevice(r->device));
+    hipStream_t cs = (hipStream_t)compute_stream;
+    // the strips (or, without the split, the one kernel) wait for the previous exchange: halo_stream = the transfer stream
+    int st = rank_stage(r, dJ_in, dJ_out, d_idx, compute_stream, (void *)r->xfer, true);
+    if (st) return st;
+    const int owned = r->end - r->begin;
+    const int lo_w = r->part[1] ? r->need_lo : 0, hi_w = r->part[2] ? r->need_hi : 0;       // planes the strips cover
+    const bool strips_cover = r->part[0] && r->dn_needs <= (r->part[1] ? lo_w : (r->dn_needs ? 0 : owned)) &&
+                              r->up_needs <= (r->part[2] ? hi_w : (r->up_needs ? 0 : owned));
+    if (strips_cover) {
+        for (int k = 0; k < 2; ++k)
+            if (r->part[k + 1]) RANKH_TRY(r, hipStreamWaitEvent(r->xfer, r->sdone[k], 0));
+        // ... and, like the strips themselves, behind everything the compute stream held before this stage (J_out's halo
+        // planes were the previous stage's input)
+        RANKH_TRY(r, hipStreamWaitEvent(r->xfer, r->fork, 0));
+    } else {
+        RANKH_TRY(r, hipEventRecord(r->xready, cs));
+        RANKH_TRY(r, hipStreamWaitEvent(r->xfer, r->xready, 0));
+    }
+    return rank_exchange_on_xfer(r, dJ_out);
 }
 
 // The monitor's two sums (Solver_pos_att.m:274-275) over the WHOLE grid: this rank's owned planes reduced on the device
@@ -487,8 +578,10 @@ int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, dou
     const bool msingle = r->monitor_single && r->dtype != HJB_F64;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, cs) != hipSuccess)
         st = rfail(r, HJB_E_DEVICE, "sweep: event set-up failed: %s", hipGetErrorString(hipGetLastError()));
+    const bool post = r->post_exchange && (r->world > 1 || r->loopback);
+    if (post && !st && n_stages >= 1) st = hjb_rank_exchange(r, J[0], compute_stream);      // the terminal cost's halos, once
     for (int k_s = n_stages; k_s >= 1 && !st; --k_s) {
-        st = hjb_rank_step(r, J[cur], J[1 - cur], d_idx, compute_stream);
+        st = post ? hjb_rank_step_post(r, J[cur], J[1 - cur], d_idx, compute_stream) : hjb_rank_step(r, J[cur], J[1 - cur], d_idx, compute_stream);
         if (st) break;
         cur = 1 - cur;
         ++done;

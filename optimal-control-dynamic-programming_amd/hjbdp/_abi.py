@@ -197,11 +197,14 @@ SYMBOLS = {
     "hjb_rank_exchange": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_rank_transfer_stream": (C.c_void_p, [C.c_void_p]),
     "hjb_rank_step": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_rank_step_post": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_rank_monitor_sums": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "hjb_rank_sweep": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "hjb_rank_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hjb_rank_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_rank_stage_post": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hjb_rank_wait_strips": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "hjb_rank_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
     "hjb_rank_get_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "hjb_rank_check_status": (C.c_int32, [C.c_void_p, C.c_void_p]),

@@ -437,6 +437,21 @@ class RankSlab:
         self._check(self.lib.hjb_rank_stage(self._r, ptr(dJ_in), ptr(dJ_out), ptr(d_idx), int(compute_stream) or None,
                                             int(halo_stream) or None))
 
+    def stage_post(self, dJ_in, dJ_out, d_idx, compute_stream=0, halo_stream=0):
+        """The stage with the boundary strips first (hjb_rank_stage_post): their halos are already in dJ_in."""
+        def ptr(x):
+            if x is None:
+                return None
+            return int(x.data_ptr()) if hasattr(x, "data_ptr") else int(x)
+        self._check(self.lib.hjb_rank_stage_post(self._r, ptr(dJ_in), ptr(dJ_out), ptr(d_idx), int(compute_stream) or None,
+                                                 int(halo_stream) or None))
+
+    def wait_strips(self, stream):
+        """`stream` waits for the last stage's boundary strips; -> True when they cover every plane a neighbour needs."""
+        cov = C.c_int32(0)
+        self._check(self.lib.hjb_rank_wait_strips(self._r, int(stream) or None, C.byref(cov)))
+        return bool(cov.value)
+
     def set_option(self, key, value):
         self._check(self.lib.hjb_rank_set_option(self._r, key.encode(), int(value)))
         self.refresh()

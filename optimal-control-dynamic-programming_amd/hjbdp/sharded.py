@@ -137,6 +137,8 @@ class ShardedSweep:
                 rk._check(rk.lib.hjb_rank_comm_init(rk._r, box[0]))
         self.stage_fn = stage_fn
         self._halo_ops = {}
+        self.post_exchange = True     # split form: strips first, the exchange of the output behind them (False: exchange the input first)
+        self._halos_valid = False     # the current buffer's halo planes hold the neighbours' boundary planes
         # what my neighbours need from me
         self.up_needs = min(need_lo, self.end) if self.rank < world - 1 else 0     # my top planes -> rank+1's lower halo
         self.dn_needs = min(need_hi, nl - self.begin) if self.rank > 0 else 0      # my bottom planes -> rank-1's upper halo
@@ -170,24 +172,28 @@ class ShardedSweep:
         self._rank.set_option(key, value)
 
     def check_device_status(self):
+        if getattr(self, "_comm_stream", None) is not None:       # a trailing exchange (post_exchange) may still be in flight
+            self.torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
         self._rank.check_device_status(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_terminal(self, J_global=None):
         """J_N: None = zeros (Dynamic_Solver.m:83-84); else global [nS] column-major."""
         J = self.J[self.cur]
         J.zero_()
+        self._halos_valid = False
         if J_global is not None:
             g = self.torch.as_tensor(np.asarray(J_global, dtype=self.spec.j_dtype).reshape(self.spec.n[-1], self.inner))
             J[self.halo_lo:self.halo_lo + self.owned] = g[self.begin:self.end].to(self.device)
 
-    def exchange_halos(self, wait=True):
-        """Fill the halo planes of the current J from the neighbouring ranks.  wait=False returns the
-        pending work objects instead of waiting (RCCL: the transfers run on the communicator's stream)."""
+    def exchange_halos(self, wait=True, which=None):
+        """Fill the halo planes of the current J (which=None) or of buffer `which` from the neighbouring ranks.  wait=False
+        returns the pending work objects instead of waiting (RCCL: the transfers run on the communicator's stream)."""
         if self.world == 1:
             return []
         import torch.distributed as dist
-        J = self.J[self.cur]
-        cached = self._halo_ops.get(self.cur)           # the two J buffers never move: their send / receive views are built once
+        which = self.cur if which is None else which
+        J = self.J[which]
+        cached = self._halo_ops.get(which)              # the two J buffers never move: their send / receive views are built once
         if cached is None:
             ops, keep = [], []
             lo0 = self.halo_lo
@@ -206,7 +212,7 @@ class ShardedSweep:
                 if self.halo_hi:
                     ops.append(dist.P2POp(dist.irecv, J[lo0 + self.owned:], self.rank + 1, group=self.group))
             assert all(o.tensor.is_contiguous() for o in ops)
-            cached = self._halo_ops[self.cur] = (ops, keep)
+            cached = self._halo_ops[which] = (ops, keep)
         ops, keep = cached
         if ops:
             if J.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -242,6 +248,24 @@ class ShardedSweep:
         elif self._rank is None or not self._rank.split:
             self.exchange_halos()
             self.stage_fn(J_in, J_out, self.idx)
+        elif self.post_exchange:
+            # Boundary strips FIRST (the halos of J_in arrived during the previous stage), the interior beside them, and the
+            # exchange of J_OUT's boundary planes as soon as the strips are done - it has the rest of the interior to complete,
+            # and the next stage starts with its halos in place (hjb_rank_step_post's order, include/hjbdp.h).
+            t = self.torch
+            main = t.cuda.current_stream(self.device)
+            if not self._halos_valid:                      # the terminal cost: one exchange before the first stage
+                self._comm_stream.wait_stream(main)
+                with t.cuda.stream(self._comm_stream):
+                    for w in self.exchange_halos(wait=False):
+                        w.wait()
+            self._rank.stage_post(J_in, J_out, self.idx, compute_stream=main.cuda_stream, halo_stream=self._comm_stream.cuda_stream)
+            if not self._rank.wait_strips(self._comm_stream.cuda_stream):
+                self._comm_stream.wait_stream(main)        # a neighbour needs planes the strips do not cover: after the interior
+            with t.cuda.stream(self._comm_stream):
+                for w in self.exchange_halos(wait=False, which=1 - self.cur):
+                    w.wait()
+            self._halos_valid = True
         else:
             t = self.torch
             main = t.cuda.current_stream(self.device)
@@ -300,6 +324,8 @@ class ShardedSweep:
         return np.concatenate(outJ), np.concatenate(outI)
 
     def close(self):
+        if getattr(self, "_comm_stream", None) is not None:
+            self._comm_stream.synchronize()
         if self._rank is not None:
             self._rank.close()
             self._rank = None

@@ -552,6 +552,38 @@ def test_rccl_transport_inside_the_library_loopback(env, overlap):
         assert lib.hjb_rank_monitor_sums(rk._r, int(dOut), int(dI), None, sums) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
         assert abs(sums[0] - float(mine.astype(np.float64).sum())) <= 1e-9 * abs(sums[0])
         assert sums[1] == float(io.astype(np.float64).sum())
+        # hjb_rank_step_post: the strips first, the exchange of the OUTPUT's boundary planes behind the strips, under the interior.
+        # One exchange of the input, then the step: the stage equals the oracle's backup of the exchanged input, and the output
+        # comes back with its own halos filled (loopback: its own boundary planes)
+        dIn.upload(np.asfortranarray(init).reshape(-1, order="F"))
+        dOut.upload(np.full(init.size, -7.0, dtype=np.float32))
+        assert lib.hjb_rank_exchange(rk._r, int(dIn), None) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
+        assert lib.hjb_rank_step_post(rk._r, int(dIn), int(dOut), int(dI), None) == _abi.HJB_OK, lib.hjb_rank_last_error(rk._r)
+        rk.check_device_status()
+        rk.check_device_status(lib.hjb_rank_transfer_stream(rk._r))
+        got = dOut.download(np.float32).reshape(inner, planes, order="F")
+        own = Jo.reshape(inner, planes, order="F")[:, hlo:hlo + owned]
+        assert np.array_equal(got[:, hlo:hlo + owned], own) and np.array_equal(dI.download(spec.idx_np_dtype), io)
+        assert np.array_equal(got[:, :hlo], own[:, owned - hlo:]) and np.array_equal(got[:, hlo + owned:], own[:, :hhi])
+        # the whole loop both ways (option "post_exchange"): the same sweep, equal to the oracle driven stage by stage with the
+        # loopback's halos (each stage's input halos = that buffer's own boundary planes)
+        cur = init.copy()
+        for _ in range(5):
+            cur[:, :hlo] = cur[:, owned:owned + hlo]
+            cur[:, hlo + owned:] = cur[:, hlo:hlo + hhi]
+            nxt, iref = c_oracle.backup_stage(_abi, spec, np.asfortranarray(cur).reshape(-1, order="F"), slab=(rk.begin, rk.end, hlo, hhi))
+            cur = nxt.reshape(inner, planes, order="F").copy()
+        for post in (1, 0):
+            rk.set_option("post_exchange", post)
+            dIn.upload(np.asfortranarray(init).reshape(-1, order="F"))
+            dOut.upload(np.asfortranarray(init).reshape(-1, order="F"))
+            done, early, in0, ms = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+            st = lib.hjb_rank_sweep(rk._r, 5, 0, 0.0, int(dIn), int(dOut), int(dI), None, C.byref(done), C.byref(early), C.byref(in0), C.byref(ms))
+            assert st == _abi.HJB_OK and done.value == 5, lib.hjb_rank_last_error(rk._r)
+            rk.check_device_status(lib.hjb_rank_transfer_stream(rk._r))
+            J = (dIn if in0.value else dOut).download(np.float32).reshape(inner, planes, order="F")
+            assert np.array_equal(J[:, hlo:hlo + owned], cur[:, hlo:hlo + owned]), post
+            assert np.array_equal(dI.download(spec.idx_np_dtype), iref), post
     rk.close()
 
 
