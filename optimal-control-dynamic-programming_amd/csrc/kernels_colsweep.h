@@ -71,6 +71,14 @@ constexpr int kCsMaxCu = kLeanMaxCu;
 #define HJB_CS_WAVES 6
 #endif
 constexpr int kCsFlush = HJB_CS_FLUSH;
+// HJB_CS_DIRECT (round 5): every step STORES its result at once instead of parking 16 steps in LDS and writing them out behind
+// a full drain.  The drain was there because gfx9 counts loads and stores on one counter and they complete out of order WITH
+// EACH OTHER; but the counted waits stay safe with stores pending as long as the count they wait for is the number of younger
+// LOADS only: vmcnt <= N leaves at most N - (stores pending) loads pending, and loads complete in order among themselves, so the
+// awaited (older) gathers have landed whatever the stores do - a store can only make a wait last longer, never let it pass early.
+#ifndef HJB_CS_DIRECT
+#define HJB_CS_DIRECT 1
+#endif
 constexpr int kCsDppLanes = 60; // states per wave in the one-load form (+ a halo lane + a spare lane pair + 1)
 // The plan of one (i2, i3), 32-bit words:
 //   [0] halo violation flag | groups << 8   [1 + g] byte offset of group g's first corner row
@@ -146,6 +154,13 @@ __device__ __forceinline__ uint32_t gather_async(uint32_t off, gptr<char> base) 
     if (BYTES == 4) asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(off), "s"(base));
     else asm volatile("global_load_ushort %0, %1, %2" : "=v"(r) : "v"(off), "s"(base));
     return r;
+}
+// A result stored the same way: one 32-bit per-lane byte offset against a scalar base, issued by hand (HJB_CS_DIRECT).
+template <int BYTES>
+__device__ __forceinline__ void store_async(uint32_t off, uint32_t v, __attribute__((address_space(1))) char *base) {
+    if (BYTES == 4) asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+    else if (BYTES == 2) asm volatile("global_store_short %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+    else asm volatile("global_store_byte %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_gathers() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N)); }
 // The same with a count known only at run time (a multiple of K, at most 9 K): `s_waitcnt` takes an immediate, and a
@@ -301,8 +316,8 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     __shared__ f4 s_slots[4][kCsSlots * 2];
-    __shared__ T s_best[4][kCsFlush][64];
-    __shared__ uint8_t s_idx[4][kCsFlush][64];               // control numbers (< kCsUMax) as bytes: more steps per flush
+    __shared__ T s_best[4][HJB_CS_DIRECT ? 1 : kCsFlush][HJB_CS_DIRECT ? 1 : 64];
+    __shared__ uint8_t s_idx[4][HJB_CS_DIRECT ? 1 : kCsFlush][HJB_CS_DIRECT ? 1 : 64];      // control numbers (< kCsUMax) as bytes: more steps per flush
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int n0 = P->n[0], n1 = P->n[1], n2 = P->n[2], n3 = P->n[3];
@@ -432,6 +447,10 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     const uint32_t idx_col = (uint32_t)i0 + (uint32_t)n0 * (uint32_t)n1 * ((uint32_t)i2 + (uint32_t)n2 * (uint32_t)i3);
     const uint32_t js1 = (uint32_t)P->jstride[1];
     const int index_base = P->index_base, idx_bytes = P->idx_bytes;
+    // HJB_CS_DIRECT: per-lane byte offsets of the column's results (J < 4 GiB in this kernel: every gather offset is 32-bit too)
+    const uint32_t out_off = out_col * (uint32_t)sizeof(TJ), idx_off = idx_col * (uint32_t)idx_bytes;
+    typedef __attribute__((address_space(1))) char *gwptr;
+    gwptr Jout_b = (gwptr)Jout, idx_b = (gwptr)idx_out;
     __builtin_amdgcn_wave_barrier();
 
     // the axis-0 lerp of one corner row from the value(s) a lane loaded

@@ -650,4 +650,4 @@ def test_cpp_rank_driver_matches_the_python_path(env):
         out = bk.solve(13)
     want = float(out["J"].astype(np.float64).sum())
     assert abs(line["checksum_sum_J"] - want) <= 1e-11 * abs(want), (line["checksum_sum_J"], want)
-    assert abs(line["value"] - 34 ** 4 * 9 * 12 / (line["ms_per_step"] * 12e-3)) <= 1e-5 * line["value"]
+    assert abs(line["value"] - 34 ** 4 * 9 * 12 / (line["ms_per_step"] * 12e-3)) <= 1e-4 * line["value"]      # both are printed rounded
