@@ -340,7 +340,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             if (cst) return cst;
             h->hcs.dpp = (dok && h->cs_dpp) ? 1 : 0;
             colsweep_split(h);
-            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            { const int ust = colsweep_upload(h); if (ust) return ust; }
             choose_launch(h);
         }
         return HJB_OK;
@@ -350,7 +350,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         h->cs_split = (int)value;
         if (h->cs_state == 1) {
             colsweep_split(h);
-            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            { const int ust = colsweep_upload(h); if (ust) return ust; }
             choose_launch(h);
         }
         return HJB_OK;
@@ -359,7 +359,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         h->cs_coop = value != 0;
         if (h->cs_state == 1) {
             h->hcs.coop = h->cs_coop ? h->cs_coop_epl : 0;
-            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            { const int ust = colsweep_upload(h); if (ust) return ust; }
             choose_launch(h);
         }
         return HJB_OK;
@@ -372,7 +372,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             HIP_TRY(h, hipMemcpy(plan.data(), h->hcs.plan, plan.size() * 4, hipMemcpyDeviceToHost));
             const int cst = colsweep_map(h, plan);
             if (cst) return cst;
-            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            { const int ust = colsweep_upload(h); if (ust) return ust; }
             choose_launch(h);
         }
         return HJB_OK;
@@ -385,7 +385,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             HIP_TRY(h, hipMemcpy(plan.data(), h->hcs.plan, plan.size() * 4, hipMemcpyDeviceToHost));
             const int cst = colsweep_map(h, plan);
             if (cst) return cst;
-            HIP_TRY(h, hipMemcpy(h->dcs, &h->hcs, sizeof(DColSweep), hipMemcpyHostToDevice));
+            { const int ust = colsweep_upload(h); if (ust) return ust; }
             choose_launch(h);
         }
         return HJB_OK;

@@ -172,6 +172,7 @@ int rebuild_tables(Handle *h, bool mfma);
 int table_hash(Handle *h, uint64_t *out);
 int ensure_colsweep(Handle *h);
 void colsweep_split(Handle *h);
+int colsweep_upload(Handle *h);      // the device copy of Handle::hcs, launch record included
 int examine_tile2d(Handle *h);
 int launch_tile2d(Handle *h, const void *dJn, void *dJo, void *didx, int K, hipStream_t st);
 void choose_launch(Handle *h);

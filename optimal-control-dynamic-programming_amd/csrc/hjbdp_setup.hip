@@ -1097,6 +1097,50 @@ int colcoop_plan(Handle *h, std::vector<int32_t> &plan, const std::vector<int32_
 // a boundary strip (240 columns) lasts 15 steps instead of 120.  Round 4, whole grids (launches far beyond the wave slots): parts of
 // ~60 steps beat one long column by 1-2 % on every shape tried (120^4: 1 / 2 / 3 parts 1.674 / 1.640 / 1.647 ms; 160 steps: 1.551 /
 // 1.527 / 1.516; 80 steps: equal; profiles/r04_c4_split.log) - so a column is also cut into round(n1 / 60) parts.
+// The device copy of the column-sweep parameters, with the launch record at its head (kernels_colsweep.h CsRec): every
+// scalar a wave reads before it knows its column, copied from the structures that own them.
+int colsweep_upload(Handle *h) {
+    DColSweep &C = h->hcs;
+    const DParams &P = h->hp;
+    const DTabled &T = h->htb;
+    uint32_t *r = C.rec;
+    memset(r, 0, sizeof C.rec);
+    auto put_ptr = [&](int i, const void *p) { const uint64_t v = (uint64_t)(uintptr_t)p; r[i] = (uint32_t)v; r[i + 1] = (uint32_t)(v >> 32); };
+    for (int x = 0; x < 8; ++x) r[kRecXcdCnt + x] = (uint32_t)C.xcd_cnt[x];
+    r[kRecN0] = (uint32_t)P.n[0]; r[kRecN1] = (uint32_t)P.n[1]; r[kRecN2] = (uint32_t)P.n[2]; r[kRecN3] = (uint32_t)P.n[3];
+    r[kRecSplit] = (uint32_t)C.split; r[kRecWin] = (uint32_t)C.xcd_win; r[kRecXStride] = (uint32_t)C.xcd_stride; r[kRecNcu] = (uint32_t)C.ncu;
+    put_ptr(kRecXcdIg, C.xcd_ig); put_ptr(kRecPlan, C.plan);
+    put_ptr(kRecA0Tab, T.ax[0].tab); put_ptr(kRecA1Tab, T.ax[1].tab); put_ptr(kRecStatus, P.status);
+    r[kRecGBytes] = C.g_bytes; r[kRecWBytes] = C.w_bytes; r[kRecS1Bytes] = C.s1_bytes;
+    r[kRecNpreCol] = (uint32_t)C.npre_col; r[kRecNpre] = (uint32_t)P.n_cost_prefix; r[kRecStepUniform] = (uint32_t)C.step_uniform;
+    r[kRecA0S0] = (uint32_t)T.ax[0].sstride[0]; r[kRecA0S2] = (uint32_t)T.ax[0].sstride[2]; r[kRecA0S3] = (uint32_t)T.ax[0].sstride[3];
+    r[kRecA1S1] = (uint32_t)T.ax[1].sstride[1]; r[kRecA1S2] = (uint32_t)T.ax[1].sstride[2]; r[kRecA1S3] = (uint32_t)T.ax[1].sstride[3];
+    r[kRecSlabBegin] = (uint32_t)P.slab_begin; r[kRecHaloLo] = (uint32_t)P.halo_lo;
+    r[kRecJs1] = (uint32_t)P.jstride[1]; r[kRecJs2] = (uint32_t)P.jstride[2]; r[kRecJs3] = (uint32_t)P.jstride[3];
+    r[kRecIndexBase] = (uint32_t)P.index_base; r[kRecIdxBytes] = (uint32_t)P.idx_bytes;
+    // the cost record: up to three column-constant state terms (those before the first that depends on state dim 1) and the one
+    // per-step term of the usual shape; a shape it cannot hold says so (n = -1 never equals npre_col) and the kernel reads DParams
+    uint32_t *c = C.crec;
+    memset(c, 0, sizeof C.crec);
+    const bool holds = !h->cost64 && C.npre_col >= 0 && C.npre_col <= 3;
+    c[kCRecNCol] = holds ? (uint32_t)C.npre_col : (uint32_t)-1;
+    if (holds) {
+        auto put_term = [&](int at, const DTerm &t, int sa, int sb, int sc) {
+            const uint64_t v = (uint64_t)(uintptr_t)t.data;
+            c[at] = (uint32_t)v; c[at + 1] = (uint32_t)(v >> 32);
+            c[at + 2] = (uint32_t)t.stride[sa]; c[at + 3] = (uint32_t)t.stride[sb]; c[at + 4] = (uint32_t)t.stride[sc];
+        };
+        for (int j = 0; j < C.npre_col; ++j) put_term(kCRecTerm + 5 * j, P.cost[j], 0, 2, 3);
+        if (C.step_uniform && P.n_cost_prefix - C.npre_col == 1) {
+            c[kCRecHasSu] = 1;
+            put_term(kCRecSu, P.cost[C.npre_col], 1, 2, 3);
+        }
+    }
+    if (!h->dcs) return fail(h, HJB_E_DEVICE, "variant 7 parameters not allocated");
+    HIP_TRY(h, hipMemcpy(h->dcs, &C, sizeof(DColSweep), hipMemcpyHostToDevice));
+    return HJB_OK;
+}
+
 void colsweep_split(Handle *h) {
     const DParams &P = h->hp;
     DColSweep &CSh = h->hcs;
@@ -1196,7 +1240,8 @@ int ensure_colsweep_t(Handle *h) {
     st = dev_alloc(h, sizeof(DColSweep), &d);
     if (st) return st;
     h->dcs = (DColSweep *)d;
-    HIP_TRY(h, hipMemcpy(h->dcs, &CSh, sizeof(DColSweep), hipMemcpyHostToDevice));
+    st = colsweep_upload(h);
+    if (st) return st;
     h->cs_state = 1;
     return HJB_OK;
 }

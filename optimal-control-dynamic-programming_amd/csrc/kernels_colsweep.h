@@ -47,6 +47,7 @@
 // b % 8.  C4 (120^4 x 9, float32): 1.81 ms per stage = 1.03e12 backups/s.  Same values, same arithmetic as every
 // other variant: bit-identical results.
 #pragma once
+#include <cstddef>
 #include "hjbdp_dev.h"
 #include "kernels_generic.h"
 #include "kernels_tabled.h"
@@ -90,7 +91,28 @@ constexpr int kCsSlots = kCsGMax * kCsMMax;
 constexpr int kCsPlanWords = kCsPI + 8 * kCsSlots;
 static_assert(1 + 3 * kCsGMax <= kCsPI && kCsPI % 4 == 0, "plan header; the slots are read as 16-byte vectors");
 
+// Every scalar a wave needs before it knows its column, as ONE record of 48 words at the head of DColSweep: the kernel reads
+// it with three s_load_dwordx16 and one wait (k_backup_colsweep, "hop 1").  Filled on the host from DParams / DTabled /
+// DColSweep themselves (hjbdp_setup.hip::colsweep_upload) - a copy for speed, never a second source of truth.
+enum CsRec {
+    kRecXcdCnt = 0,                                   // [8]
+    kRecN0 = 8, kRecN1, kRecN2, kRecN3,
+    kRecSplit = 12, kRecWin, kRecXStride, kRecNcu,
+    kRecXcdIg = 16,                                   // pointer (2 words)
+    kRecPlan = 18,                                    // pointer
+    kRecA0Tab = 20, kRecA1Tab = 22, kRecStatus = 24,  // pointers
+    kRecGBytes = 26, kRecWBytes, kRecS1Bytes,
+    kRecNpreCol = 29, kRecNpre, kRecStepUniform,
+    kRecA0S0 = 32, kRecA0S2, kRecA0S3, kRecA1S1, kRecA1S2, kRecA1S3,
+    kRecSlabBegin = 38, kRecHaloLo, kRecJs1, kRecJs2, kRecJs3, kRecIndexBase, kRecIdxBytes,
+    kRecWords = 48
+};
+// ... and the cost terms a column reads before its first step, for the usual shapes: up to three column-constant state terms
+// and the one per-step term, each {data pointer, three strides}: 24 words read beside the plan header ("hop 3").
+enum CsCostRec { kCRecNCol = 0, kCRecHasSu = 1, kCRecTerm = 2 /* 5 words each x 3 */, kCRecSu = 17 /* 5 words */, kCRecWords = 24 };
 struct DColSweep {
+    alignas(64) uint32_t rec[kRecWords];
+    uint32_t crec[kCRecWords];
     const int32_t *plan;
     int32_t gax;            // group axis: 2 or 3 (the other one is the window axis)
     int32_t ng;             // groups per plan (maximum over the plans)
@@ -320,56 +342,107 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     __shared__ uint8_t s_idx[4][HJB_CS_DIRECT ? 1 : kCsFlush][HJB_CS_DIRECT ? 1 : 64];      // control numbers (< kCsUMax) as bytes: more steps per flush
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int n0 = P->n[0], n1 = P->n[1], n2 = P->n[2], n3 = P->n[3];
+    // ---- hop 1: EVERY scalar of the launch in one batch ------------------------------------------------------------------
+    // A wave's set-up is a chain of dependent loads - launch scalars -> which column -> the column's plan, table entries and cost
+    // terms -> its first rows - and on a small grid, a multi-GPU strip or a short part of a column that chain IS the stage time.
+    // Read where they were used through P / TB / CS, the scalars cost a round trip to the scalar cache EACH (seventeen waits before
+    // the first gather in the round-4 assembly; hipcc sinks a scalar load to its use whatever the source order).  Here: the record
+    // at the head of DColSweep, three loads and ONE wait, by hand.
+    typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+    u16v rA, rB, rC;
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx16 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(rA), "=s"(rB), "=s"(rC) : "s"(CS) : "memory");
+#define CS_REC(i) ((i) < 16 ? rA[(i) & 15] : ((i) < 32 ? rB[(i) & 15] : rC[(i) & 15]))
+#define CS_REC_PTR(TY, i) ((TY)(uintptr_t)((uint64_t)CS_REC(i) | ((uint64_t)CS_REC((i) + 1) << 32)))
+    const int n0 = (int)CS_REC(kRecN0), n1 = (int)CS_REC(kRecN1), n2 = (int)CS_REC(kRecN2), n3 = (int)CS_REC(kRecN3);
+    const unsigned xcd = blockIdx.x & 7u;
+    unsigned cnt = rA[0];
+#pragma unroll
+    for (int x = 1; x < 8; ++x) cnt = xcd == (unsigned)x ? rA[x] : cnt;
+    const int cs_split = (int)CS_REC(kRecSplit), cs_win = (int)CS_REC(kRecWin), cs_xstride = (int)CS_REC(kRecXStride);
+    cptr<int32_t> xcd_tab = as_const<int32_t>(CS_REC_PTR(const int32_t *, kRecXcdIg));
+    const int32_t *const plan_base = CS_REC_PTR(const int32_t *, kRecPlan);
+    const uint32_t g_bytes = CS_REC(kRecGBytes), w_bytes = CS_REC(kRecWBytes), s1_bytes = CS_REC(kRecS1Bytes);
+    const int ncu = (int)CS_REC(kRecNcu), npre_col = (int)CS_REC(kRecNpreCol), npre = (int)CS_REC(kRecNpre);
+    const bool step_uniform = CS_REC(kRecStepUniform) != 0;
+    const void *const a0_tab = CS_REC_PTR(const void *, kRecA0Tab), *const a1_tab = CS_REC_PTR(const void *, kRecA1Tab);
+    const int a0_s0 = (int)CS_REC(kRecA0S0), a0_s2 = (int)CS_REC(kRecA0S2), a0_s3 = (int)CS_REC(kRecA0S3);
+    const int a1_s = (int)CS_REC(kRecA1S1), a1_s2 = (int)CS_REC(kRecA1S2), a1_s3 = (int)CS_REC(kRecA1S3);
+    int32_t *const status = CS_REC_PTR(int32_t *, kRecStatus);
+    const int slab_begin = (int)CS_REC(kRecSlabBegin), halo_lo_p = (int)CS_REC(kRecHaloLo);
+    const uint32_t js1 = CS_REC(kRecJs1), js2 = CS_REC(kRecJs2), js3 = CS_REC(kRecJs3);
+    const int index_base = (int)CS_REC(kRecIndexBase), idx_bytes = (int)CS_REC(kRecIdxBytes);
+#undef CS_REC_PTR
+#undef CS_REC
     const int chunks = (n0 + LANES - 1) / LANES;
-    // ---- which column (see DColSweep::xcd_ig) --------------------------------------------------------------
+    // ---- hop 2: which column (see DColSweep::xcd_ig) - branch-free, one table look-up ------------------------------------
     int i2, i3, chunk, part;
     {
-        const unsigned xcd = blockIdx.x & 7u;
         unsigned item = (blockIdx.x >> 3) * 4u + (unsigned)wave;
-        const unsigned cnt = (unsigned)CS->xcd_cnt[xcd];
-        const unsigned nfull = (unsigned)((GAX == 3) != (CS->xcd_win != 0) ? n2 : n3);   // the axis every XCD walks in full
+        const bool win = cs_win != 0;
+        const unsigned nfull = (unsigned)((GAX == 3) != win ? n2 : n3);      // the axis every XCD walks in full
         const unsigned per_part = cnt * (unsigned)chunks * nfull;
-        if (item >= per_part * (unsigned)CS->split) return;                   // uniform over the wave
+        if (item >= per_part * (unsigned)cs_split) return;                    // uniform over the wave
         part = (int)(item / per_part);                                        // which part of the column (outermost)
         item -= (unsigned)part * per_part;
-        int ig, iw;
-        if (CS->xcd_win) {               // the XCD owns window-axis indices: the group axis is walked in full, fastest
-            const unsigned ngx = (unsigned)(GAX == 3 ? n3 : n2);
-            ig = (int)(item % ngx);
-            const unsigned r = item / ngx;
-            chunk = (int)(r % (unsigned)chunks);
-            iw = as_const<int32_t>(CS->xcd_ig)[xcd * (unsigned)CS->xcd_stride + r / (unsigned)chunks];
-        } else {
-            const unsigned r = item / cnt;
-            ig = as_const<int32_t>(CS->xcd_ig)[xcd * (unsigned)CS->xcd_stride + item % cnt];
-            chunk = (int)(r % (unsigned)chunks);
-            iw = (int)(r / (unsigned)chunks);
-        }
+        // win: the XCD owns window-axis indices, the group axis is walked in full, fastest; else it owns group-axis indices
+        const unsigned fast = win ? (unsigned)(GAX == 3 ? n3 : n2) : cnt;      // extent of the fastest index
+        const unsigned lo = item % fast, r = item / fast;
+        chunk = (int)(r % (unsigned)chunks);
+        const unsigned hi = r / (unsigned)chunks;
+        const int look = xcd_tab[xcd * (unsigned)cs_xstride + (win ? hi : lo)];
+        const int ig = win ? (int)lo : look, iw = win ? look : (int)hi;
         i2 = GAX == 3 ? iw : ig;
         i3 = GAX == 3 ? ig : iw;
     }
     int i0 = chunk * LANES + lane;
     bool valid = lane < LANES && i0 < n0;                   // this lane carries a state (see the one-load form below)
     if (!valid) i0 = n0 - 1;                                // halo / tail lanes: duplicate work, no store
-    // ---- the plan of this column: header words in scalar registers, member slots parked in LDS ------------
-    cptr<int32_t> pl = as_const<int32_t>(CS->plan) + (size_t)(i2 + n2 * i3) * kCsPlanWords;
+    // ---- hop 3: everything that hangs on (i2, i3), asked for together: the plan's member slots (-> LDS) and this lane's axis-0
+    // entry (vector loads, in flight across the scalar wait), then the plan's header words and the first axis-1 entry (scalar,
+    // one batch by hand) ------------------------------------------------------------------------------------------------
+    cptr<int32_t> pl = as_const<int32_t>(plan_base) + (size_t)(i2 + n2 * i3) * kCsPlanWords;
+    f4 slot_v[(NG * MM * 2 + 63) / 64];
     {
-        gptr<f4> src = as_global<f4>(CS->plan + (size_t)(i2 + n2 * i3) * kCsPlanWords + kCsPI);
+        gptr<f4> src = as_global<f4>(plan_base + (size_t)(i2 + n2 * i3) * kCsPlanWords + kCsPI);
 #pragma unroll
-        for (int e = lane; e < NG * MM * 2; e += 64) s_slots[wave][e] = src[e];
+        for (int j = 0; j < (NG * MM * 2 + 63) / 64; ++j)
+            if (lane + 64 * j < NG * MM * 2) slot_v[j] = src[lane + 64 * j];
     }
-    const int ng = pl[0] >> 8;                               // groups of this column (<= NG)
-    if ((pl[0] & 1) && lane == 0) *P->status = 1;
-    const uint32_t g_bytes = CS->g_bytes, w_bytes = CS->w_bytes, s1_bytes = CS->s1_bytes;
+    TabEntry<T> e0v;
+    {
+        const int off = a0_s0 * i0 + a0_s2 * i2 + a0_s3 * i3;
+        e0v.cell = as_global<TabEntry<T>>(a0_tab)[off].cell;
+        e0v.t = as_global<TabEntry<T>>(a0_tab)[off].t;
+    }
+    const int a1_base = a1_s2 * i2 + a1_s3 * i3;
+    cptr<TabEntry<T>> tab1 = as_const<TabEntry<T>>(a1_tab) + a1_base;
+    const int i1b = (int)((int64_t)n1 * part / cs_split), i1e = (int)((int64_t)n1 * (part + 1) / cs_split);   // this wave's steps
+    cptr<TabEntry<T>> tab1n = tab1 + i1b * a1_s;             // entry of the next step
+    u16v hdr, cr0;
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+    u2v ent1;
+    u8v cr1;
+    static_assert(1 + 2 * kCsGMax <= 16 && sizeof(TabEntry<T>) == 8, "plan header in one s_load_dwordx16, a table entry in one dwordx2");
+    static_assert(offsetof(DColSweep, crec) == 192 && kCRecWords == 24, "the cost record follows the launch record");
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\ts_load_dwordx16 %2, %6, 0xc0\n\ts_load_dwordx8 %3, %6, 0x100\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=s"(hdr), "=s"(ent1), "=s"(cr0), "=s"(cr1) : "s"(pl), "s"(tab1n), "s"(CS) : "memory");
+#define CS_CREC(i) ((i) < 16 ? cr0[(i) & 15] : cr1[((i) - 16) & 7])
+    int c1n = (int)ent1.x;
+    T t1n = __uint_as_float(ent1.y);
+#pragma unroll
+    for (int j = 0; j < (NG * MM * 2 + 63) / 64; ++j)
+        if (lane + 64 * j < NG * MM * 2) s_slots[wave][lane + 64 * j] = slot_v[j];
+    const int ng = (int)hdr[0] >> 8;                         // groups of this column (<= NG)
+    if ((hdr[0] & 1) && lane == 0) *status = 1;
     // ---- axis 0: the thread's own (cell, t) for the whole column ------------------------------------------
     uint32_t voff0;
     T t0;
     {
-        const DTabled::Axis &A0 = TB->ax[0];
-        const int off = A0.sstride[0] * i0 + A0.sstride[2] * i2 + A0.sstride[3] * i3;
-        const int c0 = as_global<TabEntry<T>>(A0.tab)[off].cell;
-        t0 = as_global<TabEntry<T>>(A0.tab)[off].t;
+        const int c0 = e0v.cell;
+        t0 = e0v.t;
         if (DPP) {
             // rel = cell - state index takes at most two adjacent values over the wave's states (verified on the host).
             // kb = the value most states share: lane L loads knot chunk start + L + kb, a state with rel == kb finds its
@@ -406,20 +479,30 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     int used[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        rog[g] = (uint32_t)pl[1 + g];
-        used[g] = pl[1 + kCsGMax + g];
+        rog[g] = hdr[1 + g];
+        used[g] = (int)hdr[1 + kCsGMax + g];
     }
-    const DTabled::Axis &A1 = TB->ax[1];
-    const int a1_base = A1.sstride[2] * i2 + A1.sstride[3] * i3, a1_s = A1.sstride[1];
-    cptr<TabEntry<T>> tab1 = as_const<TabEntry<T>>(A1.tab) + a1_base;
-    const int ncu = CS->ncu, npre_col = CS->npre_col, npre = P->n_cost_prefix;
-    const bool step_uniform = CS->step_uniform != 0;
     // ---- cost: leading state-only terms that do not change along the column --------------------------------
-    int si[D] = {i0, 0, i2, i3 + P->slab_begin};
+    int si[D] = {i0, 0, i2, i3 + slab_begin};
     const int cjz[HJB_MAX_C] = {0, 0, 0};
     T gcol = (T)0;
     double gcol64 = 0.0;                          // C64: the column-constant state terms of the cost in double
-    if constexpr (C64) {
+    const bool rec_cost = !C64 && (int)CS_CREC(kCRecNCol) == npre_col;      // every column term is in the record (<= 3)
+    if (rec_cost) {
+        // their values requested together (the descriptors came with the plan header), then the ordered sum
+        T x[3] = {(T)0, (T)0, (T)0};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < npre_col) {
+                const T *d = (const T *)(uintptr_t)((uint64_t)CS_CREC(kCRecTerm + 5 * j) | ((uint64_t)CS_CREC(kCRecTerm + 5 * j + 1) << 32));
+                const int64_t off = (int64_t)(int)CS_CREC(kCRecTerm + 5 * j + 2) * si[0] + (int64_t)(int)CS_CREC(kCRecTerm + 5 * j + 3) * si[2] +
+                                    (int64_t)(int)CS_CREC(kCRecTerm + 5 * j + 4) * si[3];
+                x[j] = as_global<T>(d)[off];
+            }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < npre_col) gcol = (j == 0) ? x[j] : (T)(gcol + x[j]);
+    } else if constexpr (C64) {
         for (int k = 0; k < npre_col; ++k) {
             const double x = term_value<double, D>(P->cost64[k], si, cjz);
             gcol64 = (k == 0) ? x : gcol64 + x;
@@ -443,10 +526,8 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         asm volatile("" : "+s"(Jb01));
         asm volatile("" : "+s"(Jb11));
     }
-    const uint32_t out_col = (uint32_t)i0 + (uint32_t)P->jstride[2] * (uint32_t)i2 + (uint32_t)P->jstride[3] * (uint32_t)(i3 + P->halo_lo);
+    const uint32_t out_col = (uint32_t)i0 + js2 * (uint32_t)i2 + js3 * (uint32_t)(i3 + halo_lo_p);
     const uint32_t idx_col = (uint32_t)i0 + (uint32_t)n0 * (uint32_t)n1 * ((uint32_t)i2 + (uint32_t)n2 * (uint32_t)i3);
-    const uint32_t js1 = (uint32_t)P->jstride[1];
-    const int index_base = P->index_base, idx_bytes = P->idx_bytes;
     // HJB_CS_DIRECT: per-lane byte offsets of the column's results (J < 4 GiB in this kernel: every gather offset is 32-bit too)
     const uint32_t out_off = out_col * (uint32_t)sizeof(TJ), idx_off = idx_col * (uint32_t)idx_bytes;
     typedef __attribute__((address_space(1))) char *gwptr;
@@ -573,20 +654,24 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
             }
         }
     };
-    // the per-step cost term of the usual shape: its descriptor is read once, not once per step
+    // the per-step cost term of the usual shape: its descriptor is read once (from the cost record), not once per step
     const bool one_su = step_uniform && npre - npre_col == 1;
-    cptr<T> su_ptr = as_const<T>(P->cost[one_su ? npre_col : 0].data);
+    cptr<T> su_ptr;
     int su_s1 = 0;
-    if (one_su) {
-        const DTerm &tm = P->cost[npre_col];
-        su_ptr += tm.stride[2] * i2 + tm.stride[3] * si[3];
-        su_s1 = tm.stride[1];
+    if (CS_CREC(kCRecHasSu) != 0 && one_su && !C64) {
+        su_ptr = as_const<T>((const T *)(uintptr_t)((uint64_t)CS_CREC(kCRecSu) | ((uint64_t)CS_CREC(kCRecSu + 1) << 32))) +
+                 ((int)CS_CREC(kCRecSu + 3) * i2 + (int)CS_CREC(kCRecSu + 4) * si[3]);
+        su_s1 = (int)CS_CREC(kCRecSu + 2);
+    } else {
+        su_ptr = as_const<T>(P->cost[one_su ? npre_col : 0].data);
+        if (one_su) {
+            const DTerm &tm = P->cost[npre_col];
+            su_ptr += tm.stride[2] * i2 + tm.stride[3] * si[3];
+            su_s1 = tm.stride[1];
+        }
     }
+#undef CS_CREC
     int prev_c1 = -2;
-    const int i1b = (int)((int64_t)n1 * part / CS->split), i1e = (int)((int64_t)n1 * (part + 1) / CS->split);   // this wave's steps
-    cptr<TabEntry<T>> tab1n = tab1 + i1b * a1_s;             // entry of the next step
-    int c1n = tab1n[0].cell;
-    T t1n = tab1n[0].t;
     // Everything hipcc loaded for the set-up has landed before the loop starts: a value still "pending" at the loop
     // header would make its first use INSIDE the loop a `vmcnt(0)` on every step - a drain of the gathers in flight.
     __builtin_amdgcn_s_waitcnt(0x0F70);

@@ -94,10 +94,10 @@ def test_gathers_in_flight_are_never_touched(cs_asm):
     assert len(bodies) == 4, list(bodies)
     for name, lines in bodies.items():
         _check_gathers(name, lines)
-    # the checker itself: a copy of a gather's destination planted right behind the gather must be caught
+    # the checker itself: a copy of a gather's destination planted right behind a step gather must be caught
     name, lines = next(iter(bodies.items()))
-    at = next(i for i, ln in enumerate(lines) if i > next(j for j, l in enumerate(lines) if "s_barrier" in l)
-              and re.search(r"global_load_dword\s+v\d+,", ln) and ";;#ASMSTART" in lines[i - 1])
+    bar = next(j for j, l in enumerate(lines) if "s_barrier" in l)
+    at = next(i for i, ln in enumerate(lines) if i > bar and re.search(r"global_load_dword\s+v\d+,", ln) and ";;#ASMSTART" in lines[i - 1])
     reg = re.search(r"global_load_dword\s+v(\d+),", lines[at]).group(1)
     end = next(i for i in range(at, len(lines)) if ";;#ASMEND" in lines[i])
     planted = lines[:end + 1] + ["\tv_mov_b32_e32 v200, v%s" % reg] + lines[end + 1:]
@@ -106,59 +106,81 @@ def test_gathers_in_flight_are_never_touched(cs_asm):
 
 
 def _check_gathers(name, lines):
-    if True:
-        # the column loop = the depth-1 loop that holds the s_barrier: its header block, then every block the assembler
-        # annotates as inside it, in file order, the blocks laid out before the header (the latch) last
-        bar = next(i for i, ln in enumerate(lines) if "s_barrier" in ln)
-        hdr = max(i for i in range(bar) if re.match(r"^\.LBB\d+_\d+:.*Loop Header: Depth=1", lines[i]))
-        tag = "BB" + lines[hdr].split(":")[0][len(".LBB"):]
-        member, inside = [], False
-        for i, ln in enumerate(lines):
-            if re.match(r"^\.LBB\d+_\d+:", ln) or re.match(r"^; %bb\.\d+:", ln):
-                inside = i == hdr or ("Header=%s " % tag) in ln + " " or ("Parent Loop %s " % tag) in ln + " "
-            member.append(inside)
-        after = [lines[i] for i in range(hdr, len(lines)) if member[i]]
-        before = [lines[i] for i in range(hdr) if member[i]]
-        body = after + before
-        assert any("s_barrier" in ln for ln in body) and len(body) > 500
-        in_asm, tagged = False, []
-        for ln in body:
-            if ";;#ASMSTART" in ln:
-                in_asm = True
-                continue
-            if ";;#ASMEND" in ln:
-                in_asm = False
-                continue
-            tagged.append((in_asm, ln))
-        gathers = [(i, int(re.search(r"global_load_(?:dword|ushort)\s+v(\d+),", ln).group(1)))
-                   for i, (a, ln) in enumerate(tagged) if a and re.search(r"global_load_(?:dword|ushort)\s+v\d+,", ln)]
-        n_groups = 5 if "Li5E" in name else 4
-        assert len(gathers) == n_groups * 3 * 2, (name, len(gathers))      # rows of one step, each gathered by ONE load
-        n = len(tagged)
-
-        def is_wait(i):
-            a, ln = tagged[i]
-            if a and "s_setpc_b64" in ln:                 # the computed jump into the table of counted waits: one wait
-                return True
-            return (not a) and re.search(r"s_waitcnt\s+vmcnt\(0\)", ln) is not None and False
-        drains = {i for i, (a, ln) in enumerate(tagged) if not a and re.search(r"s_waitcnt\s+vmcnt\(0\)\s*$", ln.split(";")[0].rstrip())}
-        for pos, reg in gathers:
-            waits = 0
-            for k in range(1, n + 1):
-                i = (pos + k) % n
-                if i in drains:
+    """Control-flow walk (not file order: hipcc lays blocks of the loop out of line).  From every hand-issued gather follow
+    every path - fall-through, s_branch, both sides of an s_cbranch - until the gather is retired: the SECOND counted wait
+    (a computed jump into a table of s_waitcnt: the asm block with s_setpc_b64) or a full drain (`s_waitcnt vmcnt(0)` the
+    compiler wrote, or the kernel's own one-instruction asm drain behind the (re-)prime's gathers).  No instruction on the way
+    may name the gather's destination register."""
+    ins = []                       # (text, in_asm, asm_block_id)
+    label_at = {}
+    in_asm, blk = False, -1
+    loop_headers = []              # instruction index behind every depth-1 loop header label
+    for ln in lines:
+        if re.match(r"^\.LBB\d+_\d+:.*Loop Header: Depth=1", ln):
+            loop_headers.append(len(ins))
+        if ";;#ASMSTART" in ln:
+            in_asm, blk = True, blk + 1
+            continue
+        if ";;#ASMEND" in ln:
+            in_asm = False
+            continue
+        code = ln.split(";")[0].rstrip()
+        m = re.match(r"^(\.L[A-Za-z0-9_]+):", code)
+        if m:
+            label_at[m.group(1)] = len(ins)
+            continue
+        if not code.strip() or code.strip().startswith("."):
+            continue
+        ins.append((code.strip(), in_asm, blk if in_asm else -1))
+    n = len(ins)
+    blocks = {}
+    for i, (c, a, b) in enumerate(ins):
+        if a:
+            blocks.setdefault(b, []).append(i)
+    asm_drain = {idx[0] for idx in blocks.values() if len(idx) == 1 and re.fullmatch(r"s_waitcnt\s+vmcnt\(0\)", ins[idx[0]][0])}
+    wait_jump_end = {}             # index of the s_setpc_b64 of a counted wait -> first instruction behind its asm block
+    for idx in blocks.values():
+        for i in idx:
+            if ins[i][0].startswith("s_setpc_b64"):
+                wait_jump_end[i] = idx[-1] + 1
+    bar = next(i for i, (c, a, b) in enumerate(ins) if c.startswith("s_barrier"))
+    hdr = max(h for h in loop_headers if h <= bar)            # the column loop = the depth-1 loop that holds the s_barrier
+    # (the prologue's gathers, before the loop, are retired by the FIRST wait and are not walked here)
+    gathers = [(i, int(re.search(r"global_load_(?:dword|ushort)\s+v(\d+),", c).group(1))) for i, (c, a, b) in enumerate(ins)
+               if a and i >= hdr and re.search(r"global_load_(?:dword|ushort)\s+v\d+,", c)]
+    n_groups = 5 if "Li5E" in name else 4
+    # per step each row is gathered by ONE load; as many again in the (re-)prime block (round 5: all requested before one drain)
+    assert len(gathers) == 2 * n_groups * 3 * 2, (name, len(gathers))
+    for pos, reg in gathers:
+        seen, todo = set(), [(pos + 1, 0)]
+        while todo:
+            i, waits = todo.pop()
+            while True:
+                if i >= n or (i, waits) in seen:
+                    break
+                seen.add((i, waits))
+                c, a, b = ins[i]
+                if c.startswith("s_endpgm"):
+                    break
+                if i in asm_drain or (not a and re.fullmatch(r"s_waitcnt\s+vmcnt\(0\)(\s+lgkmcnt\(\d+\))?", c)):
                     break                                   # a full drain: everything has landed
-                if is_wait(i):
+                if i in wait_jump_end:
                     waits += 1
                     if waits == 2:
                         break
+                    i = wait_jump_end[i]
                     continue
-                a, ln = tagged[i]
-                if a and re.search(r"s_waitcnt\s+vmcnt", ln):
-                    continue                                # an entry of the wait table
-                assert not _mentions(ln, reg), "%s: v%d is named while its gather is in flight: %s" % (name, reg, ln.strip())
-            else:
-                raise AssertionError("%s: no retiring wait found after the gather into v%d" % (name, reg))
+                if not (a and re.match(r"s_(waitcnt|branch|getpc|add_u32|addc_u32)", c)):
+                    assert not _mentions(c, reg), "%s: v%d is named while its gather is in flight: %s" % (name, reg, c)
+                m = re.match(r"s_branch\s+(\S+)", c)
+                if m and not a:
+                    i = label_at[m.group(1)]
+                    continue
+                m = re.match(r"s_cbranch_\w+\s+(\S+)", c)
+                if m and not a:
+                    todo.append((label_at[m.group(1)], waits))
+                i += 1
+        assert seen, name
 
 
 def test_packed2_occupancy_budgets():
