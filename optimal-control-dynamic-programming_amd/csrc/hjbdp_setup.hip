@@ -286,6 +286,17 @@ int build(Handle *h, const hjb_problem *p) {
     {
         DNested &N = h->hn;
         memset(&N, 0, sizeof N);
+        // division by a launch constant as multiply-high + shifts (Granlund - Montgomery, exact for every 32-bit numerator)
+        auto magic = [](int64_t dd, uint32_t *m, int32_t *sh) {
+            if (dd <= 1 || dd >= ((int64_t)1 << 31)) { *m = 0; *sh = -1; return; }      // 1: q = r; >= 2^31: the 64-bit-index modes do not use it
+            const uint64_t d = (uint64_t)dd;
+            int l = 0;
+            while (((uint64_t)1 << l) < d) ++l;
+            *m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+            *sh = l - 1;
+        };
+        for (int a = 0; a < D; ++a) magic(P.n[a], &N.div_m[a], &N.div_s[a]);
+        magic(P.inner, &N.div_m_inner, &N.div_s_inner);
         const uint32_t in_bit = 1u << (D + C - 1);
         bool ok = !h->tab64;          // variants 1-4 evaluate next-state terms in the kernel, in the problem dtype
         for (int a = 0; a < D - 1 && ok; ++a)
@@ -326,6 +337,7 @@ int build(Handle *h, const hjb_problem *p) {
         // loop levels (see DNested): o1 runs over control dim C-2, o0 over control dim 0 when C == 3
         N.m_o0 = (C == 3) ? p->m[0] : 1;
         N.m_o1 = (C >= 2) ? p->m[C - 2] : 1;
+        magic(N.m_o1, &N.div_m_o1, &N.div_s_o1);
         const uint32_t o1_bit = (C >= 2) ? (1u << (D + C - 2)) : 0u;
         for (int a = 0; a < D; ++a) {
             const DAxis &ax = P.axis[a];

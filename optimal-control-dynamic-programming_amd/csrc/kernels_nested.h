@@ -33,6 +33,12 @@ struct DInnerTerm {
     int32_t lds_slot;     // >= 0: control-only table staged in LDS slot; -1: general
 };
 
+// q = r / d for a divisor the host prepared (Granlund - Montgomery, exact for every 32-bit r): see DNested::div_m
+__device__ __forceinline__ uint32_t udiv_gm(uint32_t r, uint32_t m, int s) {
+    if (s < 0) return r;
+    const uint32_t t = __umulhi(r, m);
+    return (t + ((r - t) >> 1)) >> s;
+}
 struct DNested {
     int32_t m_in;         // size of the innermost control dim
     int32_t nUo;          // product of the outer control dims
@@ -48,6 +54,13 @@ struct DNested {
     int32_t ax_l0[HJB_MAX_D];   // per axis (last axis: end bounded by ax_kin)
     int32_t cost_l0;
     int32_t chunk_order;  // variant 4, window modes: 0 = chunks visited in the transposed order (kernels_packed2.h), 1 = in state order
+    // division of a 32-bit state index by the grid sizes n[a] without per-kernel reciprocals (variant 4: the compiler's own
+    // expansion keeps one magic number per divisor in a VECTOR register for the whole kernel - and spilled them at five waves):
+    // q = (t + ((r - t) >> 1)) >> div_s[a] with t = mulhi(r, div_m[a])  (n[a] == 1: div_m = 0, div_s = 0 gives q = r >> 0 ... see div_by)
+    uint32_t div_m[HJB_MAX_D];
+    int32_t div_s[HJB_MAX_D];      // -1: divisor 1
+    uint32_t div_m_o1, div_m_inner;      // the same for m_o1 (outer control step -> (o0, o1)) and for the states per plane of the last axis
+    int32_t div_s_o1, div_s_inner;
     DInnerTerm in[kMaxInner];  // [0,n_ax_in): last-axis terms, [kMaxInAx, kMaxInAx+n_cost_in): cost
     // Variant 2 (packed) only: the canonical shape has at most ONE non-prefix,
     // non-inner term per axis and one cost term per outer level.  ot[a] (a < D):

@@ -184,6 +184,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
     constexpr int NP = PRE ? D - 3 : 0;
     using sidx_t = typename std::conditional<QMODEL, int64_t, int>::type;   // linear state index
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    // The C2 modes (five waves per SIMD = 96 registers) park per-state values that are read once per o0 step in LDS, by hand:
+    // left to the compiler they went to scratch (round 4: 67 MB of spill traffic per C2 stage).  No forwarding of
+    // the stored value, which would keep it in its register (a compiler barrier behind the store: a volatile access would turn
+    // into a flat store with system scope).
+    __shared__ int s_park[M1 ? 2 : 1][M1 ? 256 : 1];
     const DAxis &axl = P->axis[D - 1];
     const int nl = axl.n;
     const int m_in = N->m_in;
@@ -261,6 +266,16 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         a_c1[a] = N->at[a].c1;
         a_lvl_rt[a] = N->at[a].level;
     }
+    // an entry of axis a's table by ELEMENT index: a 32-bit byte offset against the table's scalar base (tables are < 4 GiB; a
+    // per-lane 64-bit pointer held across the control loops was the last register pair the C2 modes kept in scratch)
+    auto at_ld = [&](int a, int elem) __attribute__((always_inline)) -> i2v {
+        return *reinterpret_cast<gptr<i2v>>(reinterpret_cast<gptr<char>>(atab[a]) + (uint32_t)elem * 8u);
+    };
+    // axis a's per-state table offset: from LDS in the C2 modes (see s_park), else the register
+    auto aoff_of = [&](int a, const int (&aoff_r)[DM]) __attribute__((always_inline)) -> int {
+        if constexpr (M1) return a < 2 ? s_park[a][threadIdx.x] : aoff_r[a];
+        else return aoff_r[a];
+    };
     // the level of axis a's table: in modes 2 and 3 the host has checked the pattern (axis D-3 level 0, axis D-2 level 1, every
     // axis before them state-only), so it is a compile-time constant of the unrolled axis loops (24^6: 166 -> 118 scalar
     // registers spilled to vector lanes, 70 fewer lane reads per o0 step); the other modes read it
@@ -337,12 +352,25 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         unsigned int cm = 0u;                 // bit j: the last-axis cell changes at control j
         {
             int si[D];
-            sidx_t r = ls;
+            if constexpr (QMODEL) {               // 64-bit state index (C3)
+                sidx_t r = ls;
 #pragma unroll
-            for (int a = 0; a < D; ++a) {
-                int na = P->n[a];
-                si[a] = (int)(r % na);
-                r /= na;
+                for (int a = 0; a < D; ++a) {
+                    int na = P->n[a];
+                    si[a] = (int)(r % na);
+                    r /= na;
+                }
+            } else {
+                // 32-bit index: division by the grid sizes with the host's multipliers (DNested::div_m): the compiler's expansion of
+                // `r / n[a]` keeps a reciprocal per divisor in a vector register for the whole kernel (uniform values computed on the
+                // vector unit) - five of the eleven registers the C2 modes spilled at five waves per SIMD
+                uint32_t r = (uint32_t)ls;
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const uint32_t q = udiv_gm(r, N->div_m[a], N->div_s[a]);
+                    si[a] = (int)(r - q * (uint32_t)P->n[a]);
+                    r = q;
+                }
             }
             const int last_local = si[D - 1];
             si[D - 1] += P->slab_begin;
@@ -377,8 +405,14 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
                 for (int d = 0; d < D; ++d) off += N->at[a].sstride[d] * (d == D - 1 ? last_local : si[d]);
                 aoff[a] = off;
+                if constexpr (M1) {
+                    if (a < 2) {
+                        s_park[a][threadIdx.x] = off;
+                        asm volatile("" ::: "memory");         // no forwarding of the stored value to the reads below
+                    }
+                }
                 if (a_lvl(a) < 0 && !(QMODEL && a < 3)) {
-                    const i2v e = atab[a][off];
+                    const i2v e = at_ld(a, off);
                     cell[a] = e.x;
                     tw[a] = __int_as_float(e.y);
                 }
@@ -452,16 +486,17 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         const int qa = lc0 - pl0, qb = lc1 - pl0;
         const bool far_cells = W3P && (qa > 1 || qb > 1);
         // smallest cell over `cnt` table entries `step` apart: four independent loads in flight per trip
-        auto min_cell = [&](gptr<i2v> tb, int cnt, int step) {
+        auto min_cell = [&](int a, int e0, int cnt, int step) {
             int cm = 0x7fffffff, o = 0;
             for (; o + 4 <= cnt; o += 4) {
-                const int x0 = tb[o * step].x, x1 = tb[(o + 1) * step].x, x2 = tb[(o + 2) * step].x, x3 = tb[(o + 3) * step].x;
+                const int x0 = at_ld(a, e0 + o * step).x, x1 = at_ld(a, e0 + (o + 1) * step).x, x2 = at_ld(a, e0 + (o + 2) * step).x,
+                          x3 = at_ld(a, e0 + (o + 3) * step).x;
                 const int lo01 = x0 < x1 ? x0 : x1, lo23 = x2 < x3 ? x2 : x3;
                 const int lo = lo01 < lo23 ? lo01 : lo23;
                 cm = lo < cm ? lo : cm;
             }
             for (; o < cnt; ++o) {
-                const int x = tb[o * step].x;
+                const int x = at_ld(a, e0 + o * step).x;
                 cm = x < cm ? x : cm;
             }
             return cm;
@@ -470,14 +505,14 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         const bool b_o0dep = HIER && a_c0[AX_B] != 0;
         int cAmin = 0, cBmin = 0;
         if constexpr (HIER) {
-            if (!b_o0dep) cBmin = min_cell(atab[AX_B] + aoff[AX_B], m_o1, a_c1[AX_B]);
+            if (!b_o0dep) cBmin = min_cell(AX_B, aoff_of(AX_B, aoff), m_o1, a_c1[AX_B]);
         }
         if constexpr (PRE) {
-            const int ca = min_cell(atab[AX_A] + aoff[AX_A], m_o0, a_c0[AX_A]);
+            const int ca = min_cell(AX_A, aoff_of(AX_A, aoff), m_o0, a_c0[AX_A]);
             if (b_o0dep) {
                 int cbm = 0x7fffffff;
                 for (int o0 = 0; o0 < m_o0; ++o0) {
-                    const int c2 = min_cell(atab[AX_B] + aoff[AX_B] + o0 * a_c0[AX_B], m_o1, a_c1[AX_B]);
+                    const int c2 = min_cell(AX_B, aoff_of(AX_B, aoff) + o0 * a_c0[AX_B], m_o1, a_c1[AX_B]);
                     cbm = c2 < cbm ? c2 : cbm;
                 }
                 cBmin = cbm;
@@ -541,7 +576,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         };
 
         i2v l0_nx = {0, 0};                   // window modes: the level-0 axis' entry, fetched one o0 step ahead
-        if constexpr (PRE) l0_nx = atab[AX_A][aoff[AX_A]];
+        if constexpr (PRE) l0_nx = at_ld(AX_A, aoff_of(AX_A, aoff));
 #ifndef HJB_K3_PROBE
 #define HJB_K3_PROBE 0
 #endif
@@ -550,7 +585,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             if constexpr (PRE) {
                 cell[AX_A] = l0_nx.x;
                 tw[AX_A] = __int_as_float(l0_nx.y);
-                if (o0 + 1 < m_o0) l0_nx = atab[AX_A][aoff[AX_A] + (o0 + 1) * a_c0[AX_A]];
+                if (o0 + 1 < m_o0) l0_nx = at_ld(AX_A, aoff_of(AX_A, aoff) + (o0 + 1) * a_c0[AX_A]);
             } else {
 #pragma unroll
                 for (int a = 0; a < D - 1; ++a) {
@@ -558,7 +593,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         if (INL0 && a == 0) {
                             axis0_entry(qs0, o0, cell[a], tw[a]);
                         } else {
-                            const i2v e = atab[a][aoff[a] + o0 * a_c0[a]];
+                            const i2v e = at_ld(a, aoff_of(a, aoff) + o0 * a_c0[a]);
                             cell[a] = e.x;
                             tw[a] = __int_as_float(e.y);
                         }
@@ -576,7 +611,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
 #pragma unroll
                 for (int a = 0; a < D - 1; ++a) {
                     if (a_lvl(a) == 1) {
-                        const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + o1 * a_c1[a]];
+                        const i2v e = at_ld(a, aoff_of(a, aoff) + o0 * a_c0[a] + o1 * a_c1[a]);
                         cell[a] = e.x;
                         tw[a] = __int_as_float(e.y);
                     }
@@ -619,7 +654,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         F[rb][q] = __builtin_fmaf(ta, f1 - f0, f0);
                     }
             } else if constexpr (M1) {
-                const int cmin = b_o0dep ? min_cell(atab[1] + aoff[1] + o0 * a_c0[1], m_o1, a_c1[1]) : cBmin;
+                const int cmin = b_o0dep ? min_cell(1, aoff_of(1, aoff) + o0 * a_c0[1], m_o1, a_c1[1]) : cBmin;
                 c1min = cmin;
                 const int n1 = P->axis[1].n;
                 const int rows[3] = {cmin, cmin + 1, cmin + 2 < n1 ? cmin + 2 : n1 - 1};
@@ -640,8 +675,14 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             }
             // modes 1-3: the level-1 axis' (cell, t) entry and the level-1 cost term are fetched ONE STEP AHEAD
             // (a dependent global load per o1 step would otherwise stall every step)
-            gptr<i2v> tb1 = atab[AX_B] + aoff[AX_B] + o0 * a_c0[AX_B];
-            const int tb1_step = a_c1[AX_B];
+            // the level-1 axis' entries of this o0 step: a 32-bit BYTE offset against the table's scalar base (a per-lane 64-bit
+            // pointer here was one of the register pairs the C2 modes kept in scratch)
+            const uint32_t tb1_off = (uint32_t)(aoff_of(AX_B, aoff) + o0 * a_c0[AX_B]) * 8u;
+            const uint32_t tb1_step = (uint32_t)a_c1[AX_B] * 8u;
+            gptr<char> tb1_base = reinterpret_cast<gptr<char>>(atab[AX_B]);
+            auto tb1_at = [&](uint32_t byte_step) __attribute__((always_inline)) -> i2v {
+                return *reinterpret_cast<gptr<i2v>>(tb1_base + (tb1_off + byte_step));
+            };
             i2v e_nx = {0, 0};
             float g_nx = 0.f;
             // cost so far + the level-1 term; when that term is the first of the sum, -0 + x == x bit for bit (no select per step)
@@ -657,8 +698,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             auto level1_terms2 = [&](int o1) -> f2 { return (f2){l1_row[o1 * l1_step], l1_row[(o1 + 1) * l1_step]}; };
             i2v e_nx2 = {0, 0};                   // ... and the entry after it: a two-step trip consumes two
             if constexpr (HIER) {
-                e_nx = tb1[0];
-                if (m_o1 > 1) e_nx2 = tb1[tb1_step];
+                e_nx = tb1_at(0u);
+                if (m_o1 > 1) e_nx2 = tb1_at(tb1_step);
                 g_nx = level1_cost(0);
             }
             // base offset of the outer axes' cells: modes 1-3 need it on the rare paths only
@@ -733,8 +774,8 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                         }
                         {
                             const int oa = o1 + 2 < o1_last ? o1 + 2 : o1_last, ob = o1 + 3 < o1_last ? o1 + 3 : o1_last;
-                            eA = tb1[oa * tb1_step];
-                            eB = tb1[ob * tb1_step];
+                            eA = tb1_at((uint32_t)oa * tb1_step);
+                            eB = tb1_at((uint32_t)ob * tb1_step);
                         }
                         // The two halves of every packed instruction are the two STEPS (A, B) of one control: the per-step
                         // quantities (cost so far, E0, dE) are register pairs as they come out of the lerps above, the
@@ -889,7 +930,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     tw[AX_B] = __int_as_float(e_nx.y);
                     go = g_nx;
                     if (o1 + 1 < m_o1) {
-                        e_nx = tb1[(o1 + 1) * tb1_step];
+                        e_nx = tb1_at((uint32_t)(o1 + 1) * tb1_step);
                         g_nx = level1_cost(o1 + 1);
                     }
                     const int r = cell[AX_B] - c1min;
@@ -1048,7 +1089,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         // one that reproduces `best` wins (first-minimum rule).  Once per state instead of once per pair and step.
         int best_j = 0;
         {
-            const int o0 = best_uo / m_o1, o1 = best_uo - o0 * m_o1;
+            const int o0 = (int)udiv_gm((uint32_t)best_uo, N->div_m_o1, N->div_s_o1), o1 = best_uo - o0 * m_o1;
             int ob = 0;
 #pragma unroll
             for (int a = 0; a < D - 1; ++a) {
@@ -1056,7 +1097,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
                     if (INL0 && a == 0) {
                         axis0_entry(qs0, o0, cell[a], tw[a]);
                     } else {
-                        const i2v e = atab[a][aoff[a] + o0 * a_c0[a] + (a_lvl(a) == 1 ? o1 * a_c1[a] : 0)];
+                        const i2v e = at_ld(a, aoff_of(a, aoff) + o0 * a_c0[a] + (a_lvl(a) == 1 ? o1 * a_c1[a] : 0));
                         cell[a] = e.x;
                         tw[a] = __int_as_float(e.y);
                     }
@@ -1129,10 +1170,16 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             } else if (C == 2) {
                 label = best_uo + P->m[0] * best_j;
             } else {
-                const int j1 = best_uo % P->m[1], j0 = best_uo / P->m[1];
+                const int j0 = (int)udiv_gm((uint32_t)best_uo, N->div_m_o1, N->div_s_o1), j1 = best_uo - j0 * P->m[1];     // m_o1 == m[1] when C == 3
                 label = j0 + P->m[0] * (j1 + P->m[1] * best_j);
             }
-            const sidx_t in_plane = ls % inner_sz, pl = ls / inner_sz;
+            sidx_t in_plane, pl;
+            if constexpr (QMODEL) {
+                in_plane = ls % inner_sz; pl = ls / inner_sz;
+            } else {
+                pl = (sidx_t)udiv_gm((uint32_t)ls, N->div_m_inner, N->div_s_inner);
+                in_plane = ls - pl * inner_sz;
+            }
             Jout[in_plane + (sidx_t)inner_sz * (pl + P->halo_lo)] = (TJ)best;
             if (idx_out) st_idx(idx_out, ls, label + P->index_base, P->idx_bytes);
         }
