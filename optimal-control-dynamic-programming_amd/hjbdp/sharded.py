@@ -174,6 +174,10 @@ class ShardedSweep:
     def check_device_status(self):
         if getattr(self, "_comm_stream", None) is not None:       # a trailing exchange (post_exchange) may still be in flight
             self.torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+        if self.transport == "lib" and self.world > 1 and self._rank is not None:
+            xs = self._rank.lib.hjb_rank_transfer_stream(self._rank._r)
+            if xs:
+                self._rank.check_device_status(xs)                 # ... on the library's transfer stream: synchronises it
         self._rank.check_device_status(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_terminal(self, J_global=None):
@@ -244,7 +248,13 @@ class ShardedSweep:
         if self._rank is not None and self.transport == "lib" and self.world > 1:
             rk = self._rank
             stream = self.torch.cuda.current_stream(self.device).cuda_stream
-            rk._check(rk.lib.hjb_rank_step(rk._r, J_in.data_ptr(), J_out.data_ptr(), self.idx.data_ptr(), stream))
+            if self.post_exchange:       # strips first, the exchange of J_out's boundary planes behind them (hjb_rank_step_post)
+                if not self._halos_valid:
+                    rk._check(rk.lib.hjb_rank_exchange(rk._r, J_in.data_ptr(), stream))
+                rk._check(rk.lib.hjb_rank_step_post(rk._r, J_in.data_ptr(), J_out.data_ptr(), self.idx.data_ptr(), stream))
+                self._halos_valid = True
+            else:
+                rk._check(rk.lib.hjb_rank_step(rk._r, J_in.data_ptr(), J_out.data_ptr(), self.idx.data_ptr(), stream))
         elif self._rank is None or not self._rank.split:
             self.exchange_halos()
             self.stage_fn(J_in, J_out, self.idx)
