@@ -1169,6 +1169,10 @@ void colsweep_split(Handle *h) {
         // launches below one round of the wave slots (the reference's own 30x30x20x15 grid: 450 columns of 20 steps): parts as short as
         // five steps still pay - 31.3 / 18.7 / 12.8 us per stage in 1 / 2 / 4 parts (profiles/r04_small_grids.log)
         while (S < 8 && waves * S * 2 <= 4096 && n1 / (S * 2) >= 5) S *= 2;
+        // round 5: with the one-round-trip prime and the batched set-up a part costs little to start, and such a launch is ONE wave's
+        // critical path (5.6 us + 1.14 us per step on that grid): as many parts as fit three quarters of the wave slots, two steps
+        // each at least - 17.0 / 11.3 / 10.6 -> 10.0 us per stage in 2 / 4 / 10 parts (profiles/r05_small_grids.log)
+        if (waves * S <= 4608 && n1 >= 4 && n1 <= 40) S = (int)std::max<int64_t>(S, std::min<int64_t>(std::min<int64_t>(n1 / 2, 4608 / std::max<int64_t>(waves, 1)), 16));
         S = std::max(S, std::min(8, (n1 + 30) / 60));
     }
     CSh.split = std::max(1, std::min(S, std::max(1, n1)));
