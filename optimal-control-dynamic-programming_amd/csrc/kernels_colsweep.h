@@ -351,7 +351,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     typedef uint32_t u16v __attribute__((ext_vector_type(16)));
     u16v rA, rB, rC;
     asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx16 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(rA), "=s"(rB), "=s"(rC) : "s"(CS) : "memory");
+                 : "=&s"(rA), "=&s"(rB), "=&s"(rC) : "s"(CS) : "memory");      // early clobber: a destination must not take the address registers a later load of the batch reads
 #define CS_REC(i) ((i) < 16 ? rA[(i) & 15] : ((i) < 32 ? rB[(i) & 15] : rC[(i) & 15]))
 #define CS_REC_PTR(TY, i) ((TY)(uintptr_t)((uint64_t)CS_REC(i) | ((uint64_t)CS_REC((i) + 1) << 32)))
     const int n0 = (int)CS_REC(kRecN0), n1 = (int)CS_REC(kRecN1), n2 = (int)CS_REC(kRecN2), n3 = (int)CS_REC(kRecN3);
@@ -428,7 +428,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
     static_assert(offsetof(DColSweep, crec) == 192 && kCRecWords == 24, "the cost record follows the launch record");
     asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\ts_load_dwordx16 %2, %6, 0xc0\n\ts_load_dwordx8 %3, %6, 0x100\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=s"(hdr), "=s"(ent1), "=s"(cr0), "=s"(cr1) : "s"(pl), "s"(tab1n), "s"(CS) : "memory");
+                 : "=&s"(hdr), "=&s"(ent1), "=&s"(cr0), "=&s"(cr1) : "s"(pl), "s"(tab1n), "s"(CS) : "memory");
 #define CS_CREC(i) ((i) < 16 ? cr0[(i) & 15] : cr1[((i) - 16) & 7])
     int c1n = (int)ent1.x;
     T t1n = __uint_as_float(ent1.y);

@@ -342,3 +342,37 @@ def test_float64_cost_terms_every_serving_kernel(env, j_storage):
         a, b = outs["exact"], outs["f64"]
         assert np.array_equal(a["F_gI_Values"].view(np.uint32), b["F_gI_Values"].view(np.uint32))
         assert np.array_equal(a["U_Optimal_id"], b["U_Optimal_id"]) and a["stages_done"] == b["stages_done"]
+
+
+@pytest.mark.parametrize("cost_mode", ["f64", "terms"])
+def test_reference_grid_on_the_fast_axes_every_part_count(env, cost_mode):
+    """The reference's own 30 x 30 x 20 x 15 x 9 pos-att channel swept on relabelled axes (x, theta, v, w) by the column-sweep kernel,
+    as `Solver_pos_att.axis_order = "auto"` runs it, with a column cut into 1 .. 20 parts (round 5's automatic choice: ten, two steps
+    each) and the stage cost summed in double ('f64') or in single ('terms'): bit-exact against the oracle on the same relabelled
+    problem.  Regression: the float64-cost instantiation crashed with eight or more parts - the hand-written batch of scalar loads in
+    the kernel's set-up lacked early-clobber outputs, and a destination took the address registers of a later load of the batch."""
+    hjbdp, _abi, c_oracle = env
+    pa = hjbdp.Solver_pos_att()
+    pa.cost_mode = cost_mode
+    sx, sv, st, sw = pa.grids()
+    spec0, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
+    order = hjbdp.suggest_axis_order(spec0)
+    assert order is not None and tuple(order)[0] == 0
+    spec, _ = hjbdp.permute_state_axes(spec0, order)
+    ref = c_oracle.sweep(_abi, spec, 6)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.info()["kernel_variant"] == 7
+        auto = bk.get_option("cs_split")
+        assert auto >= 8                                        # short columns on a launch below one round of the wave slots
+        for parts in (0, 1, 3, 8, 10, 16, 20):
+            bk.set_option("cs_split", parts)
+            out = bk.solve(6)
+            assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"]), parts
+    # the mirror on the fast axes: the same labels as in the reference's axis order but for a few in 10^4 (a different lerp order)
+    pa2 = hjbdp.Solver_pos_att()
+    pa2.cost_mode, pa2.axis_order = cost_mode, "auto"
+    a = pa2.calculate_one_channel_U_Opt(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2, "fast", n_stages=60)
+    b = pa.calculate_one_channel_U_Opt(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2, "ref", n_stages=60)
+    assert a["F_gI_Values"].shape == b["F_gI_Values"].shape == (30, 30, 20, 15)
+    assert np.max(np.abs(a["F_gI_Values"] - b["F_gI_Values"])) <= 1e-4 * np.max(np.abs(b["F_gI_Values"]))
+    assert np.mean(a["U_Optimal_id"] == b["U_Optimal_id"]) > 0.999

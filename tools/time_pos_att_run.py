@@ -1,0 +1,26 @@
+"""Wall time of Solver_pos_att.simplified_run (four channels of the reference's 30x30x20x15x9 grid, <= 1999 stages each with the
+monitor, pos-att/Solver_pos_att.m:197-242) under the mirror's cost / axis-order settings; results of every setting are compared
+with the default's (reference axis order, cost_mode 'exact').  usage: python tools/time_pos_att_run.py"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
+import hjbdp
+
+base = None
+for cost_mode, axis_order in (("exact", None), ("f64", None), ("terms", None), ("exact", "auto"), ("f64", "auto"), ("terms", "auto")):
+    best = None
+    for rep in range(3):
+        pa = hjbdp.Solver_pos_att()
+        pa.cost_mode, pa.axis_order = cost_mode, axis_order
+        t0 = time.perf_counter()
+        pa.simplified_run()
+        wall = (time.perf_counter() - t0) * 1e3
+        best = wall if best is None else min(best, wall)
+    c = pa.controllers["channel_x_controller_1"]
+    J, U = c["F_gI_Values"], c["U_Optimal_id"]
+    if base is None:
+        base = (J, U)
+    dj = float(np.max(np.abs(J - base[0])) / np.max(np.abs(base[0])))
+    same = float(np.mean(U == base[1]))
+    print("cost_mode %-6s axis_order %-5s: simplified_run %.1f ms (channels together %.1f ms; stages of channel x: %d); vs the default: max |dJ| / max J %.2e, equal labels %.5f"
+          % (cost_mode, axis_order, best, pa.wall_ms, c["stages_done"], dj, same), flush=True)
