@@ -921,7 +921,7 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
             if (HJB_K3_PROBE == 1) {
                 for (int rb = 0; rb < (HIER ? 3 : 1); ++rb) for (int q = 0; q < 4; ++q) best = __builtin_fminf(best, F[rb][q]);
             }
-            for (; HJB_K3_PROBE != 1 && o1 < m_o1; ++o1) {
+            for (; HJB_K3_PROBE != 1 && !(HJB_K3_PROBE == 4 && o1 == m_o1 - 1 && o1 > 0) && o1 < m_o1; ++o1) {
                 const int uo = uo0 + o1;
                 // ---- level 1: (E0, dE) of the two last-axis cells this state visits ----------
                 float e0a, dea, e0b, deb;
