@@ -591,7 +591,7 @@ int32_t hjb_solve(hjb_handle hh, const hjb_solve_opts *o, hjb_result *res) {
     } while (0)
     if (o->terminal) SOLVE_TRY(hipMemcpy(h->dJ[0], o->terminal, jb, hipMemcpyHostToDevice));
     else SOLVE_TRY(hipMemset(h->dJ[0], 0, jb));
-    SOLVE_TRY(hipDeviceSynchronize());   // the sweep runs on the handle's own stream from here
+    SOLVE_TRY(sync_setup());             // the sweep runs on the handle's own stream from here (other handles' sweeps are not waited for)
     // launch-bound sweeps: replay kGraphStages ping-pong launches per hipGraphLaunch
     const bool graph_ok = h->use_graph && !dJst && !dIst && !o->probe && !every_stage && o->n_stages >= 2 * kGraphStages;
     // K9: several stages per launch for local 2-D problems (no per-stage outputs, no monitor read-backs)

@@ -140,6 +140,12 @@ struct Handle {
 
 int fail(Handle *h, int code, const char *fmt, ...);
 
+// Work of hjb_create / hjb_solve's set-up (table builds, plans, memsets) is issued on the NULL stream; a handle's sweep runs on its own
+// non-blocking stream.  Waiting for the set-up is a wait on the null stream - NOT hipDeviceSynchronize, which also waits for every other
+// handle's sweep in flight (independent channels solved side by side from several host threads, hjbdp.core.solve_many, ran one after
+// the other for it).
+inline hipError_t sync_setup() { return hipStreamSynchronize(nullptr); }
+
 #define HIP_TRY(h, expr)                                                                       \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \

@@ -137,7 +137,7 @@ int build_axis_table(Handle *h, const hjb_problem *p, int a, uint32_t dom, int64
     h->preps.push_back({a, 0, (const int32_t *)dsz_d, dsz, nent, tab});
     A.tab = tab;
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, sync_setup());
     return HJB_OK;
 }
 
@@ -525,7 +525,7 @@ int build(Handle *h, const hjb_problem *p) {
                 A.tab = tab;
             }
             HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, hipDeviceSynchronize());
+            HIP_TRY(h, sync_setup());
             h->packed_pre = 0;
             // modes 1-3 read the level cost terms from LDS only
             const bool cl_lds = (!N.ot[HJB_MAX_D].present || N.ot[HJB_MAX_D].lds_off >= 0) &&
@@ -667,7 +667,7 @@ int launch_prep_any(Handle *h, int D, int grid, int a, const int32_t *dsz, int64
             if (g_test_fail_tab64_scratch.load() || hipMalloc(&tmp, (size_t)n * sizeof(TabEntry<double>)) != hipSuccess) return fail(h, HJB_E_NOMEM, "float64 table build: scratch of %lld entries", (long long)n);
             launch_prep_t<double>(D, grid, h->dp64, a, dsz, n, (TabEntry<double> *)tmp);
             hipLaunchKernelGGL(k_tab_narrow, dim3(grid), dim3(256), 0, nullptr, (const TabEntry<double> *)tmp, tab, n);
-            const hipError_t e1 = hipDeviceSynchronize();
+            const hipError_t e1 = sync_setup();
             (void)hipFree(tmp);
             if (e1 != hipSuccess) return fail(h, HJB_E_DEVICE, "float64 table build: %s", hipGetErrorString(e1));
             return HJB_OK;
@@ -710,7 +710,7 @@ int ensure_tabled_t(Handle *h) {
         A.tab = tab;
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, sync_setup());
     void *d = nullptr;
     int st3 = dev_alloc(h, sizeof(DTabled), &d);
     if (st3) return st3;
@@ -758,7 +758,7 @@ int rebuild_tables(Handle *h, bool mfma) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
-    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, sync_setup());
     HIP_TRY(h, hipEventRecord(e0, nullptr));
     const int D = h->hp.D;
     int n_mfma = 0;
@@ -1302,7 +1302,7 @@ int examine_tile2d_t(Handle *h) {
         if (st) return st;
         (void)stage_tile2d_plan(h->dtype, h->dp, h->dtb, d, ne);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, sync_setup());
         h->tile_plan = d;
     }
     return HJB_OK;
