@@ -491,13 +491,21 @@ def main():
         # run verifies what it measured.  Equal checksums = the two transports delivered the same halo planes.
         legs = {args.transport: head}
         other = "lib" if args.transport == "torch" else "torch"
+        leg_error = None
         if args.backend == "nccl":
-            legs[other] = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist, reps=3, transport=other)
+            # (never at the price of the headline above: ShardedSweep agrees across the ranks on whether the library's RCCL
+            # transport is reachable BEFORE its collective set-up, so a failure here is raised on every rank alike)
+            try:
+                legs[other] = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist, reps=3, transport=other)
+            except Exception as e:               # noqa: BLE001 - recorded in the line, the measured headline stands
+                leg_error = "%s: %s" % (type(e).__name__, e)
         out["transports"] = {k: {"ms_per_step": r["wall"] * 1e3 / r["steps"], "value": r["total_backups"] / r["wall"],
                                  "checksum_sum_J": r["checksum"], "comm_ranks": r["info"]["comm_ranks"],
                                  "what": "RCCL inside libhjbdp (hjb_rank_step: ncclSend / ncclRecv on the library's transfer stream)"
                                          if k == "lib" else "torch.distributed batch_isend_irecv (" + args.backend + ")"}
                              for k, r in legs.items()}
+        if leg_error is not None:
+            out["transports"][other] = {"error": leg_error}
         out["transports"]["headline"] = args.transport
         out["transports"]["checksums_equal"] = len({r["checksum"] for r in legs.values()}) == 1
     if not args.no_extras:
