@@ -20,8 +20,13 @@ print("host: four channel specs built in %.1f ms" % ((time.perf_counter() - t0) 
 n_st = pa.N_stage - 1
 kw = dict(monitor_period=pa.monitor_period, monitor_tol=pa.monitor_tol, monitor_single=pa.monitor_single)
 
+_dummies = []
 def one(i, log):
     t0 = time.perf_counter()
+    if os.environ.get("DUMMY_STREAMS"):            # probe: extra streams created before this handle's own (shifts its hardware queue)
+        import torch
+        for _ in range(int(os.environ["DUMMY_STREAMS"])):
+            _dummies.append(torch.cuda.Stream())
     bk = hjbdp.Backup(specs[i])
     if os.environ.get("GRAPH"):
         bk.set_option("graph", int(os.environ["GRAPH"]))
