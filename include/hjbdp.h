@@ -446,7 +446,11 @@ const char *hjb_rank_last_error(hjb_rank r);
  * the all-reduce adds the ranks in its own order - reproducible for one world size, NOT bit-identical to the one-device
  * sum, so a stop decision within rounding of `tol` can fall one monitor period apart.
  * A host without librccl: hjb_rank_comm_unique_id / hjb_rank_comm_init return HJB_E_UNSUPPORTED with the loader's message.
- * tools/bench_ranks.cpp is a C++ driver on these calls (one process per GPU, no Python). */
+ * tools/bench_ranks.cpp is a C++ driver on these calls (one process per GPU, no Python).
+ * hjb_rank_comm_available: HJB_OK when the library can reach RCCL (loads it on first use, nothing else - no communicator, no
+ * bootstrap thread), else HJB_E_UNSUPPORTED with the loader's message in hjb_rank_last_error(NULL): what EVERY rank asks before
+ * the collective hjb_rank_comm_init, so that the ranks can agree to use another transport instead of one of them failing alone. */
+int32_t hjb_rank_comm_available(void);
 int32_t hjb_rank_comm_unique_id(void *id128_out);
 int32_t hjb_rank_comm_init(hjb_rank r, const void *id128);
 /* what the communicator itself reports (ncclCommCount / ncclCommUserRank; -1 where librccl lacks the query): lets a run

@@ -66,6 +66,7 @@ int32_t hjb_rank_check_status(void *rank, void *stream);
 int32_t hjb_rank_destroy(void *rank);
 const char *hjb_rank_last_error(void *rank);
 /* RCCL transport inside the library (include/hjbdp.h): the 128-byte id from rank 0 goes to every worker by labSend / a file */
+int32_t hjb_rank_comm_available(void);
 int32_t hjb_rank_comm_unique_id(void *id128_out);
 int32_t hjb_rank_comm_init(void *rank, const void *id128);
 int32_t hjb_rank_step(void *rank, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream);

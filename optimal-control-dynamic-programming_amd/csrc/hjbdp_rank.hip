@@ -403,6 +403,11 @@ static void rank_comm_release(hjb_rank r) {
     r->xfer = nullptr; r->xready = nullptr; r->d_partials = nullptr; r->d_sums = nullptr;
 }
 
+int32_t hjb_rank_comm_available(void) {
+    if (!rccl_load()) return rfail(nullptr, HJB_E_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why.c_str());
+    return HJB_OK;
+}
+
 int32_t hjb_rank_comm_unique_id(void *id128_out) {
     if (!id128_out) return rfail(nullptr, HJB_E_INVALID, "null argument");
     if (!rccl_load()) return rfail(nullptr, HJB_E_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why.c_str());

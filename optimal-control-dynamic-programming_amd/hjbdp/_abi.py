@@ -191,6 +191,7 @@ SYMBOLS = {
     # one process per GPU: a rank's slab as interior + boundary strips
     "hjb_rank_create": (C.c_int32, [C.POINTER(hjb_problem), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "hjb_rank_create_from": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hjb_rank_comm_available": (C.c_int32, []),
     "hjb_rank_comm_unique_id": (C.c_int32, [C.c_void_p]),
     "hjb_rank_comm_init": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "hjb_rank_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -130,17 +130,19 @@ class ShardedSweep:
                 import ctypes as C
                 import torch.distributed as dist
                 uid = (C.c_char * 128)()
-                # Before the collective ncclCommInitRank: can EVERY rank's library reach RCCL at all?  (dlopen + symbols: what
-                # hjb_rank_comm_unique_id needs.)  Agreed on through the process group, so that a rank that cannot raises on ALL
+                # Before the collective ncclCommInitRank: can EVERY rank's library reach RCCL at all?  (hjb_rank_comm_available:
+                # dlopen + symbols, nothing else.)  Agreed on through the process group, so that a rank that cannot raises on ALL
                 # ranks - a caller that tries this transport beside another one (bench.py) can catch it without leaving the
                 # other ranks waiting inside RCCL.
-                ok = 1 if rk.lib.hjb_rank_comm_unique_id(uid) == 0 else 0
+                ok = 1 if rk.lib.hjb_rank_comm_available() == 0 else 0
                 why = "" if ok else ((rk.lib.hjb_rank_last_error(None) or b"").decode() or "status != HJB_OK")
                 flag = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend(group) == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                 if int(flag.item()) == 0:
                     raise RuntimeError("transport 'lib': the RCCL transport inside libhjbdp is unavailable on at least one rank"
                                        + (" (this rank: %s)" % why if why else ""))
+                if self.rank == 0:
+                    rk._check(rk.lib.hjb_rank_comm_unique_id(uid))
                 box = [bytes(uid)]
                 dist.broadcast_object_list(box, src=0, group=group)
                 rk._check(rk.lib.hjb_rank_comm_init(rk._r, box[0]))

@@ -327,6 +327,8 @@ def test_host_without_librccl_gets_a_status_not_a_crash(built):
         "assert st == _abi.HJB_E_UNSUPPORTED, st\n"
         "assert 'dlopen' in msg and 'no/such' in msg, msg\n"
         "assert lib.hjb_rank_comm_unique_id(uid) == _abi.HJB_E_UNSUPPORTED\n"      # and again: still a status
+        "assert lib.hjb_rank_comm_available() == _abi.HJB_E_UNSUPPORTED\n"        # the probe every rank asks before the set-up
+        "assert 'dlopen' in (lib.hjb_rank_last_error(None) or b'').decode()\n"
     ) % str(ROOT / "optimal-control-dynamic-programming_amd")
     import os
     env = dict(os.environ, HJBDP_RCCL_LIB="/no/such/librccl.so")

@@ -498,6 +498,7 @@ def _rccl_unique_id(lib, _abi):
     if st == _abi.HJB_E_UNSUPPORTED:
         pytest.skip("RCCL is not available here: %s" % (lib.hjb_rank_last_error(None) or b"").decode())
     assert st == _abi.HJB_OK, lib.hjb_rank_last_error(None)
+    assert lib.hjb_rank_comm_available() == _abi.HJB_OK             # the side-effect-free probe agrees
     return uid
 
 

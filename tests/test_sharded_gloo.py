@@ -127,9 +127,12 @@ def _worker_lib_unavailable(rank, world, port, q):
     calls = []
 
     class _Lib:
+        def hjb_rank_comm_available(self):
+            calls.append("available")
+            return 0 if rank == 0 else 3
         def hjb_rank_comm_unique_id(self, buf):
             calls.append("unique_id")
-            return 0 if rank == 0 else 3
+            return 0
         def hjb_rank_last_error(self, r):
             return b"RCCL is not available: stub"
         def hjb_rank_comm_init(self, r, uid):
@@ -168,5 +171,5 @@ def test_lib_transport_unavailable_on_one_rank_raises_on_every_rank():
         assert p.exitcode == 0
     for rank, msg, calls in got:
         assert "unavailable on at least one rank" in msg, got
-        assert calls == ["unique_id"], got            # nobody reached the collective set-up
+        assert calls == ["available"], got            # nobody reached the id or the collective set-up
     assert "stub" in got[1][1] and "stub" not in got[0][1]     # the failing rank says why
