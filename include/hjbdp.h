@@ -266,7 +266,9 @@ int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
  * off by default - slower on C4), "cs_xcd_mod" (residue modulus of the column -> XCD assignment: 0/1 contiguous ranges,
  * -1 the group spacing), "cs_xcd_axis" (0: the XCDs split the group axis [default], 1: the window axis), "cs_split" (parts
  * a column is swept in - each by a wave of its own, priming where it starts; 0 = automatic: more parts for launches with
- * few columns, e.g. the boundary strips of a multi-GPU slab; reads back the value in effect). */
+ * few columns, e.g. the boundary strips of a multi-GPU slab; reads back the value in effect).  Variant 5: "tabled_i32"
+ * (1 [default where every index of the problem fits 31 bits]: the table kernel's 32-bit form, 0: its general 64-bit form;
+ * reads back the form a launch would take). */
 int32_t hjb_get_option(hjb_handle h, const char *key, int64_t *value);
 
 /* ONE backup, host buffers (exactly the MATLAB statement above):

@@ -355,6 +355,10 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         }
         return HJB_OK;
     }
+    if (!strcmp(key, "tabled_i32")) {                                // 0: variant 5 in its 64-bit form whatever the sizes (A/B timing, tests)
+        h->tabled_i32_on = value != 0;
+        return HJB_OK;
+    }
     if (!strcmp(key, "cs_coop")) {                                   // 0: variant 7 runs one wave per column (testing)
         h->cs_coop = value != 0;
         if (h->cs_state == 1) {
@@ -454,6 +458,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "cs_xcd_mod")) *value = h->cs_xcd_mod;
     else if (!strcmp(key, "cs_xcd_axis")) *value = h->cs_xcd_axis;
     else if (!strcmp(key, "cs_split")) *value = h->variant == 7 ? h->hcs.split : 0;       // the value in effect
+    else if (!strcmp(key, "tabled_i32")) *value = (h->tabled_i32 && h->tabled_i32_on) ? 1 : 0;      // the form variant 5 would run
     else if (!strcmp(key, "cs_coop_why")) *value = h->cs_coop_why;
     else if (!strcmp(key, "cs_rows")) *value = h->variant == 7 ? h->cs_rows_mid : 0;
     else if (!strcmp(key, "prep_mfma")) *value = h->prep_mfma;

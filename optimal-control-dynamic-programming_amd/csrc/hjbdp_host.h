@@ -102,6 +102,8 @@ struct Handle {
     bool window3_ok = false;      // modes 2 / 3 qualify for the three-plane window (modes 5 / 6); option "window_planes" switches
     size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
     bool tabled_ok = false;       // variant 5: per-axis (cell, t) tables for every axis (built on first use)
+    bool tabled_i32 = false;      // ... and every index of it fits 31 bits: the 32-bit form of the kernel runs (kernels_tabled.h)
+    bool tabled_i32_on = true;    // option "tabled_i32" (0: the 64-bit form anyway - A/B timing, tests)
     uint32_t dom_mask[HJB_MAX_D] = {0};
     int64_t dom_entries[HJB_MAX_D] = {0};
     DTabled htb{};

@@ -16,6 +16,7 @@ struct StageArgs {
     unsigned grid = 1, block = 256;
     size_t lds = 0;
     hipStream_t st = nullptr;
+    bool idx32 = false;            // variant 5: every index fits 31 bits (the 32-bit form of the table kernel)
     int dtype = HJB_F32;           // HJB_F32 / HJB_F64 / HJB_F16S (float32 arithmetic, binary16 J storage)
     int D = 1;
     const DParams *dp = nullptr;

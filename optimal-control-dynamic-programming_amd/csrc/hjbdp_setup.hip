@@ -601,6 +601,14 @@ int build(Handle *h, const hjb_problem *p) {
         // worth it only when the tables are small next to the per-stage work (nS * nU backups)
         const bool small = total <= ((size_t)512 << 20) || (double)total <= 0.5 * (double)h->n_owned * (double)h->nU;
         h->tabled_ok = fits && small && total <= ((size_t)16 << 30);
+        {   // the 32-bit form of the table kernel: owned states, the haloed J, every axis table (checked above) and the largest
+            // table a cost term can address (global states x controls) all below 2^31 entries
+            int64_t ns_global = 1;
+            for (int d = 0; d < D; ++d) ns_global *= p->n[d];
+            const int64_t lim = ((int64_t)1 << 31) - ((int64_t)1 << 26);     // (room for the grid-stride step on top of the last index)
+            h->tabled_i32 = h->tabled_ok && h->n_owned < lim && h->j_elems < lim && h->nU < lim &&
+                            (double)ns_global * (double)h->nU < (double)lim;
+        }
         // variant 6: no axis other than axis 0 may depend on state dim 0 (its cells are then uniform along a row)
         bool rw = h->tabled_ok && D >= 2 && !p->model;
         for (int a = 1; a < D; ++a) rw = rw && (h->dom_mask[a] & 1u) == 0;
@@ -1440,6 +1448,7 @@ int launch_stage(Handle *h, const void *dJn, void *dJo, void *didx, hipStream_t 
         }
         case 5:
             if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 5 tables missing");
+            a.idx32 = h->tabled_i32 && h->tabled_i32_on;
             miss = stage_tabled(a);
             break;
         case 4:

@@ -10,6 +10,18 @@ static int go(const StageArgs &a) {
     const dim3 g(a.grid), b(a.block);
     const TJ *Jn = (const TJ *)a.Jn;
     TJ *Jo = (TJ *)a.Jo;
+    if (a.idx32) {
+        switch (a.D) {
+            case 1: hipLaunchKernelGGL((k_backup_tabled32<T, TJ, 1>), g, b, 0, a.st, a.dp, a.dtb, Jn, Jo, a.idx); break;
+            case 2: hipLaunchKernelGGL((k_backup_tabled32<T, TJ, 2>), g, b, 0, a.st, a.dp, a.dtb, Jn, Jo, a.idx); break;
+            case 3: hipLaunchKernelGGL((k_backup_tabled32<T, TJ, 3>), g, b, 0, a.st, a.dp, a.dtb, Jn, Jo, a.idx); break;
+            case 4: hipLaunchKernelGGL((k_backup_tabled32<T, TJ, 4>), g, b, 0, a.st, a.dp, a.dtb, Jn, Jo, a.idx); break;
+            case 5: hipLaunchKernelGGL((k_backup_tabled32<T, TJ, 5>), g, b, 0, a.st, a.dp, a.dtb, Jn, Jo, a.idx); break;
+            case 6: hipLaunchKernelGGL((k_backup_tabled32<T, TJ, 6>), g, b, 0, a.st, a.dp, a.dtb, Jn, Jo, a.idx); break;
+            default: return 1;
+        }
+        return 0;
+    }
     switch (a.D) {
         case 1: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 1>), g, b, 0, a.st, a.dp, a.dtb, Jn, Jo, a.idx); break;
         case 2: hipLaunchKernelGGL((k_backup_tabled<T, TJ, 2>), g, b, 0, a.st, a.dp, a.dtb, Jn, Jo, a.idx); break;

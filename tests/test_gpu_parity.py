@@ -107,6 +107,41 @@ def test_random_problems_bit_exact(env, n, m, dtype, nonuniform, variant):
     assert out["idx"].min() >= 1 and out["idx"].max() <= spec.nU
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,dtype,nonuniform", SHAPES)
+def test_table_kernel_both_index_forms_bit_exact(env, n, m, dtype, nonuniform):
+    """Variant 5 runs in 32-bit index arithmetic when every index fits 31 bits (k_backup_tabled32: hoisted corner offsets, axis-0 corner
+    pairs as one load, the next control's table entries one control ahead) and in the general 64-bit form otherwise.  Both forms, forced
+    by the option, must equal the oracle bit for bit - on whole grids and on a slab - and the small problems of this suite must get the
+    32-bit form by default."""
+    hjbdp, _abi, c_oracle = env
+    from problems import random_problem, random_terminal
+    spec = random_problem(4321 + len(n) * 10 + len(m), n, m, dtype=dtype, nonuniform=nonuniform, index_base=1)
+    term = random_terminal(spec, 9)
+    ref = c_oracle.sweep(_abi, spec, 3, terminal=term, keep_J=True, keep_idx=True)
+    for form in (1, 0):
+        with hjbdp.Backup(spec, variant=5) as bk:
+            assert bk.get_option("tabled_i32") == 1                    # the default on a small problem
+            bk.set_option("tabled_i32", form)
+            assert bk.get_option("tabled_i32") == form
+            out = bk.solve(3, terminal=term, keep_J=True, keep_idx=True)
+        assert np.array_equal(out["J_stages"], ref["J_stages"]) and np.array_equal(out["idx_stages"], ref["idx_stages"]), form
+    nl = n[-1]
+    if nl >= 6:
+        b, e = nl // 3, nl - nl // 3
+        with hjbdp.Backup(spec, variant=5) as bk:
+            need = bk.info()
+        hl, hh = min(need["halo_needed_lo"], b), min(need["halo_needed_hi"], nl - e)
+        inner = spec.nS // nl
+        sub = np.asfortranarray(term.reshape(inner, -1, order="F")[:, b - hl:e + hh]).reshape(-1, order="F")
+        Jr, ir = c_oracle.backup_stage(_abi, spec, sub, slab=(b, e, hl, hh))
+        for form in (1, 0):
+            with hjbdp.Backup(spec, slab=(b, e, hl, hh), variant=5) as bk:
+                bk.set_option("tabled_i32", form)
+                Jg, ig = bk.backup_stage(sub)
+            assert np.array_equal(Jg, Jr) and np.array_equal(ig, ir), form
+
+
 NESTED = [
     ((9, 8), (3,), np.float64, False, False),              # Solver_position / attitude-simplified shape
     ((13, 11), (7,), np.float32, True, True),

@@ -43,6 +43,8 @@ for v in variants:
                 bk.set_option("cs_xcd_axis", int(os.environ["CS_XCD_AXIS"]))
             if os.environ.get("CS_SPLIT"):
                 bk.set_option("cs_split", int(os.environ["CS_SPLIT"]))
+            if os.environ.get("TABLED_I32"):
+                bk.set_option("tabled_i32", int(os.environ["TABLED_I32"]))
             if os.environ.get("CS_COOP"):
                 bk.set_option("cs_coop", int(os.environ["CS_COOP"]))
             info = bk.info()
