@@ -228,3 +228,26 @@ def test_packed2_occupancy_budgets():
     assert "Depth=2" in after and "scratch_" not in after, [ln for ln in after.splitlines() if "scratch_" in ln][:5]
     for key in ("6ELi5", "6ELi6"):                                          # three-plane window: four waves per SIMD, no spill
         assert got[key][0] <= 128 and got[key][1] == 0, got
+
+
+def test_table_kernel_32bit_form_budget():
+    """K7's 32-bit form (kernels_tabled.h::k_backup_tabled32) is worth its second set of instantiations only while it is the leaner
+    kernel: nothing spilled in any instantiation, the 4-D float32 one (the reference's pos-att grid) within 80 VGPRs (six waves per
+    SIMD), its corners loaded as axis-0 PAIRS and its table entries through global loads (eight-byte global loads: 8 + one per axis)."""
+    import tempfile
+    import __graft_entry__ as g
+    with tempfile.TemporaryDirectory() as d:
+        asm = "%s/tabled.s" % d
+        r = subprocess.run([HIPCC, *g.HIPCC_FLAGS, *g.UNIT_FLAGS.get("stage_tabled.hip", []), "-S", "--cuda-device-only",
+                            "-I%s/include" % ROOT, "-o", asm, "%s/optimal-control-dynamic-programming_amd/csrc/stage_tabled.hip" % ROOT],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        text = open(asm).read()
+    got = dict((m[0], (int(m[1]), int(m[2]))) for m in re.findall(
+        r"\.name:\s+_ZN3hjb17k_backup_tabled32I(\w+?Li\d)E\S*\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text))
+    assert len(got) == 18, sorted(got)                          # float32 / binary16-stored / float64 x D = 1 .. 6
+    assert all(sp == 0 for _, sp in got.values()), got
+    assert got["ffLi4"][0] <= 80, got
+    body = text[text.index("\n_ZN3hjb17k_backup_tabled32IffLi4E") + 1:]
+    body = body[:body.index("s_endpgm")]
+    assert len(re.findall(r"global_load_dwordx2", body)) >= 8 + 4, "corner pairs and table entries through global loads"
