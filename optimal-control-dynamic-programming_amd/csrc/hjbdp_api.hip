@@ -262,7 +262,7 @@ int32_t hjb_get_info(hjb_handle hh, hjb_info *info) {
     info->n_controls = h->nU;
     info->j_elems = h->j_elems;
     info->kernel_variant = h->variant;
-    info->lds_bytes = h->variant == 4 ? (int32_t)h->packed2_lds : h->variant == 2 ? (int32_t)h->packed_lds
+    info->lds_bytes = h->variant == 4 ? (int32_t)(uniwin_active(h) ? h->uw_lds : h->packed2_lds) : h->variant == 2 ? (int32_t)h->packed_lds
                       : (h->variant == 1 ? (int32_t)h->nested_lds
                       : (h->variant == 3 && h->split_j_in_lds ? (int32_t)(h->j_elems * h->esz) : 0));
     info->block = h->block;
@@ -424,7 +424,24 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         if (value == 3 && !h->window3_ok) return fail(h, HJB_E_UNSUPPORTED, "window_planes 3: the inner control can skip a cell");
         if (value == 4 && three) { h->packed_pre -= 3; h->packed2_lds += 9 * 256 * 4 + 256 * 8; }
         if (value == 3 && four) { h->packed_pre += 3; h->packed2_lds -= 9 * 256 * 4 + 256 * 8; }
-        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the captured launches are the other form
+        choose_launch(h);          // (K15 serves the three-plane modes only: the grid follows; the captured launches are the other form)
+        return HJB_OK;
+    }
+    if (!strcmp(key, "uniwin")) {           // K15 (kernels_uniwin.h): -1 automatic, 0 never, 1 whenever the structure holds
+        if (value < -1 || value > 1) return fail(h, HJB_E_INVALID, "uniwin must be -1, 0 or 1");
+        if (value == 1 && !h->uniwin_ok) return fail(h, HJB_E_UNSUPPORTED, "uniwin: the problem's rate axes are not shared by a chunk (kernels_uniwin.h)");
+        h->uniwin_on = (int)value;
+        choose_launch(h);
+        return HJB_OK;
+    }
+    if (!strcmp(key, "uw_tile")) {          // K15: log2 tile extents lA + 8 * lB + 64 * lC of the chunk walk (0: default)
+        if (value < 0 || value > 511) return fail(h, HJB_E_INVALID, "uw_tile out of range");
+        if (!h->uniwin_ok) return fail(h, HJB_E_UNSUPPORTED, "uw_tile: K15 only");
+        h->uw_tile = (int)value;
+        uniwin_tiles(h);
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipMemcpy(h->duw, &h->huw, sizeof(DUniwin), hipMemcpyHostToDevice));
         return HJB_OK;
     }
     if (!strcmp(key, "chunk_order")) {      // variant 4, window modes: 0 transposed visiting order of the 256-state chunks, 1 state order
@@ -449,7 +466,12 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "graph")) *value = h->use_graph ? 1 : 0;
     else if (!strcmp(key, "axis0_table")) *value = h->axis0_inline ? 0 : 1;       // 0: mode 1 forms axis 0's (cell, t) in the kernel
     else if (!strcmp(key, "monitor_single")) *value = h->monitor_single ? 1 : 0;
-    else if (!strcmp(key, "packed2_mode")) *value = h->packed_mode ? h->packed_pre : -1;   // variant 4's contraction mode (kernels_packed2.h), -1: not eligible
+    // variant 4's contraction mode (kernels_packed2.h; 7 / 8: K15, kernels_uniwin.h), -1: not eligible
+    else if (!strcmp(key, "packed2_mode")) *value = h->packed_mode ? (uniwin_active(h) ? h->packed_pre + 2 : h->packed_pre) : -1;
+    else if (!strcmp(key, "uniwin")) *value = uniwin_active(h) ? 1 : 0;               // the form in effect
+    else if (!strcmp(key, "uniwin_ok")) *value = h->uniwin_ok ? 1 : 0;
+    else if (!strcmp(key, "uniwin_slow_points")) *value = h->uniwin_ok ? h->uniwin_slow : -1;
+    else if (!strcmp(key, "grid")) *value = h->grid;
     else if (!strcmp(key, "idx_bytes")) *value = h->idx_bytes;
     else if (!strcmp(key, "temporal")) *value = h->use_temporal;
     else if (!strcmp(key, "chunk_order")) *value = h->dn ? h->hn.chunk_order : 0;

@@ -31,6 +31,7 @@
 #include "kernels_nested.h"
 #include "kernels_packed.h"
 #include "kernels_packed2.h"
+#include "kernels_uniwin.h"
 #include "kernels_ctrlsplit.h"
 #include "kernels_tabled.h"
 #include "kernels_rowwise.h"
@@ -101,6 +102,16 @@ struct Handle {
     int packed_pre = 0;           // variant 4 contraction mode (kernels_packed2.h MODE): 0 plain, 1 C2 shape, 2 state-only axes first
     bool window3_ok = false;      // modes 2 / 3 qualify for the three-plane window (modes 5 / 6); option "window_planes" switches
     size_t lds_pad = 0;           // extra dynamic LDS per workgroup (occupancy tuning)
+    // K15 (kernels_uniwin.h, variant 4 modes 7 / 8): the window kernel for chunks that share their rate axes
+    bool uniwin_ok = false;       // the structure holds and the per-point plan is built
+    bool uniwin_auto = false;     // ... and few enough points leave the usual shape for it to be the automatic choice
+    int uniwin_on = -1;           // option "uniwin": -1 automatic, 0 never, 1 whenever uniwin_ok
+    int uniwin_slow = 0;          // points of the plan that take the slow path
+    int uw_tile = 0;              // option "uw_tile": log2 tile extents lA + 8 * lB + 64 * lC (0: the default 3, 2, 2)
+    int uw_grid = 0;
+    size_t uw_lds = 0;
+    DUniwin huw{};
+    DUniwin *duw = nullptr;
     bool tabled_ok = false;       // variant 5: per-axis (cell, t) tables for every axis (built on first use)
     bool tabled_i32 = false;      // ... and every index of it fits 31 bits: the 32-bit form of the kernel runs (kernels_tabled.h)
     bool tabled_i32_on = true;    // option "tabled_i32" (0: the 64-bit form anyway - A/B timing, tests)
@@ -179,6 +190,10 @@ int ensure_tabled(Handle *h);
 int rebuild_tables(Handle *h, bool mfma);
 int table_hash(Handle *h, uint64_t *out);
 int ensure_colsweep(Handle *h);
+void uniwin_tiles(Handle *h);        // tile extents -> Handle::huw (the caller uploads)
+inline bool uniwin_active(const Handle *h) {
+    return h->uniwin_ok && (h->packed_pre == 5 || h->packed_pre == 6) && (h->uniwin_on == 1 || (h->uniwin_on < 0 && h->uniwin_auto));
+}
 void colsweep_split(Handle *h);
 int colsweep_upload(Handle *h);      // the device copy of Handle::hcs, launch record included
 int examine_tile2d(Handle *h);

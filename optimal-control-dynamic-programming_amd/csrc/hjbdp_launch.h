@@ -11,6 +11,7 @@ namespace hjb {
 struct DNested;
 struct DTabled;
 struct DColSweep;
+struct DUniwin;
 
 struct StageArgs {
     unsigned grid = 1, block = 256;
@@ -23,6 +24,7 @@ struct StageArgs {
     const DNested *dn = nullptr;
     const DTabled *dtb = nullptr;
     const DColSweep *dcs = nullptr;
+    const DUniwin *duw = nullptr;  // variant 4 modes 7 / 8 (kernels_uniwin.h)
     const void *Jn = nullptr;
     void *Jo = nullptr;
     void *idx = nullptr;           // argmin labels, width DParams::idx_bytes
@@ -34,6 +36,9 @@ int stage_nested(const StageArgs &a, bool fast);                                
 int stage_packed(const StageArgs &a);                                            // variant 2
 int stage_ctrlsplit(const StageArgs &a, bool j_in_lds);                          // variant 3
 int stage_packed2(const StageArgs &a, int mode);                                 // variant 4
+int stage_uniwin(const StageArgs &a, bool model);                                // variant 4, modes 7 / 8 (K15)
+int stage_uniwin_occupancy(int dtype, int D, bool model, size_t lds);            // workgroups of it one CU holds
+int stage_uniwin_plan(int D, const DParams *dp, const DNested *dn, int32_t *plan, int n_points, int nA, int nB, int32_t *n_slow);
 int stage_tabled(const StageArgs &a);                                            // variant 5
 int stage_rowwise(const StageArgs &a, bool lean);                                // variant 6
 int stage_colsweep(const StageArgs &a, int gax, int ng, int costform, bool dpp);    // variant 7 (costform: 0 general, 1 fast, 2 fast in float64)

@@ -1392,6 +1392,7 @@ void choose_launch(Handle *h) {
             h->cc_grid = (int)(8 * mostc);
         }
     }
+    if (h->variant == 4 && uniwin_active(h)) h->grid = h->uw_grid;      // K15: one generation of workgroups
     if (h->grid < 1) h->grid = 1;
 }
 
@@ -1453,6 +1454,12 @@ int launch_stage(Handle *h, const void *dJn, void *dJo, void *didx, hipStream_t 
             break;
         case 4:
             if (!f32) return fail(h, HJB_E_UNSUPPORTED, "variant 4 is float32 only");
+            if (uniwin_active(h)) {                  // modes 7 / 8 (K15, kernels_uniwin.h)
+                a.duw = h->duw;
+                a.lds = h->uw_lds + h->lds_pad;
+                miss = stage_uniwin(a, h->hp.model != 0);
+                break;
+            }
             a.lds = h->packed2_lds + h->lds_pad;
             miss = stage_packed2(a, h->packed_pre);
             break;
@@ -1562,7 +1569,103 @@ int launch_probe(Handle *h, const DProbe &pr, const void *dJn, hipStream_t st) {
 }
 
 // ---- what the other units call of the templates above
-int build_handle(Handle *h, const hjb_problem *p) { return p->dtype != HJB_F64 ? build<float>(h, p) : build<double>(h, p); }
+
+// ---- K15 (kernels_uniwin.h): variant 4's three-plane window modes on chunks that share their rate axes -------------------
+// Applies when, beyond modes 5 / 6, nothing the level axes and the last axis need depends on the state-only axes: their tables'
+// domains, the last axis' state terms and its inner term (Solver_attitude.m:423-425: the next rates are functions of the rates
+// and the torque).  The plan is built here; `uniwin_auto` says whether the usual shape holds on (nearly) every point.
+void uniwin_tiles(Handle *h) {
+    DUniwin &U = h->huw;
+    auto lg = [](int n, int most) { int l = 0; while (l < most && (1 << l) < n) ++l; return l; };
+    int lA = 3, lB = 2, lC = 2;
+    if (h->uw_tile > 0) { lA = h->uw_tile & 7; lB = (h->uw_tile >> 3) & 7; lC = (h->uw_tile >> 6) & 7; }
+    U.lA = lg(U.nA, lA);
+    U.lB = lg(U.nB, lB);
+    U.lC = lg(U.nC, lC);
+    U.ntA = (U.nA + (1 << U.lA) - 1) >> U.lA;
+    U.ntB = (U.nB + (1 << U.lB) - 1) >> U.lB;
+    U.ntC = (U.nC + (1 << U.lC) - 1) >> U.lC;
+    U.tile_chunks = (uint32_t)U.cpp << (U.lA + U.lB + U.lC);
+    const uint64_t nv = (uint64_t)U.tile_chunks * (uint64_t)U.ntA * (uint64_t)U.ntB * (uint64_t)U.ntC;
+    U.n_v = (uint32_t)std::min<uint64_t>(nv, 0xfffffff0u);
+}
+
+static int setup_uniwin(Handle *h, const hjb_problem *p) {
+    const DParams &P = h->hp;
+    const DNested &N = h->hn;
+    const int D = p->D, C = p->C;
+    h->uniwin_ok = h->uniwin_auto = false;
+    if (!(h->packed_mode && (h->packed_pre == 5 || h->packed_pre == 6)) || !h->dn) return HJB_OK;
+    if (C != 3 || D < 4 || D > 6) return HJB_OK;
+    if (!(N.m_in == kUwIn || N.m_in == kUwIn - 1) || N.m_o0 > kUwMaxO || N.m_o1 > kUwMaxO) return HJB_OK;
+    const int NP = D - 3, AX_A = D - 3, AX_B = D - 2;
+    const uint32_t so_bits = (1u << NP) - 1u;             // the state-only dims
+    for (int d = 0; d < NP; ++d)
+        if (N.at[AX_A].sstride[d] != 0 || N.at[AX_B].sstride[d] != 0) return HJB_OK;
+    if (N.at[AX_B].c0 != 0 || !N.at[AX_A].tab || !N.at[AX_B].tab) return HJB_OK;
+    for (int k = 0; k <= N.ax_kin && k < p->n_next_terms[D - 1]; ++k)
+        if (p->next_terms[D - 1][k].mask & so_bits) return HJB_OK;
+    if (N.n_ax_in != 1 || N.n_cost_in != 1 || N.in[kMaxInAx].lds_slot < 0) return HJB_OK;
+    int64_t inner = 1;
+    for (int a = 0; a < NP; ++a) inner *= p->n[a];
+    const int64_t n_points = h->n_owned / inner;
+    if (inner < 128 || inner >= ((int64_t)1 << 30) || n_points >= ((int64_t)1 << 24) || h->inner >= ((int64_t)1 << 31)) return HJB_OK;
+    size_t ot_floats = 0;
+    for (int i = HJB_MAX_D; i < HJB_MAX_D + 2; ++i)
+        if (N.ot[i].present) {
+            if (N.ot[i].lds_off < 0) return HJB_OK;
+            ot_floats = std::max<size_t>(ot_floats, (size_t)N.ot[i].lds_off + (size_t)N.ot[i].lds_len);
+        }
+    h->uw_lds = (size_t)27 * 256 * 4 + ot_floats * 4 + 16;
+    if (h->uw_lds > 64 * 1024) return HJB_OK;
+    DUniwin &U = h->huw;
+    memset(&U, 0, sizeof U);
+    U.n_points = (int32_t)n_points;
+    U.inner = (int32_t)inner;
+    U.cpp = (int32_t)((inner + 255) / 256);
+    U.nA = p->n[AX_A];
+    U.nB = p->n[AX_B];
+    U.nC = P.n[D - 1];                                     // owned planes
+    U.cl1_per_o0 = (N.ot[HJB_MAX_D + 1].present && N.ot[HJB_MAX_D + 1].c0 != 0) ? 1 : 0;
+    if ((int64_t)U.nA * U.nB * U.nC != n_points) return HJB_OK;
+    void *plan = nullptr, *cnt = nullptr;
+    int st = dev_alloc(h, (size_t)n_points * kUwRec * sizeof(int32_t), &plan);
+    if (!st) st = dev_alloc(h, sizeof(int32_t), &cnt);
+    if (st) return st;
+    HIP_TRY(h, hipMemset(cnt, 0, sizeof(int32_t)));
+    if (stage_uniwin_plan(D, h->dp, h->dn, (int32_t *)plan, (int)n_points, U.nA, U.nB, (int32_t *)cnt)) return HJB_OK;
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, sync_setup());
+    int32_t n_slow = 0;
+    HIP_TRY(h, hipMemcpy(&n_slow, cnt, sizeof n_slow, hipMemcpyDeviceToHost));
+    h->uniwin_slow = n_slow;
+    U.plan = (const int32_t *)plan;
+    uniwin_tiles(h);
+    void *du = nullptr;
+    st = dev_alloc(h, sizeof(DUniwin), &du);
+    if (st) return st;
+    h->duw = (DUniwin *)du;
+    HIP_TRY(h, hipMemcpy(h->duw, &U, sizeof U, hipMemcpyHostToDevice));
+    // the launch: as many workgroups as the device holds at once (a persistent walk: a second generation would run alone)
+    int occ = stage_uniwin_occupancy(h->dtype, D, p->model != 0, h->uw_lds);
+    if (occ < 1) occ = 4;
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int64_t g = (int64_t)occ * cus;
+    g = std::min<int64_t>(g, (int64_t)((U.n_v + 7) / 8) * 8);
+    h->uw_grid = (int)std::max<int64_t>(8, g - (g & 7));
+    h->uniwin_ok = true;
+    h->uniwin_auto = (int64_t)n_slow * 50 <= n_points;     // at most 2 % of the points on the slow path
+    return HJB_OK;
+}
+
+int build_handle(Handle *h, const hjb_problem *p) {
+    const int st = p->dtype != HJB_F64 ? build<float>(h, p) : build<double>(h, p);
+    if (st) return st;
+    return setup_uniwin(h, p);
+}
+
 
 void halo_of_problem(const hjb_problem *p, bool tab64, int *lo, int *hi) {
     if (p->dtype != HJB_F64) halo_from_terms<float>(p, tab64, lo, hi);

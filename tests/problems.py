@@ -147,3 +147,43 @@ def colsweep_problem(seed, n, nU=9, nonuniform=False, gax=3, big=2.7, small=0.6,
     else:
         raise ValueError(cost)
     return ProblemSpec(knots, [nU], nxt, ct, dtype=dtype, index_base=index_base, j_storage=j_storage)
+
+
+def rate_shared_problem(seed, n_so, n_rates, m=(11, 11, 11), gain=(0.55, 0.5, 0.6), nonuniform=False, so_move=0.7,
+                        dtype=np.float32, index_base=1, j_storage=None):
+    """The shape of K15 (kernels_uniwin.h; Solver_attitude.run with the angle axes first): the state-only axes `n_so`, whose
+    next value is tabulated over ALL state dims, then three 'rate' axes whose next value depends on the three rates and on
+    ONE control dim each (control dim c drives rate axis c; the innermost control the LAST axis).  gain[c] = the move of rate
+    axis c, in cells, from the middle to either end of its control's range; costs repeat values (exact ties)."""
+    rng = np.random.default_rng(seed)
+    NP = len(n_so)
+    n = tuple(n_so) + tuple(n_rates)
+    D = len(n)
+    knots = []
+    for a in range(D):
+        if nonuniform:
+            k = np.cumsum(rng.uniform(0.6, 1.4, n[a]))
+            k = (k - k[0]) / (k[-1] - k[0]) * 2.0 - 1.0
+        else:
+            k = np.linspace(-1.0, 1.0, n[a])
+        knots.append(k.astype(dtype).astype(np.float64))
+    hs = [2.0 / (n[a] - 1) for a in range(D)]
+    all_dims = tuple(range(D))
+    nxt = []
+    for a in range(NP):
+        shape = [1] * D
+        shape[a] = n[a]
+        tab = knots[a].reshape(shape) + so_move * hs[a] * rng.uniform(-1.0, 1.0, n)
+        nxt.append([Term(all_dims, tab)])
+    for c in range(3):
+        a = NP + c
+        others = [NP + x for x in range(3) if x != c]
+        dims = tuple(others) + (D + c,)
+        tab = 0.08 * hs[a] * rng.standard_normal((n[others[0]], n[others[1]]))[:, :, None] + \
+            gain[c] * hs[a] * np.linspace(-1.0, 1.0, m[c])[None, None, :]
+        nxt.append([Term((a,), knots[a].copy()), Term(dims, tab)])
+    cost = [Term((NP + c,), (1.0 + c) * knots[NP + c] ** 2) for c in range(3)]
+    cost.append(Term(tuple(range(NP)), 2.0 * rng.random(tuple(n_so))))
+    for c in range(3):
+        cost.append(Term((D + c,), 0.25 * np.round(rng.uniform(0, 3, m[c])) ** 2))
+    return ProblemSpec(knots, list(m), nxt, cost, dtype=dtype, index_base=index_base, j_storage=j_storage)

@@ -19,7 +19,11 @@ J = [torch.zeros(spec.nS, dtype=tdt, device=dev) for _ in range(2)]
 idx = torch.empty(spec.nS, dtype=torch.int32, device=dev)
 print("J buffers 2 x %.1f GB + argmin %.1f GB" % (J[0].numel() * J[0].element_size() / 1e9, idx.numel() * 4 / 1e9), flush=True)
 with hjbdp.Backup(spec) as bk:
-    print(bk.info(), flush=True)
+    if os.environ.get("UNIWIN"):                 # K15 (kernels_uniwin.h): 0 = K3's window mode 6, 1 = K15
+        bk.set_option("uniwin", int(os.environ["UNIWIN"]))
+    if os.environ.get("UW_TILE"):
+        bk.set_option("uw_tile", int(os.environ["UW_TILE"]))
+    print(bk.info(), "packed2_mode", bk.get_option("packed2_mode"), "grid", bk.get_option("grid"), "slow points", bk.get_option("uniwin_slow_points"), flush=True)
     stream = torch.cuda.current_stream(dev).cuda_stream
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(stages + 1)]
     ev[0].record()
