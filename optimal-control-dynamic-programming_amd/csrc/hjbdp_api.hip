@@ -106,6 +106,22 @@ const char *hjb_last_error(hjb_handle hh) {
 // Everything hjb_create checks or derives WITHOUT touching a device: argument validation, the label width, and (on
 // request) the halo the last axis' tables imply.  hjb_create_multi / hjb_rank_create partition on these numbers alone.
 }  // extern "C"
+int64_t hjbhost::first_nonfinite(const void *data, int64_t n, bool f64) {
+    // x - x is 0 for finite x and NaN for inf / NaN: blocks of 4096 summed branch-free (vectorisable), the element found on a hit
+    constexpr int64_t kBlk = 4096;
+    for (int64_t b0 = 0; b0 < n; b0 += kBlk) {
+        const int64_t b1 = std::min(n, b0 + kBlk);
+        double acc = 0.0;
+        if (f64) { const double *x = (const double *)data; for (int64_t i = b0; i < b1; ++i) acc += x[i] - x[i]; }
+        else { const float *x = (const float *)data; for (int64_t i = b0; i < b1; ++i) acc += (double)(x[i] - x[i]); }
+        if (acc != 0.0) {
+            for (int64_t i = b0; i < b1; ++i)
+                if (!std::isfinite(f64 ? ((const double *)data)[i] : (double)((const float *)data)[i])) return i;
+        }
+    }
+    return -1;
+}
+
 int hjbhost::analyse_problem(const hjb_problem *p, int *idx_bytes_out, int64_t *n_states_out, int *halo_lo, int *halo_hi) {
     if (!p) return fail(nullptr, HJB_E_INVALID, "null argument");
     if (p->D < 1 || p->D > HJB_MAX_D) return fail(nullptr, HJB_E_UNSUPPORTED, "D=%d not in 1..%d", p->D, HJB_MAX_D);
@@ -128,9 +144,17 @@ int hjbhost::analyse_problem(const hjb_problem *p, int *idx_bytes_out, int64_t *
         return fail(nullptr, HJB_E_INVALID, "table_dtype HJB_TAB_F64 is for float32 arithmetic without a state model (a float64 problem is float64 throughout)");
     const int G = p->D + p->C;
     int64_t nS = 1, nU = 1;
-    for (int a = 0; a < p->D; ++a) {
+    for (int a = 0; a < p->D; ++a)       // sizes first: everything below multiplies them
         if (p->n[a] < 2) return fail(nullptr, HJB_E_INVALID, "n[%d]=%d < 2", a, p->n[a]);
+    for (int c = 0; c < p->C; ++c) {
+        if (p->m[c] < 1) return fail(nullptr, HJB_E_INVALID, "m[%d]=%d < 1", c, p->m[c]);
+        if (nU > ((int64_t)1 << 31) / p->m[c]) return fail(nullptr, HJB_E_UNSUPPORTED, "too many controls");
+        nU *= p->m[c];
+    }
+    for (int a = 0; a < p->D; ++a) {
         if (!p->knots[a]) return fail(nullptr, HJB_E_INVALID, "knots[%d] is null", a);
+        for (int i = 0; i < p->n[a]; ++i)
+            if (!std::isfinite(p->knots[a][i])) return fail(nullptr, HJB_E_INVALID, "knots[%d][%d] is not finite", a, i);
         for (int i = 0; i + 1 < p->n[a]; ++i)
             if (!(p->knots[a][i + 1] > p->knots[a][i]))
                 return fail(nullptr, HJB_E_INVALID, "knots[%d] not strictly increasing at %d", a, i);
@@ -141,19 +165,29 @@ int hjbhost::analyse_problem(const hjb_problem *p, int *idx_bytes_out, int64_t *
             const hjb_term &t = p->next_terms[a][k];
             if (!t.data || (t.mask >> G)) return fail(nullptr, HJB_E_INVALID, "next term %d of axis %d: bad mask/data", k, a);
             if (term_elems(p, t.mask) >= ((int64_t)1 << 31)) return fail(nullptr, HJB_E_UNSUPPORTED, "next term %d of axis %d has >= 2^31 elements", k, a);
+            const int64_t bad = first_nonfinite(t.data, term_elems(p, t.mask), p->dtype == HJB_F64 || p->table_dtype == HJB_TAB_F64);
+            if (bad >= 0) return fail(nullptr, HJB_E_INVALID, "next term %d of axis %d: element %lld is not finite", k, a, (long long)bad);
         }
+        // (six axes of 2^15 points would wrap a 64-bit product to 0 and pass every later size check)
+        if (nS > kMaxStates / p->n[a]) return fail(nullptr, HJB_E_UNSUPPORTED, "more than 2^40 grid points (axes 0..%d)", a);
         nS *= p->n[a];
     }
-    for (int c = 0; c < p->C; ++c) {
-        if (p->m[c] < 1) return fail(nullptr, HJB_E_INVALID, "m[%d]=%d < 1", c, p->m[c]);
-        nU *= p->m[c];
+    if (p->model == HJB_MODEL_QUAT_EULER321) {
+        for (int i = 0; i < 4; ++i) {
+            const int64_t bad = first_nonfinite(p->model_tables[i], (int64_t)p->n[0] * p->n[1] * p->n[2], false);
+            if (bad >= 0) return fail(nullptr, HJB_E_INVALID, "model_tables[%d]: element %lld is not finite", i, (long long)bad);
+        }
+        if (!std::isfinite(p->model_h)) return fail(nullptr, HJB_E_INVALID, "model_h is not finite");
     }
     if (nU >= (int64_t)1 << 31) return fail(nullptr, HJB_E_UNSUPPORTED, "too many controls");
     if (p->n_cost_terms < 1 || p->n_cost_terms > HJB_MAX_TERMS) return fail(nullptr, HJB_E_INVALID, "n_cost_terms=%d", p->n_cost_terms);
     for (int k = 0; k < p->n_cost_terms; ++k)
         if (!p->cost_terms[k].data || (p->cost_terms[k].mask >> G)) return fail(nullptr, HJB_E_INVALID, "cost term %d: bad mask/data", k);
-    for (int k = 0; k < p->n_cost_terms; ++k)
+    for (int k = 0; k < p->n_cost_terms; ++k) {
         if (term_elems(p, p->cost_terms[k].mask) >= ((int64_t)1 << 31)) return fail(nullptr, HJB_E_UNSUPPORTED, "cost term %d has >= 2^31 elements", k);
+        const int64_t bad = first_nonfinite(p->cost_terms[k].data, term_elems(p, p->cost_terms[k].mask), p->dtype == HJB_F64 || p->cost_dtype == HJB_COST_F64);
+        if (bad >= 0) return fail(nullptr, HJB_E_INVALID, "cost term %d: element %lld is not finite", k, (long long)bad);
+    }
     if (p->slab_begin || p->slab_end || p->halo_lo || p->halo_hi) {
         const int nl = p->n[p->D - 1];
         if (p->slab_begin < 0 || p->slab_end > nl || p->slab_begin >= p->slab_end || p->halo_lo < 0 || p->halo_hi < 0 ||

@@ -29,7 +29,12 @@ int32_t hjb_problem_new(int32_t D, int32_t C, const int32_t *n, const int32_t *m
     if (C < 1 || C > HJB_MAX_C) return bfail(nullptr, HJB_E_UNSUPPORTED, "C=%d not in 1..%d", C, HJB_MAX_C);
     if (dtype != HJB_F32 && dtype != HJB_F64 && dtype != HJB_F16S) return bfail(nullptr, HJB_E_UNSUPPORTED, "dtype %d", dtype);
     if (index_base != 0 && index_base != 1) return bfail(nullptr, HJB_E_INVALID, "index_base must be 0 or 1");
-    for (int a = 0; a < D; ++a) if (n[a] < 2) return bfail(nullptr, HJB_E_INVALID, "n[%d]=%d < 2", a, n[a]);
+    int64_t nS = 1;
+    for (int a = 0; a < D; ++a) {
+        if (n[a] < 2) return bfail(nullptr, HJB_E_INVALID, "n[%d]=%d < 2", a, n[a]);
+        if (nS > kMaxStates / n[a]) return bfail(nullptr, HJB_E_UNSUPPORTED, "more than 2^40 grid points (axes 0..%d)", a);
+        nS *= n[a];
+    }
     for (int c = 0; c < C; ++c) if (m[c] < 1) return bfail(nullptr, HJB_E_INVALID, "m[%d]=%d < 1", c, m[c]);
     hjb_builder b = new hjb_builder_s();
     b->p.D = D; b->p.C = C; b->p.dtype = dtype; b->p.index_base = index_base;
@@ -44,6 +49,10 @@ int32_t hjb_problem_set_knots(hjb_builder b, int32_t axis, const double *knots, 
     if (!b || !knots) return bfail(b, HJB_E_INVALID, "null argument");
     if (axis < 0 || axis >= b->p.D) return bfail(b, HJB_E_INVALID, "axis %d not in 0..%d", axis, b->p.D - 1);
     if (len != b->p.n[axis]) return bfail(b, HJB_E_INVALID, "axis %d has %d grid points, %d knots given", axis, b->p.n[axis], len);
+    for (int i = 0; i < len; ++i)
+        if (!std::isfinite(knots[i])) return bfail(b, HJB_E_INVALID, "knots of axis %d: element %d is not finite", axis, i);
+    for (int i = 0; i + 1 < len; ++i)
+        if (!(knots[i + 1] > knots[i])) return bfail(b, HJB_E_INVALID, "knots of axis %d not strictly increasing at %d", axis, i);
     b->knots[(size_t)axis].assign(knots, knots + len);
     return HJB_OK;
 }
@@ -82,6 +91,10 @@ static int add_term(hjb_builder b, hjb_term *slot, uint32_t mask, const void *da
     const int64_t need = term_elems(&b->p, mask);
     if (count != need) return bfail(b, HJB_E_INVALID, "%s: mask 0x%x spans %lld elements, %lld given", what, mask, (long long)need, (long long)count);
     const size_t esz = term_esz(b->p, next_term);
+    {
+        const int64_t bad = first_nonfinite(data, count, esz == 8);
+        if (bad >= 0) return bfail(b, HJB_E_INVALID, "%s (mask 0x%x): element %lld is not finite", what, mask, (long long)bad);
+    }
     b->blobs.emplace_back((const unsigned char *)data, (const unsigned char *)data + (size_t)count * esz);
     slot->mask = mask;
     slot->reserved = 0;
@@ -128,6 +141,8 @@ int32_t hjb_problem_set_model(hjb_builder b, int32_t model, double model_h, cons
     const size_t ne = (size_t)b->p.n[0] * b->p.n[1] * b->p.n[2];
     for (int i = 0; i < 4; ++i) {
         if (!t[i]) return bfail(b, HJB_E_INVALID, "model table %d is null", i);
+        const int64_t bad = first_nonfinite(t[i], (int64_t)ne, false);
+        if (bad >= 0) return bfail(b, HJB_E_INVALID, "model table %d: element %lld is not finite", i, (long long)bad);
         b->blobs.emplace_back((const unsigned char *)t[i], (const unsigned char *)t[i] + ne * 4);
         b->p.model_tables[i] = (const void *)(uintptr_t)b->blobs.size();     // blob number, bound in hjb_create_from
     }

@@ -205,6 +205,11 @@ int check_status(Handle *h, hipStream_t st);
 int make_probe(Handle *h, const hjb_probe *pb, DProbe *out);
 int launch_probe(Handle *h, const DProbe &pr, const void *dJn, hipStream_t st);
 
+// First element of a term / table array that is not finite (-1: all finite).  The kernels' contract covers finite data only
+// (DESIGN.md section 2): a NaN in a table is refused where it enters, with its place named, not found in J 2000 stages later.
+int64_t first_nonfinite(const void *data, int64_t n, bool f64);
+constexpr int64_t kMaxStates = (int64_t)1 << 40;     // more grid points than any device of this generation can hold one byte for
+
 // hjbdp_api.hip: everything hjb_create checks or derives WITHOUT touching a device (the partitioners use it)
 int analyse_problem(const hjb_problem *p, int *idx_bytes_out, int64_t *n_states_out, int *halo_lo, int *halo_hi);
 

@@ -33,7 +33,11 @@ int dev_alloc(Handle *h, size_t bytes, void **out) {
 int64_t term_elems(const hjb_problem *p, uint32_t mask) {
     int64_t s = 1;
     for (int d = 0; d < p->D + p->C; ++d)
-        if (mask & (1u << d)) s *= (d < p->D) ? p->n[d] : p->m[d - p->D];
+        if (mask & (1u << d)) {
+            const int64_t k = (d < p->D) ? p->n[d] : p->m[d - p->D];
+            if (k < 1 || s > (INT64_MAX >> 1) / k) return INT64_MAX;      // saturates: every caller compares with a limit
+            s *= k;
+        }
     return s;
 }
 

@@ -377,3 +377,71 @@ def test_flat_builder_types_are_validated(lib):
     assert lib.hjb_problem_new(2, 1, n, m, _abi.HJB_F64, 1, C.byref(b)) == _abi.HJB_OK
     assert lib.hjb_problem_set_types(b, _abi.HJB_IDX_I32, _abi.HJB_TAB_F64) == _abi.HJB_E_INVALID         # a float64 problem is float64 throughout
     assert lib.hjb_problem_free(b) == _abi.HJB_OK
+
+
+def test_sizes_that_overflow_and_non_finite_data_are_refused_where_they_enter(lib):
+    """six axes of 2^15 points wrapped the 64-bit state count to 0 and passed every size check; NaN / inf
+    in knots, terms or model tables went through to the kernels, whose contract covers finite data only.  Both entry points
+    (the struct API's hjb_create and the flat builder's setters) now answer with a status and name the place - without a GPU."""
+    import hjbdp
+    from hjbdp import _abi
+    h = C.c_void_p()
+    b = C.c_void_p()
+    big = (C.c_int32 * 6)(*[1 << 15] * 6)
+    m3 = (C.c_int32 * 3)(11, 11, 11)
+    assert lib.hjb_problem_new(6, 3, big, m3, _abi.HJB_F32, 1, C.byref(b)) == _abi.HJB_E_UNSUPPORTED
+    assert b"2^40" in lib.hjb_problem_last_error(None)
+    k = np.linspace(0, 1, 5)
+    spec = hjbdp.ProblemSpec([k, k], [3], [[hjbdp.Term((0,), k)], [hjbdp.Term((1,), k), hjbdp.Term((2,), np.arange(3.0))]],
+                             [hjbdp.Term((0,), k), hjbdp.Term((2,), np.ones(3))])
+    p, keep = spec.to_c()
+    for a in range(6):
+        p.n[a] = 1 << 15
+    p.D = 6
+    bigk = np.linspace(0, 1, 1 << 15)
+    for a in range(6):
+        p.knots[a] = bigk.ctypes.data_as(C.POINTER(C.c_double))
+        p.n_next_terms[a] = 1
+        p.next_terms[a][0] = p.next_terms[0][0]
+        p.next_terms[a][0].mask = 0            # a scalar term: the sizes alone are on trial
+    assert lib.hjb_create(C.byref(p), 0, C.byref(h)) == _abi.HJB_E_UNSUPPORTED
+    assert b"2^40" in lib.hjb_last_error(None)
+    # non-finite data, struct API
+    for where, val, msg in (("knots", np.inf, b"knots[1][3] is not finite"), ("next", np.nan, b"next term 1 of axis 1: element 2 is not finite"),
+                            ("cost", -np.inf, b"cost term 0: element 4 is not finite")):
+        p, keep = spec.to_c()
+        bad = {"knots": k.copy(), "next": np.arange(3.0), "cost": k.copy()}[where]
+        if where == "knots":
+            bad[3] = val
+            p.knots[1] = bad.ctypes.data_as(C.POINTER(C.c_double))
+        elif where == "next":
+            bad[2] = val
+            p.next_terms[1][1].data = bad.ctypes.data
+        else:
+            bad[4] = val
+            p.cost_terms[0].data = bad.ctypes.data
+        assert lib.hjb_create(C.byref(p), 0, C.byref(h)) == _abi.HJB_E_INVALID, where
+        assert msg in lib.hjb_last_error(None), lib.hjb_last_error(None)
+    # ... and the flat builder's setters
+    n2 = (C.c_int32 * 2)(5, 5)
+    m1 = (C.c_int32 * 1)(3)
+    assert lib.hjb_problem_new(2, 1, n2, m1, _abi.HJB_F64, 1, C.byref(b)) == _abi.HJB_OK
+    kb = k.copy(); kb[3] = np.inf
+    assert lib.hjb_problem_set_knots(b, 0, kb.ctypes.data_as(C.POINTER(C.c_double)), 5) == _abi.HJB_E_INVALID
+    assert b"knots of axis 0: element 3 is not finite" in lib.hjb_problem_last_error(b)
+    kd = k.copy(); kd[2] = kd[1]
+    assert lib.hjb_problem_set_knots(b, 0, kd.ctypes.data_as(C.POINTER(C.c_double)), 5) == _abi.HJB_E_INVALID
+    assert b"not strictly increasing at 1" in lib.hjb_problem_last_error(b)
+    t = np.arange(5.0); t[2] = np.nan
+    assert lib.hjb_problem_add_next_term(b, 0, 0b001, t.ctypes.data, 5) == _abi.HJB_E_INVALID
+    assert b"element 2 is not finite" in lib.hjb_problem_last_error(b)
+    assert lib.hjb_problem_add_cost_term(b, 0b010, t.ctypes.data, 5) == _abi.HJB_E_INVALID
+    assert lib.hjb_problem_free(b) == _abi.HJB_OK
+    # the scan itself: float32 and float64, a hit in any block
+    v = np.zeros(10000, dtype=np.float32); v[9999] = np.inf
+    lib.hjb_problem_new(2, 1, (C.c_int32 * 2)(100, 100), m1, _abi.HJB_F32, 1, C.byref(b))
+    assert lib.hjb_problem_add_next_term(b, 0, 0b011, v.ctypes.data, 10000) == _abi.HJB_E_INVALID
+    assert b"element 9999" in lib.hjb_problem_last_error(b)
+    v[9999] = 1.0
+    assert lib.hjb_problem_add_next_term(b, 0, 0b011, v.ctypes.data, 10000) == _abi.HJB_OK
+    assert lib.hjb_problem_free(b) == _abi.HJB_OK

@@ -324,7 +324,8 @@ def test_6d_24_pow_6_five_stages_deep(env, form, h):
     try:
         with hjbdp.Backup(spec) as bk:
             assert bk.info()["kernel_variant"] == 4
-            assert bk.get_option("packed2_mode") == (6 if form == "on_the_fly" else 5)
+            # h = 0.005: K15 (kernels_uniwin.h, modes 7 / 8); h = 0.03: its plan flags the sweeps that span 3.6 cells and K3's mode 6 stays
+            assert bk.get_option("packed2_mode") == ((8 if form == "on_the_fly" else 7) if h < 0.03 else 6)
             J_prev = np.zeros(spec.nS, dtype=np.float32)
             dA.upload(J_prev)
             src, dst = dA, dB
@@ -374,7 +375,7 @@ def test_c3_full_size_second_stage_from_the_gpus_own_output(env):
     dI = hjbdp.DeviceBuffer(spec.nS * 2)
     try:
         with hjbdp.Backup(spec) as bk:
-            assert bk.info()["kernel_variant"] == 4 and bk.get_option("packed2_mode") == 6
+            assert bk.info()["kernel_variant"] == 4 and bk.get_option("packed2_mode") == 8        # K15 (kernels_uniwin.h)
             bk.fill_separable(vecs, dA)
             bk.backup_stage_device(dA, dB, dI)                  # stage 1: separable -> dB
             bk.check_device_status()

@@ -52,6 +52,26 @@ def test_uniwin_whole_grid_bit_exact(env, n_so, n_rates, m, gain, nonuniform):
     assert len(np.unique(out["idx_stages"])) > 20
 
 
+@pytest.mark.parametrize("n,m,order", [((130, 5, 4, 5), (3, 4, 11), "std"), ((130, 4, 5, 4), (2, 5, 12), "l1_first"),
+                                       ((20, 7, 3, 4, 5), (3, 6, 11), "l0_first"), ((20, 7, 4, 3, 5), (4, 3, 12), "inner_first")])
+def test_uniwin_cost_term_orders(env, n, m, order):
+    """A control's cost term FIRST in the canonical sum (no state terms before it): the level-0 / level-1 / inner term leads, on
+    the chain problem of the K3 trip-shape tests (tests/test_gpu_parity.py) with eleven / twelve inner controls."""
+    hjbdp, _abi, c_oracle = env
+    from problems import random_terminal
+    from test_gpu_parity import _chain_spec
+    D = len(n)
+    orders = {"std": lambda k: list(range(k)), "l0_first": lambda k: [D, D + 1, D + 2], "l1_first": lambda k: [D + 1, D + 2],
+              "inner_first": lambda k: [0, D + 2]}
+    spec = _chain_spec(n, m, (0.05, 0.05, 0.10), -1.0, 1.0, orders[order])
+    term = random_terminal(spec, 5)
+    ref = c_oracle.sweep(_abi, spec, 2, terminal=term, keep_J=True, keep_idx=True)
+    with hjbdp.Backup(spec, variant=4) as bk:
+        assert bk.get_option("packed2_mode") == 7, (bk.get_option("uniwin_ok"), bk.get_option("uniwin_slow_points"))
+        out = bk.solve(2, terminal=term, keep_J=True, keep_idx=True)
+    assert np.array_equal(out["J_stages"], ref["J_stages"]) and np.array_equal(out["idx_stages"], ref["idx_stages"])
+
+
 def test_uniwin_points_outside_the_usual_shape_take_the_slow_path(env):
     """A rate step of 0.3 cells per control level (the three-plane window is still admitted) carries a sweep of eleven across
     three cells: nearly every point is flagged, the automatic choice stays with mode 5, and K15 forced on must still agree with
