@@ -56,8 +56,9 @@ KERNEL_OF_VARIANT = {7: "k_backup_colsweep", 6: "k_backup_row", 5: "k_backup_tab
 # the first entry may be a tuple of alternatives (the window modes of K3: three- or four-plane window)
 KERNEL_FILTER = {"c4": ("k_backup_colsweep<float, float", None), "c5": ("k_backup_colsweep", "k_backup_colsweep<float, float"),   # rocprofv3 leaves the binary16 name mangled
                  "c2": ("k_backup_packed2<float, 3", None),
-                 "6d": (("k_backup_packed2<float, 6, 5>", "k_backup_packed2<float, 6, 2>"), None),      # tabulated next angles
-                 "c3": (("k_backup_packed2<float, 6, 6>", "k_backup_packed2<float, 6, 3>"), None)}      # on-the-fly model
+                 # the 6-D grids: K15 (csrc/kernels_uniwin.h) where its structure holds, else K3's window modes
+                 "6d": (("k_backup_uniwin<float, 6, false>", "k_backup_packed2<float, 6, 5>", "k_backup_packed2<float, 6, 2>"), None),      # tabulated next angles
+                 "c3": (("k_backup_uniwin<float, 6, true>", "k_backup_packed2<float, 6, 6>", "k_backup_packed2<float, 6, 3>"), None)}      # on-the-fly model
 EXTRA_STEPS = {"c5": 20, "c2": 20, "6d": 4, "c3": 2}
 C3_NEEDS_GIB = 190          # J_k+1 + J_k (70.4 GB each) + uint16 labels (35.2 GB) = 176 GB resident
 
@@ -388,20 +389,25 @@ def main():
 
     head = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist, reps=1 if args.pmc_child else 3)
     # N > 1 over RCCL: BOTH halo transports sweep the same grid under the same timing contract - `--transport`
-    # first, then the other one (the RCCL calls inside libhjbdp, or torch.distributed's P2P from Python) - and the line's headline is
-    # the FASTER of the two measured legs: which of them keeps eight GPUs busy is a property of the host (one library call per stage
-    # against a Python P2P batch per stage) that only a multi-GPU box can settle.  The walls are max-over-ranks values, so every rank
-    # picks the same leg.  A leg that fails is recorded and never costs the other one (ShardedSweep agrees across the ranks on whether
-    # the library's RCCL transport is reachable BEFORE its collective set-up, so a failure is raised on every rank alike).
+    # first, then the other one (the RCCL calls inside libhjbdp, or torch.distributed's P2P from Python).  The line's HEADLINE is the
+    # `--transport` leg, whatever the other one measures (the maximum of two noisy legs is biased upward and would not compare with
+    # single-leg lines: ADVICE r05); the other leg is reported beside it under `transports`.  A second leg that fails on ANY rank is
+    # dropped on EVERY rank: the ranks all-reduce a success flag behind it (ShardedSweep has already agreed across the ranks on
+    # whether the library's RCCL transport is reachable BEFORE its collective set-up).
     legs, leg_error, chosen = {args.transport: head}, None, args.transport
     other = "lib" if args.transport == "torch" else "torch"
     if world > 1 and args.backend == "nccl" and not args.pmc_child:
+        ok = 1
         try:
             legs[other] = run_workload(args, args.workload, args.steps, args.warmup, world, rank, dev, dist, reps=3, transport=other)
         except Exception as e:               # noqa: BLE001 - recorded in the line, the measured leg stands
             leg_error = "%s: %s" % (type(e).__name__, e)
-        chosen = max(legs, key=lambda k: legs[k]["total_backups"] / legs[k]["wall"])
-        head = legs[chosen]
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            legs.pop(other, None)
+            leg_error = leg_error or "the %s leg failed on another rank" % other
     if args.pmc_child:                      # the counter passes: a few launches of every workload's stage kernel, nothing else
         for w in extras:
             if w == "c3":
@@ -511,7 +517,7 @@ def main():
         if leg_error is not None:
             out["transports"][other] = {"error": leg_error}
         out["transports"]["headline"] = chosen
-        out["transports"]["headline_rule"] = "the faster of the measured legs (first leg: --transport %s)" % args.transport
+        out["transports"]["headline_rule"] = "the --transport leg (%s); the other leg is reported beside it, never chosen" % args.transport
         out["transports"]["checksums_equal"] = len({r["checksum"] for r in legs.values()}) == 1
     if not args.no_extras:
         if world == 1:

@@ -465,7 +465,13 @@ int32_t hjb_rank_step(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *
  * the interior beside them, and the exchange of dJ_OUT's boundary planes as soon as the strips are done, under the rest of the
  * interior.  Precondition: dJ_in's halos are valid - one hjb_rank_exchange(r, dJ_in, stream) before the first step; every step
  * leaves dJ_out's halos filled (ordered for the next hjb_rank_step_post / the transfer stream / a device synchronisation).
- * hjb_rank_sweep runs this form (option "post_exchange" 0: hjb_rank_step). */
+ * hjb_rank_sweep runs this form (option "post_exchange" 0: hjb_rank_step) and returns - and stops its clock - only behind the
+ * last stage's exchange, so the final buffer's halo planes are at rest when it hands the buffer back.
+ * CONCURRENT USE OF THE COMMUNICATOR: a rank has ONE communicator; the exchange runs on the transfer stream, the monitor's
+ * all-reduce on the compute stream.  The library never has two RCCL operations of one rank in flight unordered: the monitor's
+ * all-reduce is enqueued behind an event that follows the pending exchange (hjb_rank_monitor_sums waits for it on the compute
+ * stream), and the next exchange is ordered behind the compute stream.  A host that issues its own RCCL calls on this
+ * communicator must keep the same rule - one stream order per communicator. */
 int32_t hjb_rank_step_post(hjb_rank r, void *dJ_in, void *dJ_out, void *d_idx, void *compute_stream);
 int32_t hjb_rank_monitor_sums(hjb_rank r, const void *dJ, const void *d_idx, void *compute_stream, double *sums2);
 int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, double monitor_tol, void *dJ0, void *dJ1, void *d_idx,

@@ -314,6 +314,17 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     Handle *h = (Handle *)hh;
     if (!h || !key) return fail(h, HJB_E_INVALID, "null argument");
     std::shared_lock<std::shared_mutex> lk(g_capture_mu);     // may build tables (allocation, device sync)
+    {   // options that rewrite device-resident plans or tables IN PLACE wait for the whole device first: a stage of this handle may
+        // still be in flight on a non-blocking stream - the handle's own, a rank's strip streams, a caller's.  Not hot.
+        static const char *const kRewrites[] = {"prep_mfma", "cs_dpp", "cs_split", "cs_coop", "cs_xcd_axis", "cs_xcd_mod", "chunk_order",
+                                                "uw_tile", "axis0_table", "window_planes", "uniwin"};
+        for (const char *k : kRewrites)
+            if (!strcmp(key, k)) {
+                HIP_TRY(h, hipSetDevice(h->device));
+                HIP_TRY(h, hipDeviceSynchronize());
+                break;
+            }
+    }
     if (!strcmp(key, "variant")) {
         if (value < -1 || value > 7) return fail(h, HJB_E_INVALID, "variant %lld unknown", (long long)value);
         if (value == 7) {

@@ -1,12 +1,17 @@
 // hjbdp_rank.hip - hjb_rank_*: one process per GPU, and the RCCL transport inside the library.
 // gfx950 (MI355X) only; no CPU fallback - without a HIP device every compute entry point returns HJB_E_DEVICE.
 #include <dlfcn.h>
+// RCCL's own declarations: types, enums and - through decltype - the signatures of every entry point this unit calls.  The
+// library is still dlopen'ed on first use (no link dependency); what the header gives is that an enum value, the size of
+// ncclUniqueId or an argument list can no longer drift from the librccl the image ships without this unit failing to build.
+#include <rccl/rccl.h>
 
 #include "hjbdp_host.h"
 
 using namespace hjbhost;
 
-struct ncclUniqueIdBytes { char internal[128]; };      // rccl.h ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
+static_assert(NCCL_UNIQUE_ID_BYTES == 128 && sizeof(ncclUniqueId) == 128,
+              "include/hjbdp.h hands the communicator id across the C ABI as 128 bytes (hjb_rank_comm_unique_id / _comm_init)");
 
 extern "C" {
 
@@ -28,7 +33,7 @@ struct hjb_rank_s {
     std::string err;
     // RCCL transport (hjb_rank_comm_init): the communicator, the transfer stream, an event that orders it behind the
     // compute stream, the monitor's reduction scratch, and the loopback switch of the one-GPU transport test
-    void *comm = nullptr;
+    ncclComm_t comm = nullptr;
     hipStream_t xfer = nullptr;
     hipEvent_t xready = nullptr;
     double *d_partials = nullptr, *d_sums = nullptr;
@@ -311,22 +316,23 @@ int32_t hjb_rank_wait_strips(hjb_rank r, void *stream, int32_t *covered) {
 namespace {
 struct RcclApi {
     void *lib = nullptr;
-    int (*GetUniqueId)(void *) = nullptr;
-    int (*CommInitRank)(void **, int, ncclUniqueIdBytes, int) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    int (*CommCount)(void *, int *) = nullptr;          // optional: what the communicator itself reports (hjb_rank_comm_info)
-    int (*CommUserRank)(void *, int *) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;          // optional: what the communicator itself reports (hjb_rank_comm_info)
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     std::string why;
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mu;
-constexpr int kNcclUint8 = 1, kNcclFloat64 = 8, kNcclSum = 0;      // rccl.h: ncclDataType_t / ncclRedOp_t
+constexpr ncclDataType_t kNcclUint8 = ncclUint8, kNcclFloat64 = ncclFloat64;
+constexpr ncclRedOp_t kNcclSum = ncclSum;
 
 bool rccl_load() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
@@ -351,17 +357,17 @@ bool rccl_load() {
         return f;
     };
     RcclApi a;
-    a.GetUniqueId = (int (*)(void *))sym("ncclGetUniqueId");
-    a.CommInitRank = (int (*)(void **, int, ncclUniqueIdBytes, int))sym("ncclCommInitRank");
-    a.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
-    a.GroupStart = (int (*)())sym("ncclGroupStart");
-    a.GroupEnd = (int (*)())sym("ncclGroupEnd");
-    a.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))sym("ncclSend");
-    a.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))sym("ncclRecv");
-    a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
-    a.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
-    a.CommCount = (int (*)(void *, int *))dlsym(lib, "ncclCommCount");
-    a.CommUserRank = (int (*)(void *, int *))dlsym(lib, "ncclCommUserRank");
+    a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+    a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+    a.Send = (decltype(a.Send))sym("ncclSend");
+    a.Recv = (decltype(a.Recv))sym("ncclRecv");
+    a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+    a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(lib, "ncclCommUserRank");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv || !a.AllReduce ||
         !a.GetErrorString) {
         dlclose(lib);
@@ -376,8 +382,8 @@ bool rccl_load() {
 
 #define RCCL_TRY(r, expr)                                                                                     \
     do {                                                                                                      \
-        const int e_ = (expr);                                                                                \
-        if (e_ != 0) return rfail(r, HJB_E_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(e_));        \
+        const ncclResult_t e_ = (expr);                                                                       \
+        if (e_ != ncclSuccess) return rfail(r, HJB_E_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(e_)); \
     } while (0)
 #define RANKH_TRY(r, expr)                                                                                    \
     do {                                                                                                      \
@@ -411,7 +417,7 @@ int32_t hjb_rank_comm_available(void) {
 int32_t hjb_rank_comm_unique_id(void *id128_out) {
     if (!id128_out) return rfail(nullptr, HJB_E_INVALID, "null argument");
     if (!rccl_load()) return rfail(nullptr, HJB_E_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why.c_str());
-    RCCL_TRY(nullptr, g_rccl.GetUniqueId(id128_out));
+    RCCL_TRY(nullptr, g_rccl.GetUniqueId((ncclUniqueId *)id128_out));
     return HJB_OK;
 }
 
@@ -420,7 +426,7 @@ int32_t hjb_rank_comm_init(hjb_rank r, const void *id128) {
     if (r->comm) return rfail(r, HJB_E_INVALID, "this rank already has a communicator");
     if (!rccl_load()) return rfail(r, HJB_E_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why.c_str());
     RANKH_TRY(r, hipSetDevice(r->device));
-    ncclUniqueIdBytes id;
+    ncclUniqueId id;
     memcpy(id.internal, id128, sizeof id.internal);
     // loopback (option "comm_loopback", the one-GPU transport test): a communicator of ONE rank, both neighbours = this rank
     RCCL_TRY(r, g_rccl.CommInitRank(&r->comm, r->loopback ? 1 : r->world, id, r->loopback ? 0 : r->rank));
@@ -463,7 +469,7 @@ static int rank_exchange_on_xfer(hjb_rank r, void *dJ) {
     const int dn = r->loopback ? 0 : r->rank - 1, up = r->loopback ? 0 : r->rank + 1;
     if (!(r->dn_needs || r->hlo || r->up_needs || r->hhi)) { RANKH_TRY(r, hipEventRecord(r->xdone, r->xfer)); return HJB_OK; }
     RCCL_TRY(r, g_rccl.GroupStart());
-    int e1 = 0;
+    ncclResult_t e1 = ncclSuccess;
     // towards rank - 1: my lowest owned planes are its upper halo; its top planes are my lower halo
     if (r->dn_needs && !e1) e1 = g_rccl.Send(J + plane_b * r->hlo, plane_b * r->dn_needs, kNcclUint8, dn, r->comm, r->xfer);
     if (r->up_needs && !e1) e1 = g_rccl.Send(J + plane_b * (r->hlo + owned - r->up_needs), plane_b * r->up_needs, kNcclUint8, up, r->comm, r->xfer);
@@ -476,8 +482,8 @@ static int rank_exchange_on_xfer(hjb_rank r, void *dJ) {
         if (r->hlo && !e1) e1 = g_rccl.Recv(J, plane_b * r->hlo, kNcclUint8, dn, r->comm, r->xfer);
         if (r->hhi && !e1) e1 = g_rccl.Recv(J + plane_b * (r->hlo + owned), plane_b * r->hhi, kNcclUint8, up, r->comm, r->xfer);
     }
-    const int e2 = g_rccl.GroupEnd();
-    if (e1 || e2) return rfail(r, HJB_E_DEVICE, "halo exchange: %s", g_rccl.GetErrorString(e1 ? e1 : e2));
+    const ncclResult_t e2 = g_rccl.GroupEnd();
+    if (e1 != ncclSuccess || e2 != ncclSuccess) return rfail(r, HJB_E_DEVICE, "halo exchange: %s", g_rccl.GetErrorString(e1 != ncclSuccess ? e1 : e2));
     if (r->xfer_delay_ticks > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, r->xfer, (long long)r->xfer_delay_ticks);
     RANKH_TRY(r, hipEventRecord(r->xdone, r->xfer));
     return HJB_OK;
@@ -558,6 +564,9 @@ int32_t hjb_rank_monitor_sums(hjb_rank r, const void *dJ, const void *d_idx, voi
     if (launch_monitor_sums(r->dtype, single_tree, (const char *)dJ + plane_b * r->hlo, d_idx, (int32_t)r->isz, n, r->d_partials, r->d_sums, cs) != HJB_OK)
         return rfail(r, HJB_E_DEVICE, "monitor reduction launch failed");
     if (!d_idx) RANKH_TRY(r, hipMemsetAsync(r->d_sums + 1, 0, sizeof(double), cs));
+    // one communicator, one order: the all-reduce goes behind whatever exchange is still pending on the transfer stream
+    // (post-exchange order; include/hjbdp.h "concurrent use of the communicator") - once per monitor period
+    if (r->xdone) RANKH_TRY(r, hipStreamWaitEvent(cs, r->xdone, 0));
     RCCL_TRY(r, g_rccl.AllReduce(r->d_sums, r->d_sums, 2, kNcclFloat64, kNcclSum, r->comm, cs));
     RANKH_TRY(r, hipMemcpyAsync(sums2, r->d_sums, 2 * sizeof(double), hipMemcpyDeviceToHost, cs));
     RANKH_TRY(r, hipStreamSynchronize(cs));
@@ -600,6 +609,10 @@ int32_t hjb_rank_sweep(hjb_rank r, int32_t n_stages, int32_t monitor_period, dou
         }
     }
     if (!st) {
+        // post-exchange order: the last stage's send / recv into the final buffer's halo planes may still be running on the
+        // transfer stream (also after an early stop).  The sweep ends - and is timed - behind it: a caller that refills the
+        // buffer or hands it back to a stream-ordered allocator must not race with that receive
+        if (post && r->xdone && done > 0) (void)hipStreamWaitEvent(cs, r->xdone, 0);
         (void)hipEventRecord(e1, cs);
         if (hipEventSynchronize(e1) != hipSuccess) st = rfail(r, HJB_E_DEVICE, "sweep: synchronisation failed");
         float ms = 0;

@@ -609,7 +609,7 @@ int build(Handle *h, const hjb_problem *p) {
             // table a cost term can address (global states x controls) all below 2^31 entries
             int64_t ns_global = 1;
             for (int d = 0; d < D; ++d) ns_global *= p->n[d];
-            const int64_t lim = ((int64_t)1 << 31) - ((int64_t)1 << 26);     // (room for the grid-stride step on top of the last index)
+            const int64_t lim = kTab32Lim;                                     // (room for the grid-stride step on top of the last index: kernels_tabled.h)
             h->tabled_i32 = h->tabled_ok && h->n_owned < lim && h->j_elems < lim && h->nU < lim &&
                             (double)ns_global * (double)h->nU < (double)lim;
         }
@@ -766,11 +766,22 @@ static bool prep_split(const Handle *h, const Handle::PrepRec &R, DPrepSplit *S)
     return true;
 }
 
+static int rebuild_tables_timed(Handle *h, bool mfma, hipEvent_t e0, hipEvent_t e1);
+
 int rebuild_tables(Handle *h, bool mfma) {
+    // the tables are rewritten IN PLACE: wait for the whole device, not only for the null stream - a stage may still be in flight
+    // on the handle's own stream, a rank's strip streams or a caller's stream (hjb_backup_stage_device).  Not a hot path.  
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipEventCreate(&e0));
-    HIP_TRY(h, hipEventCreate(&e1));
-    HIP_TRY(h, sync_setup());
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(h, HJB_E_DEVICE, "hipEventCreate failed"); }
+    const int st = rebuild_tables_timed(h, mfma, e0, e1);
+    (void)hipEventDestroy(e0);         // one exit: the events never leak
+    (void)hipEventDestroy(e1);
+    return st;
+}
+
+static int rebuild_tables_timed(Handle *h, bool mfma, hipEvent_t e0, hipEvent_t e1) {
     HIP_TRY(h, hipEventRecord(e0, nullptr));
     const int D = h->hp.D;
     int n_mfma = 0;
@@ -804,8 +815,6 @@ int rebuild_tables(Handle *h, bool mfma) {
     HIP_TRY(h, hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     h->prep_us = (double)ms * 1e3;
     h->prep_mfma = mfma ? 1 : 0;
     h->prep_mfma_axes = n_mfma;
@@ -1453,7 +1462,7 @@ int launch_stage(Handle *h, const void *dJn, void *dJo, void *didx, hipStream_t 
         }
         case 5:
             if (!h->dtb) return fail(h, HJB_E_DEVICE, "variant 5 tables missing");
-            a.idx32 = h->tabled_i32 && h->tabled_i32_on;
+            a.idx32 = h->tabled_i32 && h->tabled_i32_on && (int64_t)a.grid * a.block <= kTab32MaxThreads;
             miss = stage_tabled(a);
             break;
         case 4:

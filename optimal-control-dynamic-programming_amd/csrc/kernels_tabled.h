@@ -247,6 +247,12 @@ k_backup_tabled(const DParams *__restrict__ P, const DTabled *__restrict__ TB, c
 // together: the reference's pos-att grid 21.65 -> 20.55 us per stage, 60x60x40x30 0.2228 -> 0.2003 ms (profiles/r05_k7_batch_experiment.log).
 // The floating-point operations, their operands and their order are the generic kernel's: same bits.
 constexpr int kTab32MaxCt = 4;      // control-dependent cost terms whose state offsets are hoisted (more: generic term evaluation)
+// The 32-bit form advances its state index as a signed int by the launch's thread count: eligibility (hjbdp_setup.hip) keeps every
+// index below kTab32Lim and the launch (launch_stage) runs the 64-bit form when the launch has more than kTab32MaxThreads threads -
+// the two facts the loop counter's range rests on, tied together here
+constexpr int64_t kTab32MaxThreads = (int64_t)1 << 26;
+constexpr int64_t kTab32Lim = ((int64_t)1 << 31) - kTab32MaxThreads;
+static_assert(kTab32Lim - 1 + kTab32MaxThreads <= (int64_t)INT32_MAX, "k_backup_tabled32: the last index plus one grid stride must fit a signed int");
 
 template <typename T, int D>
 __device__ __forceinline__ int tab32_state_off(const DTerm &t, const int (&si)[D]) {

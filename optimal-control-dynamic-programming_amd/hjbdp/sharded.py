@@ -266,9 +266,11 @@ class ShardedSweep:
                 self._halos_valid = True
             else:
                 rk._check(rk.lib.hjb_rank_step(rk._r, J_in.data_ptr(), J_out.data_ptr(), self.idx.data_ptr(), stream))
+                self._halos_valid = False                  # J_out's halo planes are NOT exchanged by this order
         elif self._rank is None or not self._rank.split:
             self.exchange_halos()
             self.stage_fn(J_in, J_out, self.idx)
+            self._halos_valid = False
         elif self.post_exchange:
             # Boundary strips FIRST (the halos of J_in arrived during the previous stage), the interior beside them, and the
             # exchange of J_OUT's boundary planes as soon as the strips are done - it has the rest of the interior to complete,
@@ -297,6 +299,7 @@ class ShardedSweep:
             # interior on the compute stream now, the strips behind an event the library records on the transfer stream
             # at this point (= the halos have landed), on streams of their own; joined into the compute stream
             self._rank.stage(J_in, J_out, self.idx, compute_stream=main.cuda_stream, halo_stream=self._comm_stream.cuda_stream)
+            self._halos_valid = False                      # a later switch to post_exchange primes its halos again
         self.cur = 1 - self.cur
 
     def monitor_sums(self):

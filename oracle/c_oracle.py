@@ -8,6 +8,7 @@ hjbdp.problem.ProblemSpec.to_c), so both sides see byte-identical tables.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -30,7 +31,8 @@ def lib(abi):
     if _lib is None:
         if not SO.exists():
             build()
-        l = C.CDLL(str(SO))
+        # HJB_ORACLE_LIB: another build of the same source (tools/sanitize_cpu.sh: -fsanitize=address,undefined)
+        l = C.CDLL(os.environ.get("HJB_ORACLE_LIB") or str(SO))
         l.orc_backup_stage.restype = C.c_int
         l.orc_backup_stage.argtypes = [C.POINTER(abi.hjb_problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         l.orc_backup_stage_avx2.restype = C.c_int

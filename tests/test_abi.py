@@ -445,3 +445,27 @@ def test_sizes_that_overflow_and_non_finite_data_are_refused_where_they_enter(li
     v[9999] = 1.0
     assert lib.hjb_problem_add_next_term(b, 0, 0b011, v.ctypes.data, 10000) == _abi.HJB_OK
     assert lib.hjb_problem_free(b) == _abi.HJB_OK
+
+
+def test_rccl_declarations_come_from_the_images_own_header():
+    """csrc/hjbdp_rank.hip declared RCCL's ABI by hand (ncclUniqueId as 128 bytes by value, enum values, eight
+    signatures).  It now includes <rccl/rccl.h> and takes every signature by decltype, so a drift fails the BUILD; this test holds
+    the unit to that, and checks the facts the public header states about the id against the header the image ships."""
+    src = (ROOT / "optimal-control-dynamic-programming_amd" / "csrc" / "hjbdp_rank.hip").read_text()
+    assert "#include <rccl/rccl.h>" in src
+    assert not re.search(r"kNccl\w+\s*=\s*\d", src), "an enum value written as a number"
+    assert not re.search(r"\(\s*int\s*\(\s*\*\s*\)\s*\(", src), "a hand-written function-pointer cast"
+    for f in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv",
+              "ncclAllReduce", "ncclGetErrorString", "ncclCommCount", "ncclCommUserRank"):
+        assert "decltype(&%s)" % f in src, f
+        assert 'sym("%s")' % f in src or 'dlsym(lib, "%s")' % f in src, f
+    assert "static_assert(NCCL_UNIQUE_ID_BYTES == 128" in src
+    hdr = Path("/opt/rocm/include/rccl/rccl.h")
+    if not hdr.exists():
+        pytest.skip("no rccl.h in this image")
+    h = hdr.read_text()
+    assert re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+128\b", h)
+    assert re.search(r"ncclCommInitRank\(ncclComm_t\*\s*comm,\s*int\s+nranks,\s*ncclUniqueId\s+commId,\s*int\s+rank\)", h)     # the id BY VALUE
+    assert re.search(r"\bncclUint8\s*=\s*1\b", h) and re.search(r"\bncclFloat64\s*=\s*8\b", h) and re.search(r"\bncclSum\s*=\s*0\b", h)
+    pub = (ROOT / "include" / "hjbdp.h").read_text()
+    assert "128 bytes" in pub and "hjb_rank_comm_unique_id(void *id128_out)" in pub
