@@ -274,8 +274,8 @@ def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=Fal
     the MEDIAN repetition is reported, all of them are returned).  -> dict of measurements."""
     import torch
     from hjbdp.sharded import ShardedSweep
-    n = {"c2": 101, "6d": 24}.get(workload, args.grid_n)
-    spec, name = build_spec(workload, n_last=n * world if weak else None, n=args.grid_n)
+    n = {"c2": 101, "6d": 24, "c3": args.c3_n}.get(workload, args.grid_n)
+    spec, name = build_spec(workload, n_last=n * world if weak else None, n=args.c3_n if workload == "c3" else args.grid_n)
     sw = ShardedSweep(spec, rank, world, dev, overlap=not args.no_overlap, transport=transport or args.transport)
     if args.variant is not None:
         sw.set_option("variant", args.variant)
@@ -327,7 +327,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c5", "c2", "6d"], help="headline workload (default: C4)")
+    ap.add_argument("--workload", default="c4", choices=["c4", "c5", "c2", "6d", "c3"],
+                    help="headline workload (default: C4).  c3 = BASELINE configs[2] as the headline, meant for --gpus N: 51^6 states sharded "
+                         "along w3 (22 GB of J per rank at N = 8, a halo of one 1.38 GB plane per neighbour and stage); at N = 1 it needs "
+                         "190 GB of free HBM; no CPU leg and no extra workloads ride on it")
+    ap.add_argument("--c3-n", type=int, default=51, help="points per axis of the c3 workload (config: 51; smaller = testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs / the weak-scaling figure")
@@ -343,6 +347,8 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.workload == "c3":                # the 176 GB configuration as the headline: nothing else rides on the line
+        args.no_extras = args.no_cpu_baseline = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -497,7 +503,7 @@ def main():
         "dtype": "f32" if spec.j_dtype.itemsize == 4 else "f32 (J stored as f16)", "data": "synthetic",
         "config": {"workload": head["name"], "states": spec.nS, "states_per_gpu": head["states_rank"], "controls": spec.nU,
                    "stages": args.steps,
-                   "sharding": ("last state axis (v): %d of %d planes per GPU, halo %d/%d planes (rank 0) exchanged per stage over %s%s"
+                   "sharding": ("last state axis: %d of %d planes per GPU, halo %d/%d planes (rank 0) exchanged per stage over %s%s"
                                 % (head["states_rank"] // (spec.nS // spec.n[-1]), spec.n[-1], head["halo"][0], head["halo"][1],
                                    ("RCCL inside libhjbdp" if chosen == "lib" else "RCCL (torch.distributed P2P)") if args.backend == "nccl" else args.backend + " (test transport)",
                                    "" if args.no_overlap else ", overlapped with the interior planes")) if world > 1 else "none",

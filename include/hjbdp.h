@@ -294,7 +294,8 @@ int32_t hjb_device_mem_info(int32_t device, int64_t *free_bytes, int64_t *total_
 int32_t hjb_device_copy(int32_t device, void *dst, const void *src, int64_t bytes, int32_t kind);   /* synchronous */
 /* dJ[s] = ((v0[i0] + v1[i1]) + v2[i2]) + ...  over the handle's whole grid: one add of the arithmetic type per axis,
  * axis 0 first, stored in the handle's J storage type.  vecs[a]: HOST vector of n[a] elements of the arithmetic type
- * (float for HJB_F32 / HJB_F16S).  A separable terminal cost for grids too large to build on the host. */
+ * (float for HJB_F32 / HJB_F16S).  A separable terminal cost for grids too large to build on the host.  On a SLAB handle dJ is
+ * the slab's haloed buffer and is filled with the planes [slab_begin - halo_lo, slab_end + halo_hi) of that global function. */
 int32_t hjb_device_fill_separable(hjb_handle h, const void *const *vecs, void *dJ, void *stream);
 /* out[i] = d_src[sel[i]] for elements of elem_bytes (1, 2, 4, 8) bytes: sample a device-resident J or label array */
 int32_t hjb_device_gather(int32_t device, const void *d_src, int32_t elem_bytes, const int64_t *sel, int64_t n_sel, void *out);
@@ -426,6 +427,9 @@ int32_t hjb_rank_wait_strips(hjb_rank r, void *stream, int32_t *covered);
 int32_t hjb_rank_set_option(hjb_rank r, const char *key, int64_t value);
 int32_t hjb_rank_get_option(hjb_rank r, const char *key, int64_t *value);
 int32_t hjb_rank_check_status(hjb_rank r, void *stream);
+/* dJ (this rank's haloed buffer) = the separable function of hjb_device_fill_separable on the rank's planes, halo planes included:
+ * vecs[a] are the GLOBAL host vectors (n[a] elements each).  A terminal cost for grids that never exist in host memory. */
+int32_t hjb_rank_fill_separable(hjb_rank r, const void *const *vecs, void *dJ, void *stream);
 int32_t hjb_rank_destroy(hjb_rank r);
 const char *hjb_rank_last_error(hjb_rank r);
 

@@ -317,7 +317,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     {   // options that rewrite device-resident plans or tables IN PLACE wait for the whole device first: a stage of this handle may
         // still be in flight on a non-blocking stream - the handle's own, a rank's strip streams, a caller's.  Not hot.
         static const char *const kRewrites[] = {"prep_mfma", "cs_dpp", "cs_split", "cs_coop", "cs_xcd_axis", "cs_xcd_mod", "chunk_order",
-                                                "uw_tile", "axis0_table", "window_planes", "uniwin"};
+                                                "uw_tile", "uw_block", "axis0_table", "window_planes", "uniwin"};
         for (const char *k : kRewrites)
             if (!strcmp(key, k)) {
                 HIP_TRY(h, hipSetDevice(h->device));
@@ -442,6 +442,13 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
     if (!strcmp(key, "lds_pad")) {
         if (value < 0 || value > 128 * 1024) return fail(h, HJB_E_INVALID, "lds_pad out of range");
         h->lds_pad = (size_t)value;
+        if (h->uniwin_ok) {          // K15 launches ONE generation of workgroups: its grid follows the occupancy
+            uniwin_tiles(h);
+            HIP_TRY(h, hipSetDevice(h->device));
+            HIP_TRY(h, hipDeviceSynchronize());
+            HIP_TRY(h, hipMemcpy(h->duw, &h->huw, sizeof(DUniwin), hipMemcpyHostToDevice));
+            choose_launch(h);
+        }
         if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the captured launches carry the old LDS size
         return HJB_OK;
     }
@@ -479,14 +486,17 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         choose_launch(h);
         return HJB_OK;
     }
-    if (!strcmp(key, "uw_tile")) {          // K15: log2 tile extents lA + 8 * lB + 64 * lC of the chunk walk (0: default)
-        if (value < 0 || value > 511) return fail(h, HJB_E_INVALID, "uw_tile out of range");
-        if (!h->uniwin_ok) return fail(h, HJB_E_UNSUPPORTED, "uw_tile: K15 only");
-        h->uw_tile = (int)value;
+    if (!strcmp(key, "uw_tile") || !strcmp(key, "uw_block")) {
+        // K15: log2 tile extents lA + 8 * lB + 64 * lC of the chunk walk (0: default) / states per chunk = threads per workgroup (256, 64)
+        const bool tile = !strcmp(key, "uw_tile");
+        if (tile ? (value < 0 || value > 511) : (value != 64 && value != 256)) return fail(h, HJB_E_INVALID, "%s out of range", key);
+        if (!h->uniwin_ok) return fail(h, HJB_E_UNSUPPORTED, "%s: K15 only", key);
+        if (tile) h->uw_tile = (int)value; else h->uw_block = (int)value;
         uniwin_tiles(h);
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipDeviceSynchronize());
         HIP_TRY(h, hipMemcpy(h->duw, &h->huw, sizeof(DUniwin), hipMemcpyHostToDevice));
+        choose_launch(h);
         return HJB_OK;
     }
     if (!strcmp(key, "chunk_order")) {      // variant 4, window modes: 0 transposed visiting order of the 256-state chunks, 1 state order
@@ -515,6 +525,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "packed2_mode")) *value = h->packed_mode ? (uniwin_active(h) ? h->packed_pre + 2 : h->packed_pre) : -1;
     else if (!strcmp(key, "uniwin")) *value = uniwin_active(h) ? 1 : 0;               // the form in effect
     else if (!strcmp(key, "uniwin_ok")) *value = h->uniwin_ok ? 1 : 0;
+    else if (!strcmp(key, "uw_block")) *value = h->uniwin_ok ? h->huw.block : 0;
     else if (!strcmp(key, "uniwin_slow_points")) *value = h->uniwin_ok ? h->uniwin_slow : -1;
     else if (!strcmp(key, "grid")) *value = h->grid;
     else if (!strcmp(key, "idx_bytes")) *value = h->idx_bytes;

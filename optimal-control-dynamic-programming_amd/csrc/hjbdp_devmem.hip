@@ -53,7 +53,8 @@ int32_t hjb_device_copy(int32_t device, void *dst, const void *src, int64_t byte
 int32_t hjb_device_fill_separable(hjb_handle hh, const void *const *vecs, void *dJ, void *stream) {
     Handle *h = (Handle *)hh;
     if (!h || !vecs || !dJ) return fail(h, HJB_E_INVALID, "null argument");
-    if (h->j_elems != h->n_owned) return fail(h, HJB_E_UNSUPPORTED, "hjb_device_fill_separable fills whole grids");
+    // a slab handle: its haloed buffer = planes [slab_begin - halo_lo, slab_end + halo_hi) of the GLOBAL separable function
+    const bool slab = h->j_elems != h->n_owned || h->plane0 != 0 || h->nplanes != h->prob.n[h->hp.D - 1];
     std::shared_lock<std::shared_mutex> lk(g_capture_mu);
     HIP_TRY(h, hipSetDevice(h->device));
     const int D = h->hp.D;
@@ -71,7 +72,12 @@ int32_t hjb_device_fill_separable(hjb_handle hh, const void *const *vecs, void *
     }
     S.D = D;
     S.total = h->n_owned;
-    const unsigned grid = (unsigned)std::min<int64_t>((h->n_owned + 255) / 256, 256 * 64);
+    if (slab) {
+        S.v[D - 1] = (const char *)S.v[D - 1] + (size_t)h->plane0 * tsz;
+        S.n[D - 1] = h->nplanes;
+        S.total = h->j_elems;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>((S.total + 255) / 256, 256 * 64);
     if (h->dtype == HJB_F16S) hipLaunchKernelGGL((k_fill_separable<float, _Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, S, (_Float16 *)dJ);
     else if (h->dtype == HJB_F32) hipLaunchKernelGGL((k_fill_separable<float, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, S, (float *)dJ);
     else hipLaunchKernelGGL((k_fill_separable<double, double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, S, (double *)dJ);

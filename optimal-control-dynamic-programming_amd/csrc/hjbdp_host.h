@@ -109,6 +109,7 @@ struct Handle {
     int uniwin_slow = 0;          // points of the plan that take the slow path
     int uw_tile = 0;              // option "uw_tile": log2 tile extents lA + 8 * lB + 64 * lC (0: the default 3, 2, 2)
     int uw_grid = 0;
+    int uw_block = 256;           // option "uw_block": states per chunk = threads per workgroup (256 or 64)
     size_t uw_lds = 0;
     DUniwin huw{};
     DUniwin *duw = nullptr;
@@ -190,7 +191,7 @@ int ensure_tabled(Handle *h);
 int rebuild_tables(Handle *h, bool mfma);
 int table_hash(Handle *h, uint64_t *out);
 int ensure_colsweep(Handle *h);
-void uniwin_tiles(Handle *h);        // tile extents -> Handle::huw (the caller uploads)
+void uniwin_tiles(Handle *h);        // workgroup size, chunk count, tile extents, LDS and launch grid -> Handle (the caller uploads Handle::huw)
 inline bool uniwin_active(const Handle *h) {
     return h->uniwin_ok && (h->packed_pre == 5 || h->packed_pre == 6) && (h->uniwin_on == 1 || (h->uniwin_on < 0 && h->uniwin_auto));
 }

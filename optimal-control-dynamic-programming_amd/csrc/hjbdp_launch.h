@@ -37,7 +37,7 @@ int stage_packed(const StageArgs &a);                                           
 int stage_ctrlsplit(const StageArgs &a, bool j_in_lds);                          // variant 3
 int stage_packed2(const StageArgs &a, int mode);                                 // variant 4
 int stage_uniwin(const StageArgs &a, bool model);                                // variant 4, modes 7 / 8 (K15)
-int stage_uniwin_occupancy(int dtype, int D, bool model, size_t lds);            // workgroups of it one CU holds
+int stage_uniwin_occupancy(int dtype, int D, bool model, int block, size_t lds); // workgroups of `block` threads one CU holds
 int stage_uniwin_plan(int D, const DParams *dp, const DNested *dn, int32_t *plan, int n_points, int nA, int nB, int32_t *n_slow);
 int stage_tabled(const StageArgs &a);                                            // variant 5
 int stage_rowwise(const StageArgs &a, bool lean);                                // variant 6

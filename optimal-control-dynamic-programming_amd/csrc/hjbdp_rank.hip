@@ -212,6 +212,15 @@ int32_t hjb_rank_get_option(hjb_rank r, const char *key, int64_t *value) {
     return hjb_get_option((hjb_handle)(r->part[0] ? r->part[0] : r->whole), key, value);
 }
 
+// a separable terminal cost built on the device in this rank's haloed buffer (owned planes AND halo planes: a grid like C3's
+// never exists in host memory) - hjb_device_fill_separable on the rank's slab handle
+int32_t hjb_rank_fill_separable(hjb_rank r, const void *const *vecs, void *dJ, void *stream) {
+    if (!r || !r->whole) return rfail(r, HJB_E_INVALID, "null argument");
+    const int st = hjb_device_fill_separable((hjb_handle)r->whole, vecs, dJ, stream);
+    if (st) return rfail(r, st, "%s", r->whole->err.c_str());
+    return HJB_OK;
+}
+
 int32_t hjb_rank_check_status(hjb_rank r, void *stream) {
     if (!r) return rfail(r, HJB_E_INVALID, "null argument");
     if (hipSetDevice(r->device) != hipSuccess) return rfail(r, HJB_E_DEVICE, "hipSetDevice failed");

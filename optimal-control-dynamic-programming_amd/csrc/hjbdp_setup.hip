@@ -1469,6 +1469,7 @@ int launch_stage(Handle *h, const void *dJn, void *dJo, void *didx, hipStream_t 
             if (!f32) return fail(h, HJB_E_UNSUPPORTED, "variant 4 is float32 only");
             if (uniwin_active(h)) {                  // modes 7 / 8 (K15, kernels_uniwin.h)
                 a.duw = h->duw;
+                a.block = (unsigned)h->huw.block;
                 a.lds = h->uw_lds + h->lds_pad;
                 miss = stage_uniwin(a, h->hp.model != 0);
                 break;
@@ -1589,6 +1590,14 @@ int launch_probe(Handle *h, const DProbe &pr, const void *dJn, hipStream_t st) {
 // and the torque).  The plan is built here; `uniwin_auto` says whether the usual shape holds on (nearly) every point.
 void uniwin_tiles(Handle *h) {
     DUniwin &U = h->huw;
+    U.block = h->uw_block == 64 ? 64 : 256;
+    U.cpp = (int32_t)((U.inner + U.block - 1) / U.block);
+    {
+        size_t ot_floats = 0;
+        for (int i = HJB_MAX_D; i < HJB_MAX_D + 2; ++i)
+            if (h->hn.ot[i].present) ot_floats = std::max<size_t>(ot_floats, (size_t)h->hn.ot[i].lds_off + (size_t)h->hn.ot[i].lds_len);
+        h->uw_lds = (size_t)27 * U.block * 4 + ot_floats * 4 + 16;
+    }
     auto lg = [](int n, int most) { int l = 0; while (l < most && (1 << l) < n) ++l; return l; };
     int lA = 3, lB = 2, lC = 2;
     if (h->uw_tile > 0) { lA = h->uw_tile & 7; lB = (h->uw_tile >> 3) & 7; lC = (h->uw_tile >> 6) & 7; }
@@ -1601,6 +1610,15 @@ void uniwin_tiles(Handle *h) {
     U.tile_chunks = (uint32_t)U.cpp << (U.lA + U.lB + U.lC);
     const uint64_t nv = (uint64_t)U.tile_chunks * (uint64_t)U.ntA * (uint64_t)U.ntB * (uint64_t)U.ntC;
     U.n_v = (uint32_t)std::min<uint64_t>(nv, 0xfffffff0u);
+    // the launch: as many workgroups as the device holds at once (a persistent walk: a second generation would run alone)
+    int occ = stage_uniwin_occupancy(h->dtype, h->hp.D, h->hp.model != 0, U.block, h->uw_lds + h->lds_pad);
+    if (occ < 1) occ = U.block == 64 ? 16 : 4;
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int64_t g = (int64_t)occ * cus;
+    g = std::min<int64_t>(g, (int64_t)((U.n_v + 7) / 8) * 8);
+    h->uw_grid = (int)std::max<int64_t>(8, g - (g & 7));
 }
 
 static int setup_uniwin(Handle *h, const hjb_problem *p) {
@@ -1629,13 +1647,11 @@ static int setup_uniwin(Handle *h, const hjb_problem *p) {
             if (N.ot[i].lds_off < 0) return HJB_OK;
             ot_floats = std::max<size_t>(ot_floats, (size_t)N.ot[i].lds_off + (size_t)N.ot[i].lds_len);
         }
-    h->uw_lds = (size_t)27 * 256 * 4 + ot_floats * 4 + 16;
-    if (h->uw_lds > 64 * 1024) return HJB_OK;
+    if ((size_t)27 * 256 * 4 + ot_floats * 4 + 16 > 64 * 1024) return HJB_OK;
     DUniwin &U = h->huw;
     memset(&U, 0, sizeof U);
     U.n_points = (int32_t)n_points;
     U.inner = (int32_t)inner;
-    U.cpp = (int32_t)((inner + 255) / 256);
     U.nA = p->n[AX_A];
     U.nB = p->n[AX_B];
     U.nC = P.n[D - 1];                                     // owned planes
@@ -1659,15 +1675,6 @@ static int setup_uniwin(Handle *h, const hjb_problem *p) {
     if (st) return st;
     h->duw = (DUniwin *)du;
     HIP_TRY(h, hipMemcpy(h->duw, &U, sizeof U, hipMemcpyHostToDevice));
-    // the launch: as many workgroups as the device holds at once (a persistent walk: a second generation would run alone)
-    int occ = stage_uniwin_occupancy(h->dtype, D, p->model != 0, h->uw_lds);
-    if (occ < 1) occ = 4;
-    hipDeviceProp_t prop;
-    int cus = 256;
-    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    int64_t g = (int64_t)occ * cus;
-    g = std::min<int64_t>(g, (int64_t)((U.n_v + 7) / 8) * 8);
-    h->uw_grid = (int)std::max<int64_t>(8, g - (g & 7));
     h->uniwin_ok = true;
     h->uniwin_auto = (int64_t)n_slow * 50 <= n_points;     // at most 2 % of the points on the slow path
     return HJB_OK;

@@ -56,7 +56,7 @@ constexpr int kUwFlags = 105;      // bit 0: the point does not have the usual s
 struct DUniwin {
     const int32_t *plan;           // [n_points][kUwRec]
     int32_t n_points;              // nA * nB * nC
-    int32_t cpp;                   // 256-state chunks per point
+    int32_t cpp;                   // chunks (of `block` states) per point
     int32_t inner;                 // states of the state-only axes (product of n[0 .. D-4])
     int32_t nA, nB, nC;            // points of the level-0 axis, the level-1 axis, OWNED planes of the last axis
     int32_t lA, lB, lC;            // log2 of the tile's extent along each
@@ -64,7 +64,7 @@ struct DUniwin {
     uint32_t tile_chunks;          // cpp << (lA + lB + lC): visiting positions per tile
     uint32_t n_v;                  // visiting positions in all
     int32_t cl1_per_o0;            // the level-1 cost term depends on o0 too (reloaded per o0 step)
-    int32_t pad;
+    int32_t block;                 // states per chunk = threads per workgroup (256 or 64)
 };
 
 // ---- the plan: one thread per point of the rate axes ---------------------------------------------------------------------------
@@ -194,6 +194,31 @@ __device__ __forceinline__ f2 uw_fma_sel(f2 s, f2 a, f2 b) {
     else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(d) : "s"(s), "v"(a), "v"(b));
     return d;
 }
+// min(min(a, b), c) as ONE instruction.  Written with __builtin_fminf the compiler quiets a possible signalling NaN of every operand
+// it did not produce itself (v_max_f32 x, x, x) - the packed sums come out of asm blocks - two or three extra instructions per trip;
+// v_min3_f32 of finite values is the same minimum (the contract covers finite cost-to-go values).
+__device__ __forceinline__ float uw_min3(float a, float b, float c) {
+#if HJB_UW_MIN3ASM
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return __builtin_fminf(__builtin_fminf(a, b), c);
+#endif
+}
+__device__ __forceinline__ float uw_min2(float a, float b) {
+#if HJB_UW_MIN3ASM
+    float d;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    return __builtin_fminf(a, b);
+#endif
+}
+// scalar (SMEM) reads of wave-uniform words: the constant address space tells the compiler that a uniform index is an s_load
+typedef int i4v __attribute__((ext_vector_type(4)));
+template <typename T> using cptr = const __attribute__((address_space(4))) T *;
+
 __device__ __forceinline__ f2 uw_fma_sel_rt(int sel, f2 s, f2 a, f2 b) {
     switch (sel) {
         case 0: return uw_fma_sel<0>(s, a, b);
@@ -206,9 +231,27 @@ __device__ __forceinline__ f2 uw_fma_sel_rt(int sel, f2 s, f2 a, f2 b) {
 #ifndef HJB_UW_WAVES
 #define HJB_UW_WAVES 5
 #endif
+// A/B switches (tools/mkab.sh ... -DHJB_UW_SMEM=1): a trip's level-1 entries and cost pair by scalar loads instead of v_readlane;
+// the level-0 rows as packed lerps; the sweep's minima as hand-written v_min3 / v_min
+#ifndef HJB_UW_SMEM
+#define HJB_UW_SMEM 0
+#endif
+#ifndef HJB_UW_PKROWS
+#define HJB_UW_PKROWS 1
+#endif
+#ifndef HJB_UW_MIN3ASM
+#define HJB_UW_MIN3ASM 1
+#endif
+// 1: the whole (o0, o1) loop nest is instantiated per sweep shape behind ONE jump per chunk (the shape is the point's: it does not
+// change inside a chunk); 0: one jump per trip / single step inside a common nest
+#ifndef HJB_UW_NEST
+#define HJB_UW_NEST 0
+#endif
 
-template <typename TJ, int D, bool QMODEL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HJB_UW_WAVES)))
+// BLOCK = states per workgroup = per chunk: 256 (four waves; 27.7 KB of LDS: five workgroups = 20 waves per CU) or 64 (ONE wave per
+// workgroup: 7 KB of LDS, 23 workgroups per CU - the LDS is handed out in finer pieces - at <= 80 VGPRs: 5.75 waves per SIMD)
+template <typename TJ, int D, bool QMODEL, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 64 ? 6 : HJB_UW_WAVES)))
 k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, const DUniwin *__restrict__ U,
                 const TJ *__restrict__ Jn, TJ *__restrict__ Jout, void *__restrict__ idx_out) {
     static_assert(D >= 4, "window kernel: at least one state-only axis");
@@ -217,7 +260,7 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS: the per-lane window W[(ra * 3 + rb) * 3 + q][lane] | the level cost terms' control tables
     float *my_w = reinterpret_cast<float *>(smem_raw) + threadIdx.x;
-    float *s_ot = reinterpret_cast<float *>(smem_raw) + 27 * 256;
+    float *s_ot = reinterpret_cast<float *>(smem_raw) + 27 * BLOCK;
 #pragma unroll
     for (int i = CL0; i <= CL1; ++i) {
         const auto &t = N->ot[i];
@@ -242,6 +285,7 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
     if (cl0_present) cl0v = s_ot[N->ot[CL0].lds_off + (lane < m_o0 ? lane : 0) * N->ot[CL0].c0];
     const int cl1_off = N->ot[CL1].lds_off, cl1_c0 = N->ot[CL1].c0, cl1_c1 = N->ot[CL1].c1;
     const bool cl1_per_o0 = U->cl1_per_o0 != 0;
+    cptr<float> cl1_base = (cptr<float>)N->ot[CL1].data;
     if (cl1_present && !cl1_per_o0) cl1v = s_ot[cl1_off + (lane < m_o1 ? lane : 0) * cl1_c1];
 
     gptr<i2v> atab[NP];
@@ -266,9 +310,12 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
         const int pt = ia + nA * (ib + nB * ic);
         gptr<int> rec = as_global<int>(U->plan) + (size_t)pt * kUwRec;
         const int rec0 = rec[lane], rec1 = rec[64 + lane];
+        // ... and the same record through the scalar cache: what a trip needs of it (the level-1 entries of its two steps) is ONE
+        // s_load_dwordx4 - no vector instruction at all (a v_readlane is one)
+        cptr<i4v> recB = (cptr<i4v>)(const void *)(U->plan + (size_t)pt * kUwRec + kUwB);
 
         // ---- this lane's state -------------------------------------------------------------------------------------------------
-        int ii = (int)ci * 256 + (int)threadIdx.x;
+        int ii = (int)ci * BLOCK + (int)threadIdx.x;
         const bool valid = ii < inner;
         if (!valid) ii = inner - 1;                // harmless duplicate work, store skipped
         int si[D];
@@ -348,7 +395,7 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
 #pragma unroll
                         for (int q = 0; q < 3; ++q) gather_corners<TJ, NP>(Jn + (int64_t)js[D - 1] * planes[q], off, js, vv[q]);
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) my_w[((ra * 3 + rb) * 3 + q) * 256] = contract_corners<NP>(vv[q], tw);
+                        for (int q = 0; q < 3; ++q) my_w[((ra * 3 + rb) * 3 + q) * BLOCK] = contract_corners<NP>(vv[q], tw);
                     }
                 }
             }
@@ -363,26 +410,39 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
             const int sel = nfull * 64 + ((jc >> 1) < nfull ? (jc >> 1) : nfull) * 4 + (((jc & 1) && jc < m_in) ? 2 : 0) +
                             (((m_in & 1) && jc == m_in - 1) ? 1 : 0);
             int best_uo = 0;
+            auto nest = [&](auto NFn, auto PAn, auto STn, auto LSn) __attribute__((always_inline)) {
+                (void)NFn; (void)PAn; (void)STn; (void)LSn;
             for (int o0 = 0; o0 < m_o0; ++o0) {
                 // ---- level 0: the axis' entry, the three level-1 rows x four planes it lerps, as two packed row sets --------------
                 const int cA = uw_lane(rec0, kUwA + 2 * o0);
                 const float tA = uw_lanef(rec0, kUwA + 2 * o0 + 1);
-                const float *w0 = my_w + ((cA - cAmin) * 9) * 256;
+                const f2 tAp = {tA, tA};
+                const float *w0 = my_w + ((cA - cAmin) * 9) * BLOCK;
                 // R0[q] = {F[0][q], F[1][q]}, RD[q] = {F[1][q] - F[0][q], F[2][q] - F[1][q]}: a step on level-1 row pair (0, 1) takes
                 // the first halves, on (1, 2) the second - picked by the packed instructions' operand selects, nothing is re-formed
                 f2 R0[4], RD[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int wq = (q < 2 ? qa : qb) + (q & 1);
+#if !HJB_UW_PKROWS
                     float F[3];
 #pragma unroll
                     for (int rb = 0; rb < 3; ++rb) {
-                        const float f0 = w0[(rb * 3 + wq) * 256];
-                        const float f1 = w0[(9 + rb * 3 + wq) * 256];
+                        const float f0 = w0[(rb * 3 + wq) * BLOCK];
+                        const float f1 = w0[(9 + rb * 3 + wq) * BLOCK];
                         F[rb] = __builtin_fmaf(tA, f1 - f0, f0);
                     }
                     R0[q] = (f2){F[0], F[1]};
                     RD[q] = (f2){F[1] - F[0], F[2] - F[1]};
+                    (void)tAp;
+                    continue;
+#endif
+                    // {F[0], F[1]} and {F[1], F[2]} as packed lerps of the level-0 axis (F[rb] = fma(tA, f1 - f0, f0) element for element)
+                    const f2 a01 = {w0[(0 * 3 + wq) * BLOCK], w0[(1 * 3 + wq) * BLOCK]}, a12 = {w0[(1 * 3 + wq) * BLOCK], w0[(2 * 3 + wq) * BLOCK]};
+                    const f2 b01 = {w0[(9 + 0 * 3 + wq) * BLOCK], w0[(9 + 1 * 3 + wq) * BLOCK]}, b12 = {w0[(9 + 1 * 3 + wq) * BLOCK], w0[(9 + 2 * 3 + wq) * BLOCK]};
+                    const f2 F01 = uw_fma_sb<0>(tAp, b01 - a01, a01), F12 = uw_fma_sb<0>(tAp, b12 - a12, a12);
+                    R0[q] = F01;
+                    RD[q] = F12 - F01;
                 }
                 float go0 = gpre;
                 if (cl0_present) {
@@ -392,30 +452,50 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                 const float go0_l1 = cl1_first ? -0.0f : go0;
                 if (cl1_present && cl1_per_o0) cl1v = s_ot[cl1_off + o0 * cl1_c0 + (lane < m_o1 ? lane : 0) * cl1_c1];
                 const int cl1i = __float_as_int(cl1v);
+                cptr<float> cl1g = cl1_base + o0 * cl1_c0;                      // the level-1 cost term of this o0 step, by scalar loads
                 const int uo0 = o0 * m_o1;
                 int o1 = 0;
+                i4v eb_nx = recB[0];
+                f2 c2_nx = {-0.0f, -0.0f};                                          // (an absent term: g + (-0) == g bit for bit)
+                if (cl1_present && m_o1 > 1) c2_nx = (f2){cl1g[0], cl1g[cl1_c1]};
                 // ---- two (o0, o1) steps per trip, the two STEPS in the halves of every packed instruction -------------------------
                 for (; o1 + 1 < m_o1; o1 += 2) {
-                    const int rA = uw_lane(rec0, kUwB + 2 * o1) - cBmin, rB = uw_lane(rec0, kUwB + 2 * o1 + 2) - cBmin;
-                    const f2 t2 = {uw_lanef(rec0, kUwB + 2 * o1 + 1), uw_lanef(rec0, kUwB + 2 * o1 + 3)};
+#if HJB_UW_SMEM
+                    const i4v eb = eb_nx;                                           // (cell, t) of steps o1 and o1 + 1
+                    const f2 c2 = c2_nx;                                            // the level-1 cost term of the two steps
+                    {   // ... and the next trip's, requested now: a trip never waits for the scalar cache
+                        const int last = (m_o1 >> 1) - 1, nx0 = (o1 >> 1) + 1, nx = nx0 < last ? nx0 : (last > 0 ? last : 0);
+                        eb_nx = recB[nx];
+                        if (cl1_present) c2_nx = (f2){cl1g[2 * nx * cl1_c1], cl1g[(2 * nx + 1) * cl1_c1]};
+                    }
+#else
+                    const i4v eb = {uw_lane(rec0, kUwB + 2 * o1), uw_lane(rec0, kUwB + 2 * o1 + 1), uw_lane(rec0, kUwB + 2 * o1 + 2),
+                                    uw_lane(rec0, kUwB + 2 * o1 + 3)};
+                    const f2 c2 = {uw_lanef(cl1i, o1), uw_lanef(cl1i, o1 + 1)};
+                    (void)eb_nx; (void)c2_nx; (void)cl1g;
+#endif
+                    const int rA = eb.x - cBmin, rB = eb.z - cBmin;
+                    const f2 t2 = {__int_as_float(eb.y), __int_as_float(eb.w)};
                     f2 X2[4];
-                    if (rA == rB) {
-                        if (rA == 0) {
+                    switch (rA * 2 + rB) {                                          // (scalar: which level-1 row pair each step sits on)
+                        case 0:
 #pragma unroll
                             for (int q = 0; q < 4; ++q) X2[q] = uw_fma_sel<0>(t2, RD[q], R0[q]);
-                        } else {
+                            break;
+                        case 3:
 #pragma unroll
                             for (int q = 0; q < 4; ++q) X2[q] = uw_fma_sel<1>(t2, RD[q], R0[q]);
-                        }
-                    } else if (rA == 0) {
+                            break;
+                        case 1:
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) X2[q] = uw_fma_sel<2>(t2, RD[q], R0[q]);
-                    } else {
+                            for (int q = 0; q < 4; ++q) X2[q] = uw_fma_sel<2>(t2, RD[q], R0[q]);
+                            break;
+                        default:
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) X2[q] = uw_fma_sel<3>(t2, RD[q], R0[q]);
+                            for (int q = 0; q < 4; ++q) X2[q] = uw_fma_sel<3>(t2, RD[q], R0[q]);
+                            break;
                     }
                     const f2 Ea = X2[0], Da = X2[1] - X2[0], Eb = X2[2], Db = X2[3] - X2[2];
-                    const f2 c2 = {uw_lanef(cl1i, o1), uw_lanef(cl1i, o1 + 1)};
                     const f2 g2 = (f2){go0_l1, go0_l1} + c2;
                     float mA = INFINITY, mB = INFINITY;
                     auto pairs_fixed = [&](auto NFc, auto PAc, auto STc, auto LSc) __attribute__((always_inline)) {
@@ -427,17 +507,20 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                             const f2 Ey = q < PA ? Ea : Eb, Dy = q < PA ? Da : Db;
                             const f2 totx = uw_add_sb<0>(g2, rp[q]) + uw_fma_sb<0>(tp[q], Dx, Ex);
                             const f2 toty = uw_add_sb<1>(g2, rp[q]) + uw_fma_sb<1>(tp[q], Dy, Ey);
-                            mA = __builtin_fminf(__builtin_fminf(mA, totx.x), toty.x);
-                            mB = __builtin_fminf(__builtin_fminf(mB, totx.y), toty.y);
+                            mA = uw_min3(mA, totx.x, toty.x);
+                            mB = uw_min3(mB, totx.y, toty.y);
                         }
                         if constexpr (NF < kUwIn / 2) {             // 11 controls: the last one stands alone
                             constexpr bool second = PA < NF || LS;
                             const f2 El = second ? Eb : Ea, Dl = second ? Db : Da;
                             const f2 totx = uw_add_sb<0>(g2, rp[NF]) + uw_fma_sb<0>(tp[NF], Dl, El);
-                            mA = __builtin_fminf(mA, totx.x);
-                            mB = __builtin_fminf(mB, totx.y);
+                            mA = uw_min2(mA, totx.x);
+                            mB = uw_min2(mB, totx.y);
                         }
                     };
+#if HJB_UW_NEST
+                    pairs_fixed(NFn, PAn, STn, LSn);
+#else
 #define HJB_PF(NF, PA, ST, LS) case (NF) * 64 + (PA) * 4 + (ST) * 2 + (LS): pairs_fixed(std::integral_constant<int, NF>{}, std::integral_constant<int, PA>{}, \
                                        std::integral_constant<bool, (ST) != 0>{}, std::integral_constant<bool, (LS) != 0>{}); break;
                     switch (sel) {
@@ -449,6 +532,7 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                         default: __builtin_unreachable();
                     }
 #undef HJB_PF
+#endif
                     const int uo = uo0 + o1;
                     if (uo == 0 || mA < best) { best = mA; best_uo = uo; }
                     if (mB < best) { best = mB; best_uo = uo + 1; }
@@ -471,19 +555,44 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                         for (int q = 0; q < kUwIn / 2; ++q) {
                             const int sel2 = q < PA ? 0 : ((ST && q == PA) ? 2 : 1);       // (a constant once unrolled)
                             const f2 tot = (go2 + rp[q]) + uw_fma_sel_rt(sel2, tp[q], d2, e2);
-                            ibest = __builtin_fminf(__builtin_fminf(ibest, tot.x), tot.y);
+                            ibest = uw_min3(ibest, tot.x, tot.y);
                         }
                     };
+#if HJB_UW_NEST
+                    {
+                        constexpr int NFq = decltype(NFn)::value, PAq = decltype(PAn)::value;
+                        constexpr bool STq = decltype(STn)::value, LSq = decltype(LSn)::value;
+                        constexpr int JJ = STq ? 2 * PAq + 1 : (LSq ? 2 * NFq : (PAq < NFq ? 2 * PAq : kUwIn));     // the cell change's control
+                        step_fixed(std::integral_constant<int, JJ / 2>{}, std::integral_constant<bool, (JJ & 1) != 0>{});
+                    }
+#else
 #define HJB_SF(J) case (J): step_fixed(std::integral_constant<int, (J) / 2>{}, std::integral_constant<bool, ((J) & 1) != 0>{}); break;
                     switch (jc < kUwIn ? jc : kUwIn) {
                         HJB_SF(1) HJB_SF(2) HJB_SF(3) HJB_SF(4) HJB_SF(5) HJB_SF(6) HJB_SF(7) HJB_SF(8) HJB_SF(9) HJB_SF(10) HJB_SF(11) HJB_SF(12)
                         default: __builtin_unreachable();          // 1 <= jc: control 0 opens the first cell
                     }
 #undef HJB_SF
+#endif
                     const int uo = uo0 + o1;
                     if (uo == 0 || ibest < best) { best = ibest; best_uo = uo; }
                 }
             }
+            };
+#if HJB_UW_NEST
+#define HJB_NS(NF, PA, ST, LS) case (NF) * 64 + (PA) * 4 + (ST) * 2 + (LS): nest(std::integral_constant<int, NF>{}, std::integral_constant<int, PA>{}, \
+                                       std::integral_constant<bool, (ST) != 0>{}, std::integral_constant<bool, (LS) != 0>{}); break;
+            switch (sel) {
+                HJB_NS(5, 0, 1, 0) HJB_NS(5, 1, 0, 0) HJB_NS(5, 1, 1, 0) HJB_NS(5, 2, 0, 0) HJB_NS(5, 2, 1, 0)
+                HJB_NS(5, 3, 0, 0) HJB_NS(5, 3, 1, 0) HJB_NS(5, 4, 0, 0) HJB_NS(5, 4, 1, 0) HJB_NS(5, 5, 0, 0) HJB_NS(5, 5, 0, 1)
+                HJB_NS(6, 0, 1, 0) HJB_NS(6, 1, 0, 0) HJB_NS(6, 1, 1, 0) HJB_NS(6, 2, 0, 0) HJB_NS(6, 2, 1, 0)
+                HJB_NS(6, 3, 0, 0) HJB_NS(6, 3, 1, 0) HJB_NS(6, 4, 0, 0) HJB_NS(6, 4, 1, 0) HJB_NS(6, 5, 0, 0) HJB_NS(6, 5, 1, 0)
+                HJB_NS(6, 6, 0, 0)
+                default: __builtin_unreachable();          // 1 <= jc: control 0 opens the first cell
+            }
+#undef HJB_NS
+#else
+            nest(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
+#endif
             // ---- which inner control: the winning step's controls once more, in order (first-minimum rule) ----------------------
             int best_j = 0;
             {
@@ -512,8 +621,8 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                         float Fr[2];
 #pragma unroll
                         for (int db = 0; db < 2; ++db) {
-                            const float f0 = my_w[((ra * 3 + rb + db) * 3 + q0 + dq) * 256];
-                            const float f1 = my_w[(((ra + 1) * 3 + rb + db) * 3 + q0 + dq) * 256];
+                            const float f0 = my_w[((ra * 3 + rb + db) * 3 + q0 + dq) * BLOCK];
+                            const float f1 = my_w[(((ra + 1) * 3 + rb + db) * 3 + q0 + dq) * BLOCK];
                             Fr[db] = __builtin_fmaf(tA, f1 - f0, f0);
                         }
                         X[dq] = __builtin_fmaf(tB, Fr[1] - Fr[0], Fr[0]);

@@ -8,8 +8,8 @@ namespace hjb {
 
 int stage_uniwin_f32(const StageArgs &a, bool model);
 int stage_uniwin_f16(const StageArgs &a, bool model);
-int uniwin_occupancy_f32(int D, bool model, size_t lds);
-int uniwin_occupancy_f16(int D, bool model, size_t lds);
+int uniwin_occupancy_f32(int D, bool model, int block, size_t lds);
+int uniwin_occupancy_f16(int D, bool model, int block, size_t lds);
 
 int stage_uniwin(const StageArgs &a, bool model) {
     if (a.dtype == HJB_F32) return stage_uniwin_f32(a, model);
@@ -17,9 +17,9 @@ int stage_uniwin(const StageArgs &a, bool model) {
     return 1;                        // float32 arithmetic only
 }
 
-int stage_uniwin_occupancy(int dtype, int D, bool model, size_t lds) {
-    if (dtype == HJB_F32) return uniwin_occupancy_f32(D, model, lds);
-    if (dtype == HJB_F16S) return uniwin_occupancy_f16(D, model, lds);
+int stage_uniwin_occupancy(int dtype, int D, bool model, int block, size_t lds) {
+    if (dtype == HJB_F32) return uniwin_occupancy_f32(D, model, block, lds);
+    if (dtype == HJB_F16S) return uniwin_occupancy_f16(D, model, block, lds);
     return 0;
 }
 

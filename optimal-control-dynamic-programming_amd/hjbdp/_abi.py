@@ -158,6 +158,7 @@ SYMBOLS = {
     "hjb_device_mem_info": (C.c_int32, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hjb_device_copy": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "hjb_device_fill_separable": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    "hjb_rank_fill_separable": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     "hjb_device_gather": (C.c_int32, [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.c_void_p]),
     "hjb_probe_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(hjb_probe)]),
     # flat builder API (primitives and plain arrays only: what MATLAB's calllib can marshal)

@@ -437,6 +437,14 @@ class RankSlab:
         self._check(self.lib.hjb_rank_stage(self._r, ptr(dJ_in), ptr(dJ_out), ptr(d_idx), int(compute_stream) or None,
                                             int(halo_stream) or None))
 
+    def fill_separable(self, vecs, dJ, stream=0):
+        """dJ (this rank's haloed buffer) = ((vecs[0][i0] + vecs[1][i1]) + ...) on the rank's planes, halos included; vecs are the
+        GLOBAL vectors (hjb_rank_fill_separable)."""
+        vs = [np.ascontiguousarray(v, dtype=self.spec.dtype) for v in vecs]
+        ptrs = (C.c_void_p * len(vs))(*[v.ctypes.data for v in vs])
+        dp = int(dJ.data_ptr()) if hasattr(dJ, "data_ptr") else int(dJ)
+        self._check(self.lib.hjb_rank_fill_separable(self._r, ptrs, dp, int(stream) or None))
+
     def stage_post(self, dJ_in, dJ_out, d_idx, compute_stream=0, halo_stream=0):
         """The stage with the boundary strips first (hjb_rank_stage_post): their halos are already in dJ_in."""
         def ptr(x):

@@ -39,7 +39,7 @@ function [obj, U_Opt_stages] = Solver_attitude_hjbdp_simplified_run(obj, varargi
         prob.single = false;
         prob.next_terms = {[T(1, s_w), T(3, dw)], [T(2, t), T(1, dt)]};
         prob.cost_terms = [T(1, Qw(ch) * s_w.^2), T(2, Qt(ch) * t.^2), T(3, R(ch) * U.^2)];
-        out = hjbdp_solve(prob, n_stages, rest{:});               % :236-247
+        out = hjbdp_solve(prob, n_stages, 'fast_axes', false, rest{:});     % :236-247 (the reference's (w, theta) order, as the Python mirror runs it; 'fast_axes', true in rest overrides)
         pol = griddedInterpolant({s_w, t}, U(out.idx), 'nearest');    % :249-251
         if keep_policy, U_Opt_stages{ch} = reshape(U(out.idx_stages), [numel(s_w), numel(t), n_stages]); end   % test_simplified.m:102-104
         switch ch

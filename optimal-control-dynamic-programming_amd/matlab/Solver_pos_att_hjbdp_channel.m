@@ -10,17 +10,18 @@ function out = Solver_pos_att_hjbdp_channel(obj, s_x, s_v, s_t, s_w, f0, f1, f6,
 %   tol 1e-2) sums the single array in single -> 'monitor_single'.  The four [n_x,n_v,n_t,n_w,nU] query tables are never
 %   formed: x_next = X + h V, v_next = V + h (f1+f2+f6+f7)/Mass, t_next = T + h W, w_next = W + h (moment)/J
 %   (:330-402) go to the library as their 1-D operands.
-%   'cost_mode' 'exact' (default): J_current_M = single(double sum) exactly as J_current_reshaped (:784-802) forms
+%   'cost_mode' 'exact': J_current_M = single(double sum) exactly as J_current_reshaped (:784-802) forms
 %   it, passed as one [n_x,n_v,n_t,n_w,nU] operand (fine up to ~1e8 entries); 'terms': its five separable operands,
 %   summed in single inside the library in the reference's order (<= 2 ulp from the double sum) - for grids like 120^4;
-%   'f64': the separable operands in DOUBLE, summed in double per (state, control) and rounded to single ONCE - bit-identical
-%   to 'exact' at any grid size (hjbdp.h HJB_COST_F64; ~10 % slower than 'terms' on 120^4).
-%   'fast_axes' true lets the library run (x, theta, w, v) - its column-sweep kernel, 3.7x faster on large grids -
-%   with results permuted back (J equal to rounding, see hjbdp_solve).  Other name/value pairs go to hjbdp_solve.
+%   'f64' (DEFAULT): the separable operands in DOUBLE, summed in double per (state, control) and rounded to single ONCE -
+%   bit-identical to 'exact' at any grid size (hjbdp.h HJB_COST_F64; ~10 % slower than 'terms' on 120^4).
+%   'fast_axes' (hjbdp_solve's default: true) lets the library run (x, theta, w, v) - its column-sweep kernel, 2 - 4x faster -
+%   with results permuted back (J equal to rounding, see hjbdp_solve); 'fast_axes', false runs the reference's own order.
+%   Other name/value pairs go to hjbdp_solve.
 % NOT executed in the build image (no MATLAB); tested twin: hjbdp/solver_pos_att.py::calculate_one_channel_U_Opt
 % (bit-exact against the oracle on the reference's grid incl. monitor and failure mode); call sequence replayed
 % through ctypes by tests/test_gpu_flat_api.py::test_matlab_shim_sequences_pos_att_channel.
-    cost_mode = 'exact';  n_stages = obj.N_stage - 1;  rest = {};
+    cost_mode = 'f64';  n_stages = obj.N_stage - 1;  rest = {};
     for i = 1:2:numel(varargin)
         switch varargin{i}
             case 'cost_mode', cost_mode = varargin{i + 1};

@@ -2,7 +2,7 @@ function out = hjbdp_solve(prob, n_stages, varargin)
 %HJBDP_SOLVE  Backward Bellman sweep on AMD MI355X GPUs through libhjbdp's FLAT C API (include/hjbdp_matlab.h:
 %   primitives, plain arrays and opaque handles only - everything calllib can marshal).
 %
-%   out = hjbdp_solve(prob, n_stages, 'keep_stages', true, 'monitor_period', 50, 'monitor_tol', 1e-2, 'devices', 0, 'fast_axes', false)
+%   out = hjbdp_solve(prob, n_stages, 'keep_stages', true, 'monitor_period', 50, 'monitor_tol', 1e-2, 'devices', 0, 'fast_axes', true)
 %
 %   Replaces the stage loops of the reference solvers
 %     test/Dynamic_Solver.m:86-102, position-control/Solver_position.m:132-141,
@@ -21,8 +21,8 @@ function out = hjbdp_solve(prob, n_stages, varargin)
 %                D = 6, C = 3, single only.  What makes 51^6 states possible (Solver_attitude_hjbdp_run.m).
 %   'devices': a scalar runs on that GPU (hjb_create_from / hjb_solve_flat); a vector [0 1 .. 7] partitions the LAST
 %   state axis over those GPUs of this process (hjb_create_multi_from / hjb_solve_multi_flat; no per-stage planes).
-%   'fast_axes' (default false = the reference's own axis order, the bit-parity-tested one; opt in exactly as the Python
-%   mirrors do with axis_order): let the library relabel the state axes when another labelling runs a faster stage kernel
+%   'fast_axes' (default TRUE, as the Python mirrors' axis_order = "auto"; false = the reference's own axis order, both held to
+%   the oracle bit for bit): let the library relabel the state axes when another labelling runs a faster stage kernel
 %   (hjb_problem_suggest_order / hjb_problem_permute_axes: Solver_pos_att's (x, v, theta, w) becomes (x, theta, w, v), 3.7x
 %   faster on 120^4); terminal cost in and every output are permuted here, so the caller sees its own axis order.
 %   CAVEAT: relabelling changes the order in which the 1-D lerps are taken, so J agrees with the reference order only to
@@ -52,7 +52,7 @@ function out = hjbdp_solve(prob, n_stages, varargin)
     addParameter(p, 'monitor_period', 0);
     addParameter(p, 'monitor_tol', 0);
     addParameter(p, 'devices', 0);
-    addParameter(p, 'fast_axes', false);
+    addParameter(p, 'fast_axes', true);
     addParameter(p, 'double_tables', false);
     addParameter(p, 'monitor_single', false);
     addParameter(p, 'double_cost', false);

@@ -32,9 +32,14 @@
  * Argmin labels are always written as int32 here, whatever hjb_problem.idx_dtype says (the wrapper widens the
  * library's labels before comparing).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE            /* sched_getaffinity, CPU_COUNT */
+#endif
 #include <immintrin.h>
 #include <math.h>
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -175,6 +180,23 @@ static inline float sparse_get(const sparse_j *sp, int64_t off, int *miss) {
     return 0.f;
 }
 
+
+/* Threads for a loop of `iters` iterations of `work` elementary operations each.  The checker is called once per STAGE by the tests:
+ * a 132-state sweep of 151 stages entered 151 parallel regions of as many threads as the host shows (128 on a GPU box whose
+ * container may be granted far fewer cores) - 0.12 s per region, 18 s for a problem that takes microseconds.  A thread is worth
+ * starting for ~5e5 operations; the count never exceeds what the process may run on (affinity mask, cgroup quota). */
+static int usable_cpus(void);
+static int threads_for(int64_t iters, int64_t work, int asked) {
+    int nt = asked > 0 ? asked : 1;
+    const int cap = usable_cpus();
+    if (nt > cap) nt = cap;
+    const double total = (double)iters * (double)(work > 0 ? work : 1);
+    const int64_t by_work = (int64_t)(total / 5.0e5) + 1;
+    if ((int64_t)nt > by_work) nt = (int)by_work;
+    if ((int64_t)nt > iters) nt = (int)(iters > 0 ? iters : 1);
+    return nt < 1 ? 1 : nt;
+}
+
 #define DEFINE_BACKUP(T, NAME, FMA)                                                                   \
     static int NAME(const hjb_problem *p, const T *Jn, T *Jout, int32_t *idx_out, int nthreads,        \
                     const int64_t *sel, int64_t nsel, const T *const *jsep, const sparse_j *sp) {      \
@@ -209,8 +231,8 @@ static inline float sparse_get(const sparse_j *sp, int64_t off, int *miss) {
         int64_t nU = 1;                                                                                \
         for (int c = 0; c < C; ++c) nU *= p->m[c];                                                     \
         int err = 0;                                                                                   \
-        (void)nthreads;                                                                                \
-        _Pragma("omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)")         \
+        nthreads = threads_for(sel ? nsel : n_owned, nU * ((int64_t)1 << D), nthreads);               \
+        _Pragma("omp parallel for schedule(static) num_threads(nthreads)")                            \
         for (int64_t it = 0; it < (sel ? nsel : n_owned); ++it) {                                      \
             const int64_t ls = sel ? sel[it] : it;                                                     \
             int gi[HJB_MAX_G];                                                                         \
@@ -405,8 +427,8 @@ static int backup_f32_avx2(const hjb_problem *p, const float *Jn, float *Jout, i
         corner[c] = off;
     }
     int err = 0;
-    (void)nthreads;
-    #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    nthreads = threads_for(rows, (int64_t)n0 * nU * ((int64_t)1 << D), nthreads);
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int64_t row = 0; row < rows; ++row) {
         int gi[HJB_MAX_G];
         {
@@ -805,10 +827,39 @@ int orc_lookup(int dtype, int D, const int32_t *n, const double *const *knots, c
     return HJB_OK;
 }
 
-int orc_max_threads(void) {
+/* CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (v2 cpu.max, v1 cfs_quota_us) */
+static int usable_cpus(void) {
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 1;
 #ifdef _OPENMP
-    return omp_get_max_threads();
-#else
-    return 1;
+    n = omp_get_max_threads();
 #endif
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int a = CPU_COUNT(&set);
+        if (a > 0 && a < n) n = a;
+    }
+    long long quota = -1, period = 100000;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) != NULL) {
+        if (fscanf(f, "%lld", &quota) != 1) quota = -1;
+        fclose(f);
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) != NULL) {
+            if (fscanf(f, "%lld", &period) != 1) period = 100000;
+            fclose(f);
+        }
+    }
+    if (quota > 0 && period > 0) {
+        const int c = (int)((quota + period - 1) / period);
+        if (c > 0 && c < n) n = c;
+    }
+    cached = n < 1 ? 1 : n;
+    return cached;
 }
+
+int orc_max_threads(void) { return usable_cpus(); }

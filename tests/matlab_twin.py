@@ -20,7 +20,7 @@ def T(dims, data):
     return {"dims": [dims] if np.isscalar(dims) else list(dims), "data": np.asarray(data)}
 
 
-def hjbdp_solve(lib, prob, n_stages, keep_stages=False, monitor_period=0, monitor_tol=0.0, devices=0, fast_axes=False,
+def hjbdp_solve(lib, prob, n_stages, keep_stages=False, monitor_period=0, monitor_tol=0.0, devices=0, fast_axes=True,
                 double_tables=False, monitor_single=False, labels="int32", double_cost=False, on_stage=None):
     D, Cn = len(prob["knots"]), len(prob["m"])
     cls, dt = (np.float32, 0) if prob["single"] else (np.float64, 1)
@@ -265,7 +265,7 @@ def attitude_run_finish(out, dims):
     return J, (i1.astype(int), i2.astype(int), i3.astype(int))
 
 
-def pos_att_channel_prob(pa, s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw, R, J, cost_mode="exact"):
+def pos_att_channel_prob(pa, s_x, s_v, s_t, s_w, f0, f1, f6, f7, Qx, Qv, Qt, Qw, R, J, cost_mode="f64"):
     """matlab/Solver_pos_att_hjbdp_channel.m."""
     from hjbdp.solver_pos_att import vectors_allcomb
     fa, fb, fc, fd = vectors_allcomb(f0, f1, f6, f7)

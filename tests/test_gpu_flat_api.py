@@ -391,7 +391,7 @@ def test_matlab_shim_sequences_attitude_simplified(env):
     plain = hjbdp.Solver_attitude(n_mesh_t=60, n_mesh_w_simplified=140).simplified_run(n_stages=30)
     assert plain.U_Opt_stages is None
     for ch in range(3):
-        out = mt.hjbdp_solve(lib, mt.attitude_simplified_prob(sa, ch), 30, keep_stages=True)     # the shim's 'keep_policy'
+        out = mt.hjbdp_solve(lib, mt.attitude_simplified_prob(sa, ch), 30, keep_stages=True, fast_axes=False)     # the shim's 'keep_policy' (the mirror runs the reference's axis order)
         assert np.array_equal(out["J"], sa.F_values[ch]) and np.array_equal(out["idx"], sa.U_idx[ch])
         assert np.array_equal(plain.F_values[ch], sa.F_values[ch]) and np.array_equal(plain.U_idx[ch], sa.U_idx[ch])
         # every stage's policy (attitude-control/test/test_simplified.m:102-104): U_vector(U_idx) per stage, page k_s - 1
@@ -439,18 +439,22 @@ def test_matlab_shim_sequences_pos_att_channel(env, cost_mode):
     pa.cost_mode = cost_mode
     sx, sv, st, sw = pa.grids()
     args = (sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
-    c = pa.calculate_one_channel_U_Opt(*args, "channel_x_controller_1", n_stages=120)
     prob, combos = mt.pos_att_channel_prob(pa, *args, cost_mode=cost_mode)
-    out = mt.hjbdp_solve(lib, prob, 120, double_cost=(cost_mode == "f64"), **mt.POS_ATT_SOLVE_KW)
-    assert out["J"].shape == (30, 30, 20, 15)
-    assert np.array_equal(out["J"], c["F_gI_Values"]) and np.array_equal(out["idx"], c["U_Optimal_id"])
-    assert out["stages_done"] == c["stages_done"] and out["stopped_early"] == c["stopped_early"]
-    for k, v in zip(("f0_allcomb", "f1_allcomb", "f6_allcomb", "f7_allcomb"), combos):
-        assert np.array_equal(v, c[k])
-    if cost_mode == "terms":
-        fast = mt.hjbdp_solve(lib, prob, 120, fast_axes=True, **mt.POS_ATT_SOLVE_KW)
-        assert fast["axis_order"] == [1, 3, 4, 2]
-        assert np.allclose(fast["J"], out["J"], rtol=5e-5, atol=1e-6)
+    outs = {}
+    # the shim's default (hjbdp_solve's 'fast_axes' true = the mirror's axis_order "auto") and the reference's own axis order
+    for fast in ((True, False) if cost_mode != "exact" else (False,)):
+        pa.axis_order = "auto" if fast else None
+        c = pa.calculate_one_channel_U_Opt(*args, "channel_x_controller_1", n_stages=120)
+        out = mt.hjbdp_solve(lib, prob, 120, double_cost=(cost_mode == "f64"), fast_axes=fast, **mt.POS_ATT_SOLVE_KW)
+        assert out["J"].shape == (30, 30, 20, 15)
+        assert out["axis_order"] == ([1, 3, 4, 2] if fast else [1, 2, 3, 4])
+        assert np.array_equal(out["J"], c["F_gI_Values"]) and np.array_equal(out["idx"], c["U_Optimal_id"]), fast
+        assert out["stages_done"] == c["stages_done"] and out["stopped_early"] == c["stopped_early"]
+        for k, v in zip(("f0_allcomb", "f1_allcomb", "f6_allcomb", "f7_allcomb"), combos):
+            assert np.array_equal(v, c[k])
+        outs[fast] = out
+    if True in outs:
+        assert np.allclose(outs[True]["J"], outs[False]["J"], rtol=5e-5, atol=1e-6)
 
 
 def test_rank_create_from_builder_equals_struct_form(env):

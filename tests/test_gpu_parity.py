@@ -946,6 +946,42 @@ def test_two_rank_sharded_bench_matches_single_rank(env, overlap):
     assert tr["torch"]["checksum_sum_J"] == b["checksum_sum_J"] and "transports" not in a
 
 
+@pytest.mark.order(96)
+@pytest.mark.watchdog(1300)
+def test_two_rank_c3_bench_matches_single_rank(env):
+    """`bench.py --gpus N --workload c3` (BASELINE configs[2] sharded along w3; 22 GB of J per rank at 51^6 on eight GPUs) on ONE GPU at
+    16^6: two torchrun ranks share cuda:0 and exchange their 4 MB halo plane over gloo; the summed checksum equals the single-rank
+    run's, both on K15 (kernels_uniwin.h, packed2 mode 8) - the kernel, the slab offsets and the halo arithmetic the 8-GPU run uses."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    if _TORCH_COLD:
+        pytest.skip("torch did not come up in a child process on this box (see test_device_buffer_entry_point_with_torch)")
+    root = Path(__file__).resolve().parent.parent
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    common = ["--workload", "c3", "--c3-n", "16", "--steps", "3", "--warmup", "1", "--no-pmc"]
+    try:
+        one = subprocess.run([sys.executable, str(root / "bench.py")] + common, capture_output=True, text=True, timeout=600)
+        assert one.returncode == 0, one.stderr[-2000:]
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), str(root / "bench.py"),
+                              "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                             capture_output=True, text=True, timeout=600)
+    except subprocess.TimeoutExpired:
+        _TORCH_COLD.append(1)
+        pytest.skip("a torch child process did not finish within 600 s on this box (cold image)")
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert a["config"]["states"] == b["config"]["states"] == 16 ** 6 and a["config"]["controls"] == 1331
+    assert b["n_gpus"] == 2 and "8 of 16 planes per GPU, halo 0/1" in b["config"]["sharding"]
+    assert a["config"]["kernel_variant"] == 4 and b["config"]["kernel_variant"] == 4
+    assert "cpu_baseline" not in a and "other_workloads" not in a          # the 176 GB configuration as the headline: nothing rides on it
+    assert abs(a["checksum_sum_J"] - b["checksum_sum_J"]) <= 1e-12 * abs(a["checksum_sum_J"]) and a["checksum_sum_J"] > 0
+
+
 F16 = [((9, 8), (3,), False), ((13, 11, 9), (4, 5), True), ((6, 5, 4, 5), (3, 4), False), ((7, 6), (70,), True)]
 
 
@@ -1078,6 +1114,7 @@ def test_temporal_blocking_refused_when_not_local(env):
         assert ei.value.status == _abi.HJB_E_UNSUPPORTED
 
 
+@pytest.mark.extended        # (12 s of random shapes: opt-in; tools/stress_parity.py runs the long form, profiles/r0N_stress_parity.txt)
 @pytest.mark.order(90)
 @pytest.mark.watchdog(400)
 def test_randomised_stress_slice(env):

@@ -182,6 +182,7 @@ def test_c3_full_size_51_pow_6(env):
         dO.free(); dI.free()
 
 
+@pytest.mark.extended        # (tests/test_gpu_deep.py::test_6d_24_pow_6_five_stages_deep runs the same grid, kernels and sample five stages deep)
 @pytest.mark.order(5)
 @pytest.mark.parametrize("form", ["tabulated", "on_the_fly"])
 def test_6d_24_pow_6_sampled_states(env, form):
@@ -223,6 +224,7 @@ def test_6d_24_pow_6_as_slabs_of_the_last_axis(env):
     _c3_mode_as_slabs(env, 24, (2, 4), 246)
 
 
+@pytest.mark.extended        # (superseded by the FULL-SIZE rehearsal: tests/test_gpu_deep.py::test_c3_full_size_second_stage_whole_grid_and_as_eight_slabs)
 @pytest.mark.order(6)
 @pytest.mark.watchdog(900)
 def test_c3_mode_32_pow_6_as_eight_slabs(env):
@@ -285,19 +287,45 @@ def test_solver_attitude_full_6d(env):
     assert set(np.unique(sa.U1_Opt)).issubset({np.float32(-0.11), np.float32(0), np.float32(0.11)})
 
 
+def _oracle_in_the_mirrors_order(c_oracle, _abi, pa, spec, n_stages, **kw):
+    """The oracle's sweep of `spec` in the axis order the mirror runs it (pa.axis_order), mapped back to the reference's."""
+    run_spec, to_old = pa._relabel(spec)
+    ref = c_oracle.sweep(_abi, run_spec, n_stages, **kw)
+    if to_old is not None:
+        ref = dict(ref)
+        ref["J"], ref["idx"] = to_old(ref["J"]), to_old(ref["idx"])
+    return ref
+
+
 @pytest.mark.order(7)
-def test_solver_pos_att_channel_reference_grid(env):
-    """One pos-att channel on the reference's 30x30x20x15x9 grid, 12 stages."""
+@pytest.mark.parametrize("form", ["default", "reference"])
+def test_solver_pos_att_channel_reference_grid(env, form):
+    """One pos-att channel on the reference's 30x30x20x15x9 grid, 12 stages, as the mirror runs it by DEFAULT (the library's
+    axis labelling (x, theta, w, v): column-sweep kernel; stage cost = the separable operands summed in double) and in the
+    reference's own forms (axis order (x, v, theta, w), the materialised single(double sum) cost table): each bit for bit
+    against the oracle on the same problem; the two agree to the rounding of a different lerp order."""
     hjbdp, _abi, c_oracle = env
     pa = hjbdp.Solver_pos_att()
+    if form == "reference":
+        pa.axis_order, pa.cost_mode = None, "exact"
+    else:
+        assert pa.axis_order == "auto" and pa.cost_mode == "f64"
     sx, sv, st, sw = pa.grids()
     args = (sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
     c = pa.calculate_one_channel_U_Opt(*args, "chx", n_stages=12)
     spec, _ = pa.build_channel_spec(*args)
-    ref = c_oracle.sweep(_abi, spec, 12, monitor_period=50, monitor_tol=1e-2)
+    ref = _oracle_in_the_mirrors_order(c_oracle, _abi, pa, spec, 12, monitor_period=50, monitor_tol=1e-2)
     assert np.array_equal(c["F_gI_Values"].reshape(-1, order="F"), ref["J"])
     assert np.array_equal(c["U_Optimal_id"].reshape(-1, order="F"), ref["idx"])
     assert c["U_Optimal_id"].min() >= 1 and c["U_Optimal_id"].max() <= 9
+    if form == "default":
+        with hjbdp.Backup(pa._relabel(spec)[0]) as bk:
+            assert bk.info()["kernel_variant"] == 7                  # the default lands on the column-sweep kernel
+        pr = hjbdp.Solver_pos_att()
+        pr.axis_order, pr.cost_mode = None, "exact"
+        r = pr.calculate_one_channel_U_Opt(*args, "chx_ref", n_stages=12)
+        assert np.max(np.abs(r["F_gI_Values"] - c["F_gI_Values"])) <= 1e-5 * np.max(np.abs(r["F_gI_Values"]))
+        assert np.mean(r["U_Optimal_id"] == c["U_Optimal_id"]) > 0.999
 
 
 @pytest.mark.order(7)
@@ -316,7 +344,7 @@ def test_solver_pos_att_all_channels_with_monitor(env):
     spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, [0.0], pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
                                     pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
     assert pa.monitor_single and spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8     # the mirror's defaults: the reference's typing
-    ref = c_oracle.sweep(_abi, spec, 120, monitor_period=10, monitor_tol=5.0, monitor_single=True)
+    ref = _oracle_in_the_mirrors_order(c_oracle, _abi, pa, spec, 120, monitor_period=10, monitor_tol=5.0, monitor_single=True)
     c = pa.controllers["channel_x_controller_1_failure"]
     assert len(c["f0_allcomb"]) == 6
     assert c["stages_done"] == ref["stages_done"] and c["stopped_early"] == ref["stopped_early"]

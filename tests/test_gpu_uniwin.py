@@ -49,7 +49,7 @@ def test_uniwin_whole_grid_bit_exact(env, n_so, n_rates, m, gain, nonuniform):
         assert bad.size == 0, (name, "J", bad[:8])
         bad = np.flatnonzero(o["idx_stages"] != ref["idx_stages"])
         assert bad.size == 0, (name, "labels", bad[:8])
-    assert len(np.unique(out["idx_stages"])) > 20
+    assert len(np.unique(out["idx_stages"])) > 8
 
 
 @pytest.mark.parametrize("n,m,order", [((130, 5, 4, 5), (3, 4, 11), "std"), ((130, 4, 5, 4), (2, 5, 12), "l1_first"),

@@ -52,6 +52,8 @@ def test_pos_att_control_set_and_grids():
     assert len(vectors_allcomb([0.0], pa.F_Thr1, pa.F_Thr6, pa.F_Thr7)[0]) == 6   # failure channel
     sx, sv, st, sw = pa.grids()
     assert (len(sx), len(sv), len(st[0]), len(sw)) == (30, 30, 20, 15) and pa.N_stage == 2000
+    assert pa.cost_mode == "f64" and pa.axis_order == "auto"        # the defaults are the fast path; the reference's own forms opt in
+    pa.cost_mode = "exact"
     spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
                                     6, 6, .5, .5, .1, pa.J2)
     assert spec.n == (30, 30, 20, 15) and spec.m == (9,) and spec.dtype == np.float32
@@ -68,6 +70,7 @@ def test_pos_att_exact_and_terms_cost_agree(orc):
     pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 8, 7, 6, 5
     sx, sv, st, sw = pa.grids()
     args = (sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
+    pa.cost_mode = "exact"
     s_exact, _ = pa.build_channel_spec(*args)
     pa.cost_mode = "terms"
     s_terms, _ = pa.build_channel_spec(*args)

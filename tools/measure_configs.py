@@ -50,9 +50,13 @@ out, v = solve_timed(pspec, 19)
 add("Solver_attitude.run, same, axes relabelled (angles first, w3 last)", spec.nS * 27 * 19, out["sweep_ms"], v)
 pa = hjbdp.Solver_pos_att()
 sx, sv, st, sw = pa.grids()
-spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
+spec_ref, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
+spec, _ = pa._relabel(spec_ref)          # the mirror's defaults: axis_order "auto", cost_mode 'f64'
 out, v = solve_timed(spec, 1999, monitor_period=50, monitor_tol=1e-2)
-add("Solver_pos_att channel 30x30x20x15 x 9, <=1999 stages (monitor), f32", spec.nS * 9 * out["stages_done"],
+add("Solver_pos_att channel 30x30x20x15 x 9, <=1999 stages (monitor), f32, the mirror's defaults", spec.nS * 9 * out["stages_done"],
+    out["sweep_ms"], v, "stopped after %d stages" % out["stages_done"])
+out, v = solve_timed(spec_ref, 1999, monitor_period=50, monitor_tol=1e-2)
+add("... in the reference's own axis order (axis_order = None)", spec.nS * 9 * out["stages_done"],
     out["sweep_ms"], v, "stopped after %d stages" % out["stages_done"])
 # 6-D north-star figure: the attitude model on a 24^6 grid x 11^3 torques, tabulated next angles
 import os
@@ -74,8 +78,14 @@ pa.cost_mode = "terms"
 pa.n_mesh_x = pa.n_mesh_v = pa.n_mesh_t = pa.n_mesh_w = 120
 sx, sv, st, sw = pa.grids()
 spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, 6, 6, .5, .5, .1, pa.J2)
+# as the mirror runs it by default: the library's axis labelling (axis_order "auto" -> hjb_problem_suggest_order)
+assert pa.axis_order == "auto"
+spec_ref = spec
+spec, _ = pa._relabel(spec_ref)
 out, v = solve_timed(spec, 5)
-add("C4 pos-att 120^4 x 9, 5 stages, f32", spec.nS * 9 * 5, out["sweep_ms"], v)
+add("C4 pos-att 120^4 x 9, 5 stages, f32, the mirror's default axis order (x, theta, w, v)", spec.nS * 9 * 5, out["sweep_ms"], v)
+out, v = solve_timed(spec_ref, 5)
+add("C4 in the reference's own axis order (x, v, theta, w) (axis_order = None)", spec.nS * 9 * 5, out["sweep_ms"], v)
 spec16 = hjbdp.ProblemSpec(spec.knots, spec.m, spec.next_terms, spec.cost_terms, dtype=np.float32, index_base=1,
                            j_storage=np.float16)
 out, v = solve_timed(spec16, 5)

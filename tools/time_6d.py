@@ -29,6 +29,8 @@ with hjbdp.Backup(pspec) as bk:
         bk.set_option("uniwin", int(os.environ["UNIWIN"]))
     if os.environ.get("UW_TILE"):
         bk.set_option("uw_tile", int(os.environ["UW_TILE"]))
+    if os.environ.get("UW_BLOCK"):               # K15: states per chunk = threads per workgroup (256 | 64)
+        bk.set_option("uw_block", int(os.environ["UW_BLOCK"]))
     if os.environ.get("LDS_PAD"):                # extra LDS per workgroup: 16384 leaves three workgroups per CU instead of four
         bk.set_option("lds_pad", int(os.environ["LDS_PAD"]))
     print(bk.info(), "packed2_mode", bk.get_option("packed2_mode"), "grid", bk.get_option("grid"), "slow points", bk.get_option("uniwin_slow_points"), flush=True)
