@@ -49,6 +49,7 @@ sys.path.insert(0, str(ROOT))
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (= f32-input MFMA rate)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_CYCLES_PER_WAVE_INSTR = 2.0   # wave64 on a SIMD-32 (MI355X_MICROARCH.md; profiles/r02_valu_rate.json)
+MEASURED_PK_FMA_TFLOPS = 118.1     # what v_pk_fma_f32 delivers on this part at four waves per SIMD (tools/valu_rate.hip, profiles/r05_valu_rate.json)
 KERNEL_OF_VARIANT = {7: "k_backup_colsweep", 6: "k_backup_row", 5: "k_backup_tabled", 4: "k_backup_packed2",
                      2: "k_backup_packed", 1: "k_backup_nested", 3: "k_backup_ctrlsplit", 0: "k_backup_generic"}
 # how the stage kernel of each workload is told apart in one rocprofv3 pass over all of them (demangled names)
@@ -57,8 +58,8 @@ KERNEL_OF_VARIANT = {7: "k_backup_colsweep", 6: "k_backup_row", 5: "k_backup_tab
 KERNEL_FILTER = {"c4": ("k_backup_colsweep<float, float", None), "c5": ("k_backup_colsweep", "k_backup_colsweep<float, float"),   # rocprofv3 leaves the binary16 name mangled
                  "c2": ("k_backup_packed2<float, 3", None),
                  # the 6-D grids: K15 (csrc/kernels_uniwin.h) where its structure holds, else K3's window modes
-                 "6d": (("k_backup_uniwin<float, 6, false>", "k_backup_packed2<float, 6, 5>", "k_backup_packed2<float, 6, 2>"), None),      # tabulated next angles
-                 "c3": (("k_backup_uniwin<float, 6, true>", "k_backup_packed2<float, 6, 6>", "k_backup_packed2<float, 6, 3>"), None)}      # on-the-fly model
+                 "6d": (("k_backup_uniwin<float, 6, false", "k_backup_packed2<float, 6, 5>", "k_backup_packed2<float, 6, 2>"), None),      # tabulated next angles
+                 "c3": (("k_backup_uniwin<float, 6, true", "k_backup_packed2<float, 6, 6>", "k_backup_packed2<float, 6, 3>"), None)}      # on-the-fly model
 EXTRA_STEPS = {"c5": 20, "c2": 20, "6d": 4, "c3": 2}
 C3_NEEDS_GIB = 190          # J_k+1 + J_k (70.4 GB each) + uint16 labels (35.2 GB) = 176 GB resident
 
@@ -457,6 +458,9 @@ def main():
             if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES"):
                 wait_frac = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
         rf = {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
+              # the same achieved rate against what the packed-fma pipe measurably delivers (the spec peak is not reachable by any
+              # instruction mix on this part: profiles/r05_valu_rate.json) - beside `frac`, not instead of it
+              "frac_of_measured_pk_fma_peak": tflops / MEASURED_PK_FMA_TFLOPS, "measured_pk_fma_peak": MEASURED_PK_FMA_TFLOPS,
               "traffic": traffic, "traffic_uncorrected": traffic_raw, "kernel": kname, "avg_launch_ms": launch_ms,
               "alg_flop_per_backup": f_alg(sp.D),
               "alg_bytes_per_launch": bytes_state * res["states_rank"], "valu_issue_util": valu_util,
@@ -474,6 +478,7 @@ def main():
             rf["alg_flops_credit_TFLOPs"] = tflops
             rf["achieved"] = None if valu_util is None else valu_util * PEAK_FP32_TFLOPS
             rf["frac"] = valu_util
+            rf["frac_of_measured_pk_fma_peak"] = None
             rf["frac_is"] = "valu_issue_util (F_alg credit %.1f TFLOP/s exceeds the vector peak: shared interpolation work)" % tflops
         return rf
 

@@ -231,21 +231,23 @@ __device__ __forceinline__ f2 uw_fma_sel_rt(int sel, f2 s, f2 a, f2 b) {
 #ifndef HJB_UW_WAVES
 #define HJB_UW_WAVES 5
 #endif
-// A/B switches (tools/mkab.sh ... -DHJB_UW_SMEM=1): a trip's level-1 entries and cost pair by scalar loads instead of v_readlane;
-// the level-0 rows as packed lerps; the sweep's minima as hand-written v_min3 / v_min
+// A/B switches (tools/mkab.sh ... -DHJB_UW_SMEM=1; measured in profiles/r06_k15_ab_round1.log, _round2.log): a trip's level-1
+// entries and cost pair by scalar loads instead of v_readlane (-7 % vector instructions, +50 % scalar: 1 - 4 % SLOWER); the level-0
+// rows as packed lerps and the sweep's minima as hand-written v_min3 / v_min (fewer instructions, equal time within 1 %): all off.
+// What pays is HJB_UW_NEST: -8 % (the scalar stream of a trip - a 25-way compare tree - was as long as half its vector stream)
 #ifndef HJB_UW_SMEM
 #define HJB_UW_SMEM 0
 #endif
 #ifndef HJB_UW_PKROWS
-#define HJB_UW_PKROWS 1
+#define HJB_UW_PKROWS 0
 #endif
 #ifndef HJB_UW_MIN3ASM
-#define HJB_UW_MIN3ASM 1
+#define HJB_UW_MIN3ASM 0
 #endif
 // 1: the whole (o0, o1) loop nest is instantiated per sweep shape behind ONE jump per chunk (the shape is the point's: it does not
 // change inside a chunk); 0: one jump per trip / single step inside a common nest
 #ifndef HJB_UW_NEST
-#define HJB_UW_NEST 0
+#define HJB_UW_NEST 1
 #endif
 
 // BLOCK = states per workgroup = per chunk: 256 (four waves; 27.7 KB of LDS: five workgroups = 20 waves per CU) or 64 (ONE wave per

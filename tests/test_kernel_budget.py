@@ -251,3 +251,52 @@ def test_table_kernel_32bit_form_budget():
     body = text[text.index("\n_ZN3hjb17k_backup_tabled32IffLi4E") + 1:]
     body = body[:body.index("s_endpgm")]
     assert len(re.findall(r"global_load_dwordx2", body)) >= 8 + 4, "corner pairs and table entries through global loads"
+
+
+def test_uniwin_occupancy_budget():
+    """K15 (kernels_uniwin.h, variant 4 modes 7 / 8) exists for its fifth wave per SIMD: every instantiation of the 256-state form
+    within 96 VGPRs with NOTHING in scratch, the sweep's weights and control costs as SCALAR operands of the packed instructions
+    (the register budget rests on it), and no scratch or LDS traffic inside the two-step trip (loop depth >= 3: chunk > o0 > trip)."""
+    import tempfile
+    import __graft_entry__ as g
+    with tempfile.TemporaryDirectory() as d:
+        asm = "%s/uw.s" % d
+        r = subprocess.run([HIPCC, *g.HIPCC_FLAGS, "-S", "--cuda-device-only", "-I%s/include" % ROOT, "-o", asm,
+                            "%s/optimal-control-dynamic-programming_amd/csrc/stage_uniwin_f32.hip" % ROOT], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        text = open(asm).read()
+    got = dict((m[0], (int(m[1]), int(m[2]), int(m[3]))) for m in re.findall(
+        r"\.name:\s+_ZN3hjb15k_backup_uniwinIf(Li\dELb[01]ELi\d+)E\S*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?"
+        r"\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text))
+    assert sorted(got) == sorted("Li%dELb%dELi%d" % (dd, q, b) for (dd, q) in ((4, 0), (5, 0), (6, 0), (6, 1)) for b in (64, 256)), sorted(got)
+    for key, (scratch, vgprs, spills) in got.items():
+        assert scratch == 0 and spills == 0 and vgprs <= 96, (key, got[key])          # five waves per SIMD, nothing spilled
+    body = text[text.index("\n_ZN3hjb15k_backup_uniwinIfLi6ELb1ELi256E") + 1:]
+    body = body[:body.index("s_endpgm")]
+    # the sweep: packed fma / add with a scalar register pair as an operand, operand selects written out
+    assert len(re.findall(r"v_pk_fma_f32 v\[\d+:\d+\], s\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\] op_sel", body)) >= 200
+    assert len(re.findall(r"v_pk_add_f32 v\[\d+:\d+\], v\[\d+:\d+\], s\[\d+:\d+\] op_sel", body)) >= 200
+    # the two-step trips are the INNERMOST depth-3 loops (chunk > o0 > trip; the slow per-backup path nests deeper): nothing but
+    # vector / scalar arithmetic, lane reads and branches in them
+    active, header, deep, n_trip_loops = False, None, [], 0
+    lines = body.splitlines()
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", lines[i])
+        if m:
+            c = m.group(2) or ""
+            while i + 1 < len(lines) and re.match(r"^\s+;", lines[i + 1]):        # the label's comment continues on the next lines
+                i += 1
+                c += lines[i]
+            if "Inner Loop Header: Depth=3" in c:
+                active, header = True, m.group(1).lstrip(".L")
+                n_trip_loops += 1
+            elif header and ("Header=%s Depth=3" % header) in c:
+                active = True
+            else:
+                active = False
+        elif active and re.search(r"\b(scratch_|ds_read|ds_write|global_load|global_store|s_load|buffer_)", lines[i]):
+            deep.append(lines[i].strip())
+        i += 1
+    assert n_trip_loops >= 20, n_trip_loops                 # one per sweep shape (the loop nest is instantiated per shape)
+    assert not deep, deep[:5]
