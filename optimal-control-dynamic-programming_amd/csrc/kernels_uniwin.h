@@ -249,6 +249,11 @@ __device__ __forceinline__ f2 uw_fma_sel_rt(int sel, f2 s, f2 a, f2 b) {
 #ifndef HJB_UW_NEST
 #define HJB_UW_NEST 1
 #endif
+// > 0 (with HJB_UW_NEST): a second instantiation of every nest for THIS level-1 control count with the trips of an o0 step written
+// out (lane reads at constant lanes, no loop bookkeeping) - the attitude grids' 11; other counts take the loop
+#ifndef HJB_UW_UNROLL_O1
+#define HJB_UW_UNROLL_O1 0
+#endif
 
 // BLOCK = states per workgroup = per chunk: 256 (four waves; 27.7 KB of LDS: five workgroups = 20 waves per CU) or 64 (ONE wave per
 // workgroup: 7 KB of LDS, 23 workgroups per CU - the LDS is handed out in finer pieces - at <= 80 VGPRs: 5.75 waves per SIMD)
@@ -412,8 +417,10 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
             const int sel = nfull * 64 + ((jc >> 1) < nfull ? (jc >> 1) : nfull) * 4 + (((jc & 1) && jc < m_in) ? 2 : 0) +
                             (((m_in & 1) && jc == m_in - 1) ? 1 : 0);
             int best_uo = 0;
-            auto nest = [&](auto NFn, auto PAn, auto STn, auto LSn) __attribute__((always_inline)) {
+            auto nest = [&](auto NFn, auto PAn, auto STn, auto LSn, auto MO1n) __attribute__((always_inline)) {
                 (void)NFn; (void)PAn; (void)STn; (void)LSn;
+                constexpr int MO1 = decltype(MO1n)::value;                 // the level-1 control count when it is a constant of this copy (else 0)
+                const int mo1 = MO1 > 0 ? MO1 : m_o1;
             for (int o0 = 0; o0 < m_o0; ++o0) {
                 // ---- level 0: the axis' entry, the three level-1 rows x four planes it lerps, as two packed row sets --------------
                 const int cA = uw_lane(rec0, kUwA + 2 * o0);
@@ -461,7 +468,8 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                 f2 c2_nx = {-0.0f, -0.0f};                                          // (an absent term: g + (-0) == g bit for bit)
                 if (cl1_present && m_o1 > 1) c2_nx = (f2){cl1g[0], cl1g[cl1_c1]};
                 // ---- two (o0, o1) steps per trip, the two STEPS in the halves of every packed instruction -------------------------
-                for (; o1 + 1 < m_o1; o1 += 2) {
+#pragma unroll
+                for (; o1 + 1 < mo1; o1 += 2) {
 #if HJB_UW_SMEM
                     const i4v eb = eb_nx;                                           // (cell, t) of steps o1 and o1 + 1
                     const f2 c2 = c2_nx;                                            // the level-1 cost term of the two steps
@@ -540,7 +548,7 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                     if (mB < best) { best = mB; best_uo = uo + 1; }
                 }
                 // ---- the last step of an odd count: one step, two CONTROLS in the halves -----------------------------------------
-                if (o1 < m_o1) {
+                if (o1 < mo1) {
                     const int rA = uw_lane(rec0, kUwB + 2 * o1) - cBmin;
                     const float t1 = uw_lanef(rec0, kUwB + 2 * o1 + 1);
                     float X[4];
@@ -582,7 +590,22 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
             };
 #if HJB_UW_NEST
 #define HJB_NS(NF, PA, ST, LS) case (NF) * 64 + (PA) * 4 + (ST) * 2 + (LS): nest(std::integral_constant<int, NF>{}, std::integral_constant<int, PA>{}, \
-                                       std::integral_constant<bool, (ST) != 0>{}, std::integral_constant<bool, (LS) != 0>{}); break;
+                                       std::integral_constant<bool, (ST) != 0>{}, std::integral_constant<bool, (LS) != 0>{}, HJB_NS_MO1{}); break;
+#if HJB_UW_UNROLL_O1 > 0
+#define HJB_NS_MO1 std::integral_constant<int, HJB_UW_UNROLL_O1>
+            if (m_o1 == HJB_UW_UNROLL_O1) {
+                switch (sel) {
+                    HJB_NS(5, 0, 1, 0) HJB_NS(5, 1, 0, 0) HJB_NS(5, 1, 1, 0) HJB_NS(5, 2, 0, 0) HJB_NS(5, 2, 1, 0)
+                    HJB_NS(5, 3, 0, 0) HJB_NS(5, 3, 1, 0) HJB_NS(5, 4, 0, 0) HJB_NS(5, 4, 1, 0) HJB_NS(5, 5, 0, 0) HJB_NS(5, 5, 0, 1)
+                    HJB_NS(6, 0, 1, 0) HJB_NS(6, 1, 0, 0) HJB_NS(6, 1, 1, 0) HJB_NS(6, 2, 0, 0) HJB_NS(6, 2, 1, 0)
+                    HJB_NS(6, 3, 0, 0) HJB_NS(6, 3, 1, 0) HJB_NS(6, 4, 0, 0) HJB_NS(6, 4, 1, 0) HJB_NS(6, 5, 0, 0) HJB_NS(6, 5, 1, 0)
+                    HJB_NS(6, 6, 0, 0)
+                    default: __builtin_unreachable();
+                }
+            } else
+#undef HJB_NS_MO1
+#endif
+#define HJB_NS_MO1 std::integral_constant<int, 0>
             switch (sel) {
                 HJB_NS(5, 0, 1, 0) HJB_NS(5, 1, 0, 0) HJB_NS(5, 1, 1, 0) HJB_NS(5, 2, 0, 0) HJB_NS(5, 2, 1, 0)
                 HJB_NS(5, 3, 0, 0) HJB_NS(5, 3, 1, 0) HJB_NS(5, 4, 0, 0) HJB_NS(5, 4, 1, 0) HJB_NS(5, 5, 0, 0) HJB_NS(5, 5, 0, 1)
@@ -592,8 +615,9 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                 default: __builtin_unreachable();          // 1 <= jc: control 0 opens the first cell
             }
 #undef HJB_NS
+#undef HJB_NS_MO1
 #else
-            nest(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
+            nest(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{}, std::integral_constant<int, 0>{});
 #endif
             // ---- which inner control: the winning step's controls once more, in order (first-minimum rule) ----------------------
             int best_j = 0;

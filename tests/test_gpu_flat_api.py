@@ -301,9 +301,10 @@ def test_flat_api_reference_typing_of_pos_att(env):
     lib = hjbdp.load_library()
     pa = hjbdp.Solver_pos_att()
     pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 14, 9, 8, 7
+    pa.cost_mode = "terms"                  # single cost operands (this test is about the TABLE typing; the double cost: test_gpu_types.py)
     sx, sv, st, sw = pa.grids()
     spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7, pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
-    assert spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8
+    assert spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8 and spec.cost_dtype is None
     b = C.c_void_p()
     n = (C.c_int32 * 4)(*spec.n)
     m = (C.c_int32 * 1)(*spec.m)

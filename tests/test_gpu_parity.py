@@ -218,6 +218,7 @@ def test_rowwise_variant_pos_att_slab_and_f16(env):
     from problems import random_terminal
     pa = hjbdp.Solver_pos_att()
     pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 70, 6, 5, 10
+    pa.cost_mode = "exact"                  # the materialised single(double sum) table (a float64-cost problem runs on kernels 5 / 7 only)
     sx, sv, st, sw = pa.grids()
     spec, _ = pa.build_channel_spec(sx, sv, st[0], sw, pa.F_Thr0, pa.F_Thr1, pa.F_Thr6, pa.F_Thr7,
                                     pa.Qx1, pa.Qv1, pa.Qt1, pa.Qw1, pa.R1, pa.J2)
