@@ -446,7 +446,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
             uniwin_tiles(h);
             HIP_TRY(h, hipSetDevice(h->device));
             HIP_TRY(h, hipDeviceSynchronize());
-            HIP_TRY(h, hipMemcpy(h->duw, &h->huw, sizeof(DUniwin), hipMemcpyHostToDevice));
+            { DUniwin tmp = h->huw; if (!h->uw_claim) tmp.counters = nullptr; HIP_TRY(h, hipMemcpy(h->duw, &tmp, sizeof(DUniwin), hipMemcpyHostToDevice)); }
             choose_launch(h);
         }
         if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the captured launches carry the old LDS size
@@ -486,6 +486,19 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         choose_launch(h);
         return HJB_OK;
     }
+    if (!strcmp(key, "uw_claim")) {         // K15: 1 = dynamic claim of the chunk walk's positions (default), 0 = fixed stride (A/B)
+        if (!h->uniwin_ok) return fail(h, HJB_E_UNSUPPORTED, "uw_claim: K15 only");
+        if (value != 0 && value != 1) return fail(h, HJB_E_INVALID, "uw_claim must be 0 or 1");
+        static_assert(sizeof(void *) == 8, "");
+        h->uw_claim = (int)value;
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipDeviceSynchronize());
+        DUniwin tmp = h->huw;
+        if (!h->uw_claim) tmp.counters = nullptr;
+        HIP_TRY(h, hipMemcpy(h->duw, &tmp, sizeof(DUniwin), hipMemcpyHostToDevice));
+        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        return HJB_OK;
+    }
     if (!strcmp(key, "uw_tile") || !strcmp(key, "uw_block")) {
         // K15: log2 tile extents lA + 8 * lB + 64 * lC of the chunk walk (0: default) / states per chunk = threads per workgroup (256, 64)
         const bool tile = !strcmp(key, "uw_tile");
@@ -495,7 +508,7 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         uniwin_tiles(h);
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipDeviceSynchronize());
-        HIP_TRY(h, hipMemcpy(h->duw, &h->huw, sizeof(DUniwin), hipMemcpyHostToDevice));
+        { DUniwin tmp = h->huw; if (!h->uw_claim) tmp.counters = nullptr; HIP_TRY(h, hipMemcpy(h->duw, &tmp, sizeof(DUniwin), hipMemcpyHostToDevice)); }
         choose_launch(h);
         return HJB_OK;
     }
@@ -526,6 +539,7 @@ int32_t hjb_get_option(hjb_handle hh, const char *key, int64_t *value) {
     else if (!strcmp(key, "uniwin")) *value = uniwin_active(h) ? 1 : 0;               // the form in effect
     else if (!strcmp(key, "uniwin_ok")) *value = h->uniwin_ok ? 1 : 0;
     else if (!strcmp(key, "uw_block")) *value = h->uniwin_ok ? h->huw.block : 0;
+    else if (!strcmp(key, "uw_claim")) *value = h->uniwin_ok ? h->uw_claim : 0;
     else if (!strcmp(key, "uniwin_slow_points")) *value = h->uniwin_ok ? h->uniwin_slow : -1;
     else if (!strcmp(key, "grid")) *value = h->grid;
     else if (!strcmp(key, "idx_bytes")) *value = h->idx_bytes;

@@ -109,6 +109,7 @@ struct Handle {
     int uniwin_slow = 0;          // points of the plan that take the slow path
     int uw_tile = 0;              // option "uw_tile": log2 tile extents lA + 8 * lB + 64 * lC (0: the default 3, 2, 2)
     int uw_grid = 0;
+    int uw_claim = 1;             // option "uw_claim": 1 = the chunk walk's positions are claimed from per-XCD counters, 0 = fixed stride
     int uw_block = 256;           // option "uw_block": states per chunk = threads per workgroup (256 or 64)
     size_t uw_lds = 0;
     DUniwin huw{};

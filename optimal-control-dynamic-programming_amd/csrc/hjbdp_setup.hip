@@ -1470,6 +1470,7 @@ int launch_stage(Handle *h, const void *dJn, void *dJo, void *didx, hipStream_t 
             if (uniwin_active(h)) {                  // modes 7 / 8 (K15, kernels_uniwin.h)
                 a.duw = h->duw;
                 a.block = (unsigned)h->huw.block;
+                if (h->huw.counters) HIP_TRY(h, hipMemsetAsync(h->huw.counters, 0, 8 * 16 * sizeof(uint32_t), st));   // (a memset node under capture)
                 a.lds = h->uw_lds + h->lds_pad;
                 miss = stage_uniwin(a, h->hp.model != 0);
                 break;
@@ -1669,6 +1670,13 @@ static int setup_uniwin(Handle *h, const hjb_problem *p) {
     HIP_TRY(h, hipMemcpy(&n_slow, cnt, sizeof n_slow, hipMemcpyDeviceToHost));
     h->uniwin_slow = n_slow;
     U.plan = (const int32_t *)plan;
+    {   // the per-XCD claim counters of the chunk walk (kernels_uniwin.h): 8 x one 64-byte line, zeroed before every launch
+        void *ctr = nullptr;
+        st = dev_alloc(h, 8 * 16 * sizeof(uint32_t), &ctr);
+        if (st) return st;
+        HIP_TRY(h, hipMemset(ctr, 0, 8 * 16 * sizeof(uint32_t)));
+        U.counters = (uint32_t *)ctr;
+    }
     uniwin_tiles(h);
     void *du = nullptr;
     st = dev_alloc(h, sizeof(DUniwin), &du);

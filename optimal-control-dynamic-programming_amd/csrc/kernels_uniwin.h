@@ -65,6 +65,7 @@ struct DUniwin {
     uint32_t n_v;                  // visiting positions in all
     int32_t cl1_per_o0;            // the level-1 cost term depends on o0 too (reloaded per o0 step)
     int32_t block;                 // states per chunk = threads per workgroup (256 or 64)
+    uint32_t *counters;            // [8][16]: per XCD the next position of its walk (zeroed before every launch); null: static walk
 };
 
 // ---- the plan: one thread per point of the rate axes ---------------------------------------------------------------------------
@@ -299,13 +300,29 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
 #pragma unroll
     for (int a = 0; a < NP; ++a) atab[a] = as_global<i2v>(N->at[a].tab);
 
-    // visiting order (see the header): workgroup b serves XCD b % 8 with the (b % 8)-th contiguous eighth of every grid-sized span
-    unsigned int first_v = blockIdx.x;
-    if ((gridDim.x & 7u) == 0u) first_v = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // visiting order (see the header): workgroup b serves XCD b % 8 with the (b % 8)-th contiguous eighth of every grid-sized span.
+    // The positions are CLAIMED, not strided: a workgroup that is done takes the next position of its XCD's walk from a counter
+    // (one atomic per 256-state chunk).  With a fixed stride the workgroups of an XCD drift apart over the tens of thousands of
+    // chunks each of them sweeps at 51^6, the chunks in flight stop being neighbours and the tile's window slices are fetched
+    // once per chunk instead of once per tile (C3: 7.6 TB of fabric traffic per stage against 0.18 TB algorithmic).
+    __shared__ unsigned int s_claim[2];
+    const unsigned int xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3;          // (the grid is a multiple of 8: hjbdp_setup.hip)
+    uint32_t *claim = U->counters ? U->counters + 16 * xcd : nullptr;
+    unsigned int first_v = xcd * per_xcd + (blockIdx.x >> 3), turn = 0;
     const unsigned int n_v = U->n_v, tile_chunks = U->tile_chunks;
     const int lA = U->lA, lB = U->lB, lC = U->lC;
     const unsigned int ntA = (unsigned int)U->ntA, ntB = (unsigned int)U->ntB;
-    for (unsigned int v = first_v; v < n_v; v += gridDim.x) {
+    for (unsigned int v = first_v;; v += gridDim.x) {
+        if (claim) {
+            if (threadIdx.x == 0) {
+                const unsigned int k = atomicAdd(claim, 1u), span = k / per_xcd;
+                s_claim[turn & 1u] = span * gridDim.x + xcd * per_xcd + (k - span * per_xcd);
+            }
+            __syncthreads();                       // (one barrier per chunk: the slot of turn t is rewritten at turn t + 2, behind barrier t + 1)
+            v = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_claim[turn & 1u]);
+            ++turn;
+        }
+        if (v >= n_v) break;
         // ---- which chunk (all scalar) ---------------------------------------------------------------------------------------
         const unsigned int tile = v / tile_chunks, rem = v - tile * tile_chunks;
         const unsigned int ci = rem >> (lA + lB + lC), p = rem & ((1u << (lA + lB + lC)) - 1u);

@@ -29,6 +29,8 @@ with hjbdp.Backup(pspec) as bk:
         bk.set_option("uniwin", int(os.environ["UNIWIN"]))
     if os.environ.get("UW_TILE"):
         bk.set_option("uw_tile", int(os.environ["UW_TILE"]))
+    if os.environ.get("UW_CLAIM"):               # K15: 0 = fixed-stride chunk walk, 1 = positions claimed from per-XCD counters (default)
+        bk.set_option("uw_claim", int(os.environ["UW_CLAIM"]))
     if os.environ.get("UW_BLOCK"):               # K15: states per chunk = threads per workgroup (256 | 64)
         bk.set_option("uw_block", int(os.environ["UW_BLOCK"]))
     if os.environ.get("LDS_PAD"):                # extra LDS per workgroup: 16384 leaves three workgroups per CU instead of four

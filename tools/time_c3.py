@@ -23,6 +23,8 @@ with hjbdp.Backup(spec) as bk:
         bk.set_option("uniwin", int(os.environ["UNIWIN"]))
     if os.environ.get("UW_TILE"):
         bk.set_option("uw_tile", int(os.environ["UW_TILE"]))
+    if os.environ.get("UW_CLAIM"):               # K15: 0 = fixed-stride chunk walk, 1 = positions claimed from per-XCD counters (default)
+        bk.set_option("uw_claim", int(os.environ["UW_CLAIM"]))
     if os.environ.get("UW_BLOCK"):
         bk.set_option("uw_block", int(os.environ["UW_BLOCK"]))
     print(bk.info(), "packed2_mode", bk.get_option("packed2_mode"), "grid", bk.get_option("grid"), "slow points", bk.get_option("uniwin_slow_points"), flush=True)

@@ -1,6 +1,7 @@
 """Wall time of Solver_pos_att.simplified_run (four channels of the reference's 30x30x20x15x9 grid, <= 1999 stages each with the
 monitor, pos-att/Solver_pos_att.m:197-242) under the mirror's cost / axis-order settings; results of every setting are compared
-with the default's (reference axis order, cost_mode 'exact').  usage: python tools/time_pos_att_run.py"""
+with the reference's own forms (axis order (x, v, theta, w), cost_mode 'exact'); the mirror's DEFAULT since round 6 is
+('f64', 'auto') - the line marked so.  usage: python tools/time_pos_att_run.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "optimal-control-dynamic-programming_amd"))
@@ -22,5 +23,5 @@ for cost_mode, axis_order in (("exact", None), ("f64", None), ("terms", None), (
         base = (J, U)
     dj = float(np.max(np.abs(J - base[0])) / np.max(np.abs(base[0])))
     same = float(np.mean(U == base[1]))
-    print("cost_mode %-6s axis_order %-5s: simplified_run %.1f ms (channels together %.1f ms; stages of channel x: %d); vs the default: max |dJ| / max J %.2e, equal labels %.5f"
-          % (cost_mode, axis_order, best, pa.wall_ms, c["stages_done"], dj, same), flush=True)
+    print("cost_mode %-6s axis_order %-5s%s: simplified_run %.1f ms (channels together %.1f ms; stages of channel x: %d); vs the reference's own forms: max |dJ| / max J %.2e, equal labels %.5f"
+          % (cost_mode, axis_order, " (the mirror's DEFAULT)" if (cost_mode, axis_order) == ("f64", "auto") else "", best, pa.wall_ms, c["stages_done"], dj, same), flush=True)
