@@ -302,6 +302,15 @@ int32_t hjb_device_gather(int32_t device, const void *d_src, int32_t elem_bytes,
 
 /* The whole backward sweep (the `for k` loops of the reference). */
 int32_t hjb_solve(hjb_handle h, const hjb_solve_opts *opts, hjb_result *result);
+/* n independent problems of ONE kernel shape swept side by side with ONE launch per stage for all of them: the four channels of
+ * Solver_pos_att.simplified_run (pos-att/Solver_pos_att.m:197-242: 2.7e5 states each - a stage kernel of one channel is a launch
+ * boundary plus one wave's chain of round trips, and of four such chains on four streams the device runs two at full rate).
+ * Every problem keeps its own terminal cost, outputs, monitor sums / difference / stop decision (a stopped problem drops out of
+ * the launches that follow) and progress callback; its results equal hjb_solve's bit for bit.  Conditions (else
+ * HJB_E_UNSUPPORTED, and the caller sweeps the problems with hjb_solve on threads of their own): n <= 8, one device, every handle
+ * on the column-sweep kernel in its usual form (float32 J, state cost terms + one control term, the one-load form), one group
+ * axis and one cost typing, one n_stages and one monitor_period for all, no per-stage outputs / probe / per-stage progress. */
+int32_t hjb_solve_batch(int32_t n, const hjb_handle *handles, const hjb_solve_opts *const *opts, hjb_result *const *results);
 
 /* Batched evaluation of a gridded function at nq points - what the reference does with the
  * sweep's results: griddedInterpolant({grid vectors}, U_vector(U_idx), 'nearest') policy lookups

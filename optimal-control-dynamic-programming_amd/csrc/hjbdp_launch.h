@@ -12,6 +12,7 @@ struct DNested;
 struct DTabled;
 struct DColSweep;
 struct DUniwin;
+struct DCsBatch;
 
 struct StageArgs {
     unsigned grid = 1, block = 256;
@@ -43,6 +44,7 @@ int stage_tabled(const StageArgs &a);                                           
 int stage_rowwise(const StageArgs &a, bool lean);                                // variant 6
 int stage_colsweep(const StageArgs &a, int gax, int ng, int costform, bool dpp);    // variant 7 (costform: 0 general, 1 fast, 2 fast in float64)
 int stage_colcoop(const StageArgs &a, int gax, int ng, bool fastcost);           // variant 7, cooperative form
+int stage_colsweep_batch(const StageArgs &a, int n, const DCsBatch *dB, uint32_t mask, int parity, int gax, int ng, bool c64);   // variant 7, n problems in one launch
 int stage_tile2d(const StageArgs &a, const void *plan, int K);                   // K9 (several stages per launch)
 int stage_tile2d_plan(int dtype, const DParams *dp, const DTabled *dtb, void *plan, int64_t n_entries);
 

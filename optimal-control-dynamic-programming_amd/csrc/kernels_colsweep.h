@@ -333,372 +333,41 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     (DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 4)))
 k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const DColSweep *__restrict__ CS,
                   const TJ *__restrict__ Jn, TJ *__restrict__ Jout, void *__restrict__ idx_out) {
-    static_assert(sizeof(T) == 4, "float32 arithmetic");
-    constexpr int D = 4, NW = kCsNW, MM = kCsMMax, LANES = DPP ? kCsDppLanes : 64;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    __shared__ f4 s_slots[4][kCsSlots * 2];
-    __shared__ T s_best[4][HJB_CS_DIRECT ? 1 : kCsFlush][HJB_CS_DIRECT ? 1 : 64];
-    __shared__ uint8_t s_idx[4][HJB_CS_DIRECT ? 1 : kCsFlush][HJB_CS_DIRECT ? 1 : 64];      // control numbers (< kCsUMax) as bytes: more steps per flush
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    // ---- hop 1: EVERY scalar of the launch in one batch ------------------------------------------------------------------
-    // A wave's set-up is a chain of dependent loads - launch scalars -> which column -> the column's plan, table entries and cost
-    // terms -> its first rows - and on a small grid, a multi-GPU strip or a short part of a column that chain IS the stage time.
-    // Read where they were used through P / TB / CS, the scalars cost a round trip to the scalar cache EACH (seventeen waits before
-    // the first gather in the round-4 assembly; hipcc sinks a scalar load to its use whatever the source order).  Here: the record
-    // at the head of DColSweep, three loads and ONE wait, by hand.
-    typedef uint32_t u16v __attribute__((ext_vector_type(16)));
-    u16v rA, rB, rC;
-    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx16 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(rA), "=&s"(rB), "=&s"(rC) : "s"(CS) : "memory");      // early clobber: a destination must not take the address registers a later load of the batch reads
-#define CS_REC(i) ((i) < 16 ? rA[(i) & 15] : ((i) < 32 ? rB[(i) & 15] : rC[(i) & 15]))
-#define CS_REC_PTR(TY, i) ((TY)(uintptr_t)((uint64_t)CS_REC(i) | ((uint64_t)CS_REC((i) + 1) << 32)))
-    const int n0 = (int)CS_REC(kRecN0), n1 = (int)CS_REC(kRecN1), n2 = (int)CS_REC(kRecN2), n3 = (int)CS_REC(kRecN3);
-    const unsigned xcd = blockIdx.x & 7u;
-    unsigned cnt = rA[0];
-#pragma unroll
-    for (int x = 1; x < 8; ++x) cnt = xcd == (unsigned)x ? rA[x] : cnt;
-    const int cs_split = (int)CS_REC(kRecSplit), cs_win = (int)CS_REC(kRecWin), cs_xstride = (int)CS_REC(kRecXStride);
-    cptr<int32_t> xcd_tab = as_const<int32_t>(CS_REC_PTR(const int32_t *, kRecXcdIg));
-    const int32_t *const plan_base = CS_REC_PTR(const int32_t *, kRecPlan);
-    const uint32_t g_bytes = CS_REC(kRecGBytes), w_bytes = CS_REC(kRecWBytes), s1_bytes = CS_REC(kRecS1Bytes);
-    const int ncu = (int)CS_REC(kRecNcu), npre_col = (int)CS_REC(kRecNpreCol), npre = (int)CS_REC(kRecNpre);
-    const bool step_uniform = CS_REC(kRecStepUniform) != 0;
-    const void *const a0_tab = CS_REC_PTR(const void *, kRecA0Tab), *const a1_tab = CS_REC_PTR(const void *, kRecA1Tab);
-    const int a0_s0 = (int)CS_REC(kRecA0S0), a0_s2 = (int)CS_REC(kRecA0S2), a0_s3 = (int)CS_REC(kRecA0S3);
-    const int a1_s = (int)CS_REC(kRecA1S1), a1_s2 = (int)CS_REC(kRecA1S2), a1_s3 = (int)CS_REC(kRecA1S3);
-    int32_t *const status = CS_REC_PTR(int32_t *, kRecStatus);
-    const int slab_begin = (int)CS_REC(kRecSlabBegin), halo_lo_p = (int)CS_REC(kRecHaloLo);
-    const uint32_t js1 = CS_REC(kRecJs1), js2 = CS_REC(kRecJs2), js3 = CS_REC(kRecJs3);
-    const int index_base = (int)CS_REC(kRecIndexBase), idx_bytes = (int)CS_REC(kRecIdxBytes);
-#undef CS_REC_PTR
-#undef CS_REC
-    const int chunks = (n0 + LANES - 1) / LANES;
-    // ---- hop 2: which column (see DColSweep::xcd_ig) - branch-free, one table look-up ------------------------------------
-    int i2, i3, chunk, part;
-    {
-        unsigned item = (blockIdx.x >> 3) * 4u + (unsigned)wave;
-        const bool win = cs_win != 0;
-        const unsigned nfull = (unsigned)((GAX == 3) != win ? n2 : n3);      // the axis every XCD walks in full
-        const unsigned per_part = cnt * (unsigned)chunks * nfull;
-        if (item >= per_part * (unsigned)cs_split) return;                    // uniform over the wave
-        part = (int)(item / per_part);                                        // which part of the column (outermost)
-        item -= (unsigned)part * per_part;
-        // win: the XCD owns window-axis indices, the group axis is walked in full, fastest; else it owns group-axis indices
-        const unsigned fast = win ? (unsigned)(GAX == 3 ? n3 : n2) : cnt;      // extent of the fastest index
-        const unsigned lo = item % fast, r = item / fast;
-        chunk = (int)(r % (unsigned)chunks);
-        const unsigned hi = r / (unsigned)chunks;
-        const int look = xcd_tab[xcd * (unsigned)cs_xstride + (win ? hi : lo)];
-        const int ig = win ? (int)lo : look, iw = win ? look : (int)hi;
-        i2 = GAX == 3 ? iw : ig;
-        i3 = GAX == 3 ? ig : iw;
-    }
-    int i0 = chunk * LANES + lane;
-    bool valid = lane < LANES && i0 < n0;                   // this lane carries a state (see the one-load form below)
-    if (!valid) i0 = n0 - 1;                                // halo / tail lanes: duplicate work, no store
-    // ---- hop 3: everything that hangs on (i2, i3), asked for together: the plan's member slots (-> LDS) and this lane's axis-0
-    // entry (vector loads, in flight across the scalar wait), then the plan's header words and the first axis-1 entry (scalar,
-    // one batch by hand) ------------------------------------------------------------------------------------------------
-    cptr<int32_t> pl = as_const<int32_t>(plan_base) + (size_t)(i2 + n2 * i3) * kCsPlanWords;
-    f4 slot_v[(NG * MM * 2 + 63) / 64];
-    {
-        gptr<f4> src = as_global<f4>(plan_base + (size_t)(i2 + n2 * i3) * kCsPlanWords + kCsPI);
-#pragma unroll
-        for (int j = 0; j < (NG * MM * 2 + 63) / 64; ++j)
-            if (lane + 64 * j < NG * MM * 2) slot_v[j] = src[lane + 64 * j];
-    }
-    TabEntry<T> e0v;
-    {
-        const int off = a0_s0 * i0 + a0_s2 * i2 + a0_s3 * i3;
-        e0v.cell = as_global<TabEntry<T>>(a0_tab)[off].cell;
-        e0v.t = as_global<TabEntry<T>>(a0_tab)[off].t;
-    }
-    const int a1_base = a1_s2 * i2 + a1_s3 * i3;
-    cptr<TabEntry<T>> tab1 = as_const<TabEntry<T>>(a1_tab) + a1_base;
-    const int i1b = (int)((int64_t)n1 * part / cs_split), i1e = (int)((int64_t)n1 * (part + 1) / cs_split);   // this wave's steps
-    cptr<TabEntry<T>> tab1n = tab1 + i1b * a1_s;             // entry of the next step
-    u16v hdr, cr0;
-    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-    typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-    u2v ent1;
-    u8v cr1;
-    static_assert(1 + 2 * kCsGMax <= 16 && sizeof(TabEntry<T>) == 8, "plan header in one s_load_dwordx16, a table entry in one dwordx2");
-    static_assert(offsetof(DColSweep, crec) == 192 && kCRecWords == 24, "the cost record follows the launch record");
-    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\ts_load_dwordx16 %2, %6, 0xc0\n\ts_load_dwordx8 %3, %6, 0x100\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(hdr), "=&s"(ent1), "=&s"(cr0), "=&s"(cr1) : "s"(pl), "s"(tab1n), "s"(CS) : "memory");
-#define CS_CREC(i) ((i) < 16 ? cr0[(i) & 15] : cr1[((i) - 16) & 7])
-    int c1n = (int)ent1.x;
-    T t1n = __uint_as_float(ent1.y);
-#pragma unroll
-    for (int j = 0; j < (NG * MM * 2 + 63) / 64; ++j)
-        if (lane + 64 * j < NG * MM * 2) s_slots[wave][lane + 64 * j] = slot_v[j];
-    const int ng = (int)hdr[0] >> 8;                         // groups of this column (<= NG)
-    if ((hdr[0] & 1) && lane == 0) *status = 1;
-    // ---- axis 0: the thread's own (cell, t) for the whole column ------------------------------------------
-    uint32_t voff0;
-    T t0;
-    {
-        const int c0 = e0v.cell;
-        t0 = e0v.t;
-        if (DPP) {
-            // rel = cell - state index takes at most two adjacent values over the wave's states (verified on the host).
-            // kb = the value most states share: lane L loads knot chunk start + L + kb, a state with rel == kb finds its
-            // neighbours in its own lane and the next one.
-            const int rel = c0 - i0;
-            const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
-            const int r0 = __builtin_amdgcn_readfirstlane(rel);                 // lane 0 is always a state
-            const unsigned long long same = __builtin_amdgcn_ballot_w64(valid && rel == r0);
-            int kb = r0;
-            if (2 * __builtin_popcountll(same) < __builtin_popcountll(vm))
-                kb = __builtin_amdgcn_readlane(rel, __builtin_ctzll(vm & ~same));
-            const unsigned long long ex = __builtin_amdgcn_ballot_w64(valid && rel != kb);
-            int knot = chunk * LANES + lane + kb;                               // the knot this lane loads
-            if (ex != 0) {
-                // ONE odd state (a cell clamped at the grid edge, typically): it moves to the spare lane pair behind the
-                // halo lane - lane LANES + 1 takes the state and loads its cell's lower knot, lane LANES + 2 the upper one -
-                // and its old lane stays as the loader its lower neighbour needs.  Every state lane is then regular.
-                const int pe = __builtin_ctzll(ex);
-                const int c0e = __builtin_amdgcn_readlane(c0, pe);
-                const T t0e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t0), pe));
-                if (lane == pe) valid = false;
-                if (lane == LANES + 1) { i0 = chunk * LANES + pe; t0 = t0e; knot = c0e; valid = true; }
-                if (lane == LANES + 2) knot = c0e + 1;
-            }                                                                   // (the host admits no more than one)
-            knot = knot < 0 ? 0 : (knot > n0 - 1 ? n0 - 1 : knot);              // clamped lanes are never referenced
-            voff0 = (uint32_t)knot * (uint32_t)sizeof(TJ);
-        } else {
-            voff0 = (uint32_t)c0 * (uint32_t)sizeof(TJ);
-        }
-    }
-    // byte offset of a corner row = (group's first row: scalar, from the plan) + (window knot w) * w_bytes + this lane's
-    // axis-0 offset + the step's axis-1 row; every group has three valid window knots (the plan keeps windows inside the grid)
-    uint32_t rog[NG];
-    int used[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        rog[g] = hdr[1 + g];
-        used[g] = (int)hdr[1 + kCsGMax + g];
-    }
-    // ---- cost: leading state-only terms that do not change along the column --------------------------------
-    int si[D] = {i0, 0, i2, i3 + slab_begin};
-    const int cjz[HJB_MAX_C] = {0, 0, 0};
-    T gcol = (T)0;
-    double gcol64 = 0.0;                          // C64: the column-constant state terms of the cost in double
-    const bool rec_cost = !C64 && (int)CS_CREC(kCRecNCol) == npre_col;      // every column term is in the record (<= 3)
-    if (rec_cost) {
-        // their values requested together (the descriptors came with the plan header), then the ordered sum
-        T x[3] = {(T)0, (T)0, (T)0};
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (j < npre_col) {
-                const T *d = (const T *)(uintptr_t)((uint64_t)CS_CREC(kCRecTerm + 5 * j) | ((uint64_t)CS_CREC(kCRecTerm + 5 * j + 1) << 32));
-                const int64_t off = (int64_t)(int)CS_CREC(kCRecTerm + 5 * j + 2) * si[0] + (int64_t)(int)CS_CREC(kCRecTerm + 5 * j + 3) * si[2] +
-                                    (int64_t)(int)CS_CREC(kCRecTerm + 5 * j + 4) * si[3];
-                x[j] = as_global<T>(d)[off];
-            }
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (j < npre_col) gcol = (j == 0) ? x[j] : (T)(gcol + x[j]);
-    } else if constexpr (C64) {
-        for (int k = 0; k < npre_col; ++k) {
-            const double x = term_value<double, D>(P->cost64[k], si, cjz);
-            gcol64 = (k == 0) ? x : gcol64 + x;
-        }
-    } else {
-        for (int k = 0; k < npre_col; ++k) {
-            const T x = term_value<T, D>(P->cost[k], si, cjz);
-            gcol = (k == 0) ? x : (T)(gcol + x);
-        }
-    }
-    // Scalar bases: (lower, upper) group row [x (lower, upper) axis-0 neighbour], and ONE 32-bit per-lane byte offset per
-    // (group, window knot), advanced along the column: every gather is `global_load v, v_off, s[base]`, no 64-bit vector
-    // arithmetic.  The bases are opaque to the compiler: the two loads of a corner pair must stay two instructions
-    // (merged into one unaligned 8-byte load they are slower, measured on the row kernel).
-    gptr<char> Jb00 = as_global<char>(Jn), Jb01 = Jb00, Jb11 = Jb00;
-    gptr<char> Jb10 = as_global<char>(reinterpret_cast<const char *>(Jn) + g_bytes);
-    asm volatile("" : "+s"(Jb10));
-    if (!DPP) {
-        Jb01 = as_global<char>(reinterpret_cast<const char *>(Jn) + sizeof(TJ));
-        Jb11 = as_global<char>(reinterpret_cast<const char *>(Jn) + g_bytes + sizeof(TJ));
-        asm volatile("" : "+s"(Jb01));
-        asm volatile("" : "+s"(Jb11));
-    }
-    const uint32_t out_col = (uint32_t)i0 + js2 * (uint32_t)i2 + js3 * (uint32_t)(i3 + halo_lo_p);
-    const uint32_t idx_col = (uint32_t)i0 + (uint32_t)n0 * (uint32_t)n1 * ((uint32_t)i2 + (uint32_t)n2 * (uint32_t)i3);
-    // HJB_CS_DIRECT: per-lane byte offsets of the column's results (J < 4 GiB in this kernel: every gather offset is 32-bit too)
-    const uint32_t out_off = out_col * (uint32_t)sizeof(TJ), idx_off = idx_col * (uint32_t)idx_bytes;
-    typedef __attribute__((address_space(1))) char *gwptr;
-    gwptr Jout_b = (gwptr)Jout, idx_b = (gwptr)idx_out;
-    __builtin_amdgcn_wave_barrier();
+#define CS_BX blockIdx.x
+#include "kernels_colsweep_body.inc"
+#undef CS_BX
+}
 
-    // the axis-0 lerp of one corner row from the value(s) a lane loaded
-    auto xl = [&](T a, T b) -> T {
-        if (DPP) return fma_t<T>(t0, lane_up_minus(a), a);      // a = the knot this lane loaded
-        return fma_t<T>(t0, (T)(b - a), a);                      // a, b = the lower / upper neighbour
-    };
-
-    // ---- the column loop ------------------------------------------------------------------------------------------
-    // Software pipeline in two halves of the group sequence, H0 = groups [0, NGH) and H1 = [NGH, NG): the rows of H1 are
-    // requested before H0 is computed, the rows of the NEXT step's H0 before H1 is computed, so every load has half a
-    // step of arithmetic (times the other waves of the SIMD) to land, and each half keeps its own registers - no
-    // rotation.  Results go to LDS and are written out every kCsFlush steps: on gfx9 loads and stores share one counter
-    // and complete out of order with each other, so a pending store makes every wait for a load a full drain.
-    constexpr int NGH = (NG + 1) / 2;
-    constexpr bool TWO = DPP && sizeof(TJ) == 4 && HJB_CS_ROLL2 != 0;         // two textual steps per loop trip
-    constexpr bool ROLL2 = TWO && HJB_CS_ROLL2 != 2;                          // the copy-free roll (above); HJB_CS_ROLL2 = 2: two steps, round-4 registers (debugging)
-    constexpr int NA = ROLL2 ? 2 : 1;                        // ROLL2: two sets of row pairs, each in turn gather destination / new A rows and old A rows
-    f2 A[NA][NG][NW];
-#pragma unroll
-    for (int q = 0; q < NA; ++q)
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int w = 0; w < NW; ++w) A[q][g][w] = f2{(T)0, (T)0};
-    constexpr int LPK = DPP ? 2 : 4;                         // gathers per window knot of a group
-    int ngs = ng;                                            // the group count as a value of the current step (below)
-    uint32_t rlo[NG][2][NW], rhi[NG][2][NW];
-    // Window knot 1 serves both slot pairs of a group, knot 0 only pair 0's slots, knot 2 only pair 1's: a knot no slot
-    // uses is neither gathered nor lerped.  How many gathers each half issues is therefore a property of the column.
-    const int pairmask = (1 << (MM / 2)) - 1;
-    int nH0 = 0, nH1 = 0;
-    // (A group the column does not have - fewer distinct cells at the grid's edge - has no slot in use and repeats group
-    // 0's rows: its knot 1 is gathered all the same, which costs two L1 hits and saves a test per group and half.)
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int n = LPK * (1 + ((used[g] & pairmask) != 0) + ((used[g] & (pairmask << (MM / 2))) != 0));
-        if (g < NGH) nH0 += n; else nH1 += n;
-    }
-    // operands of a scalar jump (wait_gathers_n): pinned to scalar registers whatever pipe the compiler summed them on (under
-    // scalar-register pressure it moves uniform arithmetic to the vector pipe, and an "s" asm operand then receives a VGPR -
-    // which only the assembler rejects: tests/test_kernel_budget.py assembles the code object for that reason)
-    nH0 = __builtin_amdgcn_readfirstlane(nH0);
-    nH1 = __builtin_amdgcn_readfirstlane(nH1);
-    // QQ (ROLL2): the set of row pairs that receives the rows - the one whose A rows have just been read for the last time
-    auto load_groups = [&](int g0, int g1, uint32_t vrow, auto QQ) __attribute__((always_inline)) {
-        constexpr int q = decltype(QQ)::value;
-        uint32_t vb[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) vb[w] = voff0 + (vrow + (uint32_t)w * w_bytes);
-#pragma unroll
-        for (int g = g0; g < g1; ++g) {
-            {
-                int ug = used[g];
-                asm volatile("" : "+s"(ug));                 // tested here, per step (see cs_group)
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    if (w == 0 && !(ug & 1)) continue;                          // a pair is in use iff its first slot is
-                    if (w == 2 && !(ug & (1 << (MM / 2)))) continue;
-                    const uint32_t o = vb[w] + rog[g];
-                    if constexpr (ROLL2) {                   // into the registers of the old A row, by name: "+v"
-                        uint32_t r0, r1;
-#if HJB_CS_ROLL2 == 3
-                        r0 = __float_as_uint(A[q][g][w].x), r1 = __float_as_uint(A[q][g][w].y);      // the destinations TIED to the old row's registers: faults on the GPU (round 5, not understood); kept for the record
-                        asm volatile("global_load_dword %0, %1, %2" : "+v"(r0) : "v"(o), "s"(Jb00));
-                        asm volatile("global_load_dword %0, %1, %2" : "+v"(r1) : "v"(o), "s"(Jb10));
-#else
-                        asm volatile("global_load_dword %0, %1, %2" : "=v"(r0) : "v"(o), "s"(Jb00));
-                        asm volatile("global_load_dword %0, %1, %2" : "=v"(r1) : "v"(o), "s"(Jb10));
-#endif
-                        A[q][g][w] = f2{__uint_as_float(r0), __uint_as_float(r1)};
-                        continue;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        rlo[g][k][w] = gather_async<sizeof(TJ)>(o, k ? Jb10 : Jb00);
-                        if (!DPP) rhi[g][k][w] = gather_async<sizeof(TJ)>(o, k ? Jb11 : Jb01);
-                    }
-                }
-            }
-        }
-    };
-    // wait until at most `younger` gathers (a multiple of LPK) are outstanding, then release groups [g0, g1) to the arithmetic
-    auto await_groups = [&](int g0, int g1, int younger, auto QQ) __attribute__((always_inline)) {
-        wait_gathers_n<LPK>(younger);
-#pragma unroll
-        for (int g = g0; g < g1; ++g) {
-            if constexpr (ROLL2) {
-                tie3(A[decltype(QQ)::value][g]);
-            } else {
-                tie6(rlo[g]);
-                if (!DPP) tie6(rhi[g]);
-            }
-        }
-    };
-    static_assert(NG - (NG + 1) / 2 <= 3 && (NG + 1) / 2 <= 3, "await_groups counts up to nine younger window knots");
-    T best, gstep, t1;
-    double gstep64 = 0.0;
-    int best_u;
-    typedef __attribute__((address_space(3))) const f4 lds_f4;
-    lds_f4 *slots = (lds_f4 *)&s_slots[wave][0];
-    asm volatile("" : "+v"(slots));          // one address register for the column, not one re-made per read
-    // The arithmetic (cs_group) is written on PAIRS (lower, upper group row) of one window knot: v_pk_add_f32 /
-    // v_pk_fma_f32 are IEEE per component, and with the pair as the unit of data no value has to be moved between registers.
-    auto compute_groups = [&](int g0, int g1, auto PP) __attribute__((always_inline)) {
-        constexpr int pn = decltype(PP)::value, po = NA - 1 - pn;      // ROLL2: set pn holds the gathered rows and takes the new A rows, set po the old ones
-#pragma unroll
-        for (int g = g0; g < g1; ++g) {
-            if (g < ngs) {
-                const f2 t0p = {t0, t0};
-                auto row0 = [&](int w) {
-                    f2 l;
-                    if constexpr (ROLL2) l = A[pn][g][w];
-                    else l = f2{raw_to<T, TJ>(rlo[g][0][w]), raw_to<T, TJ>(rlo[g][1][w])};
-                    const f2 d = DPP ? f2{lane_up_minus(l.x), lane_up_minus(l.y)}      // (next lane) - (own): one DPP subtraction each
-                                     : f2{raw_to<T, TJ>(rhi[g][0][w]), raw_to<T, TJ>(rhi[g][1][w])} - l;
-                    return __builtin_elementwise_fma(t0p, d, l);
-                };
-                cs_group<T, GAX, FASTCOST, decltype(row0), decltype(slots), C64>(used[g], g, row0, A[po][g], A[pn][g], t1, slots, gstep, ncu, npre, best, best_u, gstep64);
-            }
-        }
-    };
-    // the per-step cost term of the usual shape: its descriptor is read once (from the cost record), not once per step
-    const bool one_su = step_uniform && npre - npre_col == 1;
-    cptr<T> su_ptr;
-    int su_s1 = 0;
-    if (CS_CREC(kCRecHasSu) != 0 && one_su && !C64) {
-        su_ptr = as_const<T>((const T *)(uintptr_t)((uint64_t)CS_CREC(kCRecSu) | ((uint64_t)CS_CREC(kCRecSu + 1) << 32))) +
-                 ((int)CS_CREC(kCRecSu + 3) * i2 + (int)CS_CREC(kCRecSu + 4) * si[3]);
-        su_s1 = (int)CS_CREC(kCRecSu + 2);
-    } else {
-        su_ptr = as_const<T>(P->cost[one_su ? npre_col : 0].data);
-        if (one_su) {
-            const DTerm &tm = P->cost[npre_col];
-            su_ptr += tm.stride[2] * i2 + tm.stride[3] * si[3];
-            su_s1 = tm.stride[1];
-        }
-    }
-#undef CS_CREC
-    int prev_c1 = -2;
-    // Everything hipcc loaded for the set-up has landed before the loop starts: a value still "pending" at the loop
-    // header would make its first use INSIDE the loop a `vmcnt(0)` on every step - a drain of the gathers in flight.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" : "+v"(gcol), "+v"(t0), "+v"(voff0));
-    load_groups(0, NGH, (uint32_t)(c1n + 1) * s1_bytes, std::integral_constant<int, 0>{});      // prologue: H0 of step 0
-    int slot = 0;                                            // LDS slot of this step's result (= i1 % kCsFlush)
-    if constexpr (TWO) {
-        for (int i1 = i1b; i1 < i1e; ++i1) {
-            {
-#define CS_PN 0
-#include "kernels_colsweep_step.inc"
-#undef CS_PN
-            }
-            if (++i1 >= i1e) break;
-            {
-#define CS_PN (NA - 1)
-#include "kernels_colsweep_step.inc"
-#undef CS_PN
-            }
-        }
-    } else {
-        for (int i1 = i1b; i1 < i1e; ++i1) {
-#define CS_PN 0
-#include "kernels_colsweep_step.inc"
-#undef CS_PN
-        }
-    }
+// ---- several problems, one launch (hjb_solve_batch: Solver_pos_att.simplified_run's four channels, pos-att/Solver_pos_att.m:197-242) --
+// The reference's own channels are 2.7e5 states each: a stage kernel of one of them is a launch boundary plus one wave's chain of
+// round trips (~10 us), and of four such chains on four streams the device runs two at full rate.  blockIdx.y = the problem; each
+// keeps its own plan, tables, buffers and workgroup count; `mask` drops the problems whose monitor has stopped them; `parity`
+// says which of a problem's two J buffers is the input.
+constexpr int kCsBatchMax = 8;
+struct DCsBatch {
+    const DParams *P[kCsBatchMax];
+    const DTabled *TB[kCsBatchMax];
+    const DColSweep *CS[kCsBatchMax];
+    void *J[kCsBatchMax][2];
+    void *idx[kCsBatchMax];
+    uint32_t grid[kCsBatchMax];
+};
+template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP, bool C64 = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
+    (DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 1,
+    (DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 4)))
+k_backup_colsweep_batch(const DCsBatch *__restrict__ B, uint32_t mask, int parity) {
+    const unsigned ch = blockIdx.y;
+    if (!((mask >> ch) & 1u) || blockIdx.x >= B->grid[ch]) return;
+    const DParams *__restrict__ P = B->P[ch];
+    const DTabled *__restrict__ TB = B->TB[ch];
+    const DColSweep *__restrict__ CS = B->CS[ch];
+    const TJ *__restrict__ Jn = (const TJ *)B->J[ch][parity];
+    TJ *__restrict__ Jout = (TJ *)B->J[ch][parity ^ 1];
+    void *__restrict__ idx_out = B->idx[ch];
+#define CS_BX blockIdx.x
+#include "kernels_colsweep_body.inc"
+#undef CS_BX
 }
 
 }  // namespace hjb

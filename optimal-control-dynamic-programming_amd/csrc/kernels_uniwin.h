@@ -24,7 +24,9 @@
 //
 // The chunk walk is tiled for the L2: the points are cut into tiles of 8 x 4 x 4 and for one tile every
 // angle chunk is visited in turn, a tile's 128 points back to back: the window slices those 128 workgroups touch at a time are
-// (8+2) x (4+2) x (4+2) point-slices of ONE angle chunk's neighbourhood instead of 27 per point.
+// (8+2) x (4+2) x (4+2) point-slices of ONE angle chunk's neighbourhood instead of 27 per point.  One generation of workgroups
+// (grid = occupancy x CUs) walks it, workgroup b serving XCD b % 8, and the positions are CLAIMED from a per-XCD counter, not
+// strided: that is what keeps the chunks in flight under one L2 neighbours (24^6 36.6 -> 30.0 ms, C3 3.96 -> 2.86 s per stage).
 //
 // Arithmetic per backup is the canonical order - the same operations in the same order as K3's window
 // modes: bit-identical results.

@@ -16,6 +16,18 @@ int stage_colsweep_c64_f32_g3(const StageArgs &a, int ng, bool dpp);
 int stage_colsweep_c64_f16_g2(const StageArgs &a, int ng, bool dpp);
 int stage_colsweep_c64_f16_g3(const StageArgs &a, int ng, bool dpp);
 
+int stage_colsweep_batch_f32_g2(const StageArgs &a, int n, const DCsBatch *dB, uint32_t mask, int parity, int ng);
+int stage_colsweep_batch_f32_g3(const StageArgs &a, int n, const DCsBatch *dB, uint32_t mask, int parity, int ng);
+int stage_colsweep_batch_c64_f32_g2(const StageArgs &a, int n, const DCsBatch *dB, uint32_t mask, int parity, int ng);
+int stage_colsweep_batch_c64_f32_g3(const StageArgs &a, int n, const DCsBatch *dB, uint32_t mask, int parity, int ng);
+
+// n problems of one shape in one launch (float32 J, the usual cost shape, the one-load form): a.grid = the largest workgroup count
+int stage_colsweep_batch(const StageArgs &a, int n, const DCsBatch *dB, uint32_t mask, int parity, int gax, int ng, bool c64) {
+    if (a.dtype != HJB_F32) return 1;
+    if (c64) return gax == 3 ? stage_colsweep_batch_c64_f32_g3(a, n, dB, mask, parity, ng) : stage_colsweep_batch_c64_f32_g2(a, n, dB, mask, parity, ng);
+    return gax == 3 ? stage_colsweep_batch_f32_g3(a, n, dB, mask, parity, ng) : stage_colsweep_batch_f32_g2(a, n, dB, mask, parity, ng);
+}
+
 // costform: 0 general control terms, 1 state terms + one control term (float32), 2 the same summed in float64
 int stage_colsweep(const StageArgs &a, int gax, int ng, int costform, bool dpp) {
     const bool fastcost = costform != 0;

@@ -28,6 +28,20 @@ static int colsweep_go(const StageArgs &a, int ng, bool fastcost, bool dpp) {
     return 0;
 }
 
+// the batched launch (kernels_colsweep.h: k_backup_colsweep_batch): float32 J, the usual cost shape, the one-load form
+template <int GAX, bool C64>
+static int colsweep_go_batch(const StageArgs &a, int n, const DCsBatch *dB, uint32_t mask, int parity, int ng) {
+    const dim3 g(a.grid, (unsigned)n), b(a.block);
+#define HJB_CSB(NG)                                                                                                    \
+    case NG: hipLaunchKernelGGL((k_backup_colsweep_batch<float, float, GAX, NG, true, true, C64>), g, b, 0, a.st, dB, mask, parity); break;
+    switch (ng) {
+        HJB_CSB(1) HJB_CSB(2) HJB_CSB(3) HJB_CSB(4) HJB_CSB(5) HJB_CSB(6)
+        default: return 1;
+    }
+#undef HJB_CSB
+    return 0;
+}
+
 // cost form 2 (hjb_problem.cost_dtype == HJB_COST_F64: state terms + one control term, summed in double): units of their own
 template <typename TJ, int GAX>
 static int colsweep_go_c64(const StageArgs &a, int ng, bool dpp) {

@@ -149,6 +149,7 @@ SYMBOLS = {
     "hjb_backup_stage_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hjb_check_device_status": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "hjb_solve": (C.c_int32, [C.c_void_p, C.POINTER(hjb_solve_opts), C.POINTER(hjb_result)]),
+    "hjb_solve_batch": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(hjb_solve_opts)), C.POINTER(C.POINTER(hjb_result))]),
     "hjb_policy_lookup": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                       C.POINTER(C.POINTER(C.c_double)), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                       C.c_void_p]),

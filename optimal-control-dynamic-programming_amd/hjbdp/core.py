@@ -518,6 +518,50 @@ def suggest_axis_order(spec):
         lib.hjb_problem_free(b)
 
 
+def solve_batch(specs, n_stages, device=0, monitor_period=0, monitor_tol=0.0, progress=None, monitor_single=False):
+    """Independent sweeps of ONE kernel shape side by side with ONE launch per stage for all of them (hjb_solve_batch: the four
+    channels of Solver_pos_att.simplified_run, pos-att/Solver_pos_att.m:197-242).  Every problem keeps its own monitor sums and
+    stop decision; results equal Backup.solve's bit for bit.  Raises HjbError (HJB_E_UNSUPPORTED) when the problems do not run on
+    the column-sweep kernel in its usual form - the caller then sweeps them with solve_many.  -> (outs, wall_ms, variants)"""
+    import time
+    t0 = time.perf_counter()
+    lib = load_library()
+    n = len(specs)
+    bks = [Backup(s, device=device) for s in specs]
+    try:
+        keep, outs_np = [], []
+        hs = (C.c_void_p * n)(*[bk._h for bk in bks])
+        optp = (C.POINTER(_abi.hjb_solve_opts) * n)()
+        resp = (C.POINTER(_abi.hjb_result) * n)()
+        ress = []
+        for i, s in enumerate(specs):
+            o = _abi.hjb_solve_opts()
+            o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
+            J = np.empty(s.nS, dtype=s.j_dtype)
+            idx = np.empty(s.nS, dtype=s.idx_np_dtype)
+            o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
+            o.monitor_single = 1 if monitor_single else 0
+            if progress is not None:
+                cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
+                keep.append(cb)
+                o.progress = cb
+            r = _abi.hjb_result()
+            keep += [o, r]
+            optp[i] = C.pointer(o)
+            resp[i] = C.pointer(r)
+            outs_np.append((J, idx))
+            ress.append(r)
+        st = lib.hjb_solve_batch(n, hs, optp, resp)
+        _check(lib, None, st)
+        variants = [bk.info()["kernel_variant"] for bk in bks]
+    finally:
+        for bk in bks:
+            bk.close()
+    outs = [{"J": J, "idx": idx, "J_stages": None, "idx_stages": None, "stages_done": r.stages_done, "stopped_early": bool(r.stopped_early),
+             "sweep_ms": r.sweep_ms, "last_e": r.last_e, "last_e2": r.last_e2, "probe": None} for (J, idx), r in zip(outs_np, ress)]
+    return outs, (time.perf_counter() - t0) * 1e3, variants
+
+
 def solve_many(specs, n_stages, device=0, **solve_kw):
     """Independent sweeps (the three axis channels of Solver_position / Solver_attitude.simplified_run, the four
     runs of Solver_pos_att.simplified_run) in flight together: one handle and one host thread per sweep, each on

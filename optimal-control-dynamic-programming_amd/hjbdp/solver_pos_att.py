@@ -34,7 +34,7 @@ import math
 
 import numpy as np
 
-from .core import Backup, solve_many
+from .core import Backup, HjbError, solve_batch, solve_many
 from .matlab_compat import deg2rad, sym_linspace_pos_att
 from .problem import ProblemSpec, Term
 
@@ -103,6 +103,8 @@ class Solver_pos_att:
         self.idx_dtype = "auto"       # U_Optimal_id storage: uint8 for the 9 (6) thruster combinations
         self.monitor_single = True    # sum(F_gI.Values(:)) as a single-precision sum (:274)
         self.device = 0
+        self.batch_channels = True    # simplified_run: the four channels as one launch per stage where the library can (hjb_solve_batch)
+        self.batched = False          # ... whether the last simplified_run did
         self.controllers = {}
 
     # ------------------------------------------------------------------
@@ -244,9 +246,20 @@ class Solver_pos_att:
         built = [self.build_channel_spec(*args) for args, _ in jobs]
         n_st = self.N_stage - 1 if n_stages is None else int(n_stages)
         rel = [self._relabel(b[0]) for b in built]
-        outs, self.wall_ms, _ = solve_many([r[0] for r in rel], n_st, device=self.device,
-                                           monitor_period=self.monitor_period, monitor_tol=self.monitor_tol,
-                                           progress=progress, monitor_single=self.monitor_single)
+        kw = dict(device=self.device, monitor_period=self.monitor_period, monitor_tol=self.monitor_tol, progress=progress,
+                  monitor_single=self.monitor_single)
+        self.batched = False
+        if self.batch_channels:
+            # the four channels as ONE launch per stage (hjb_solve_batch); shapes it does not take run side by side on threads
+            try:
+                outs, self.wall_ms, _ = solve_batch([r[0] for r in rel], n_st, **kw)
+                self.batched = True
+            except HjbError as e:
+                from . import _abi
+                if e.status != _abi.HJB_E_UNSUPPORTED:
+                    raise
+        if not self.batched:
+            outs, self.wall_ms, _ = solve_many([r[0] for r in rel], n_st, **kw)
         for (args, name), (spec, combos), out, r in zip(jobs, built, outs, rel):
             self._store_controller(name, args[:4], spec.n, combos, self._map_back(out, r[1]))
         return self

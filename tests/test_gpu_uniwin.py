@@ -44,7 +44,10 @@ def test_uniwin_whole_grid_bit_exact(env, n_so, n_rates, m, gain, nonuniform):
         bk.set_option("uw_tile", 1 + 8 * 1 + 64 * 0)            # another tiling of the chunk walk: the same bits
         bk.set_option("uniwin", 1)
         tiled = bk.solve(2, terminal=term, keep_J=True, keep_idx=True)
-    for name, o in (("uniwin", out), ("mode 5", old), ("tile 2x2x1", tiled)):
+        bk.set_option("uw_block", 64)                           # one wave per workgroup, 64-state chunks: the same bits
+        assert bk.get_option("uw_block") == 64
+        small = bk.solve(2, terminal=term, keep_J=True, keep_idx=True)
+    for name, o in (("uniwin", out), ("mode 5", old), ("tile 2x2x1", tiled), ("64-state chunks", small)):
         bad = np.flatnonzero(o["J_stages"] != ref["J_stages"])
         assert bad.size == 0, (name, "J", bad[:8])
         bad = np.flatnonzero(o["idx_stages"] != ref["idx_stages"])
@@ -70,6 +73,26 @@ def test_uniwin_cost_term_orders(env, n, m, order):
         assert bk.get_option("packed2_mode") == 7, (bk.get_option("uniwin_ok"), bk.get_option("uniwin_slow_points"))
         out = bk.solve(2, terminal=term, keep_J=True, keep_idx=True)
     assert np.array_equal(out["J_stages"], ref["J_stages"]) and np.array_equal(out["idx_stages"], ref["idx_stages"])
+
+
+def test_uniwin_long_sweep_through_graph_replay_and_both_walks(env):
+    """50 stages through hjb_solve (the ping-pong loop replayed from a hipGraph: the per-launch reset of the walk's claim counters is a
+    memset node of that graph), with the chunk walk claimed from per-XCD counters (default) and with the fixed stride: every stage
+    equal to the oracle's."""
+    hjbdp, _abi, c_oracle = env
+    from problems import rate_shared_problem
+    spec = rate_shared_problem(31, (140,), (4, 3, 4), m=(3, 4, 11), gain=(0.3, 0.2, 0.25))
+    ref = c_oracle.sweep(_abi, spec, 50, keep_J=True, keep_idx=True)          # zero terminal cost (the reference's start)
+    with hjbdp.Backup(spec) as bk:
+        assert bk.get_option("packed2_mode") == 7 and bk.get_option("uw_claim") == 1
+        for claim in (1, 0, 1):
+            bk.set_option("uw_claim", claim)
+            out = bk.solve(50, keep_J=True, keep_idx=True)
+            assert np.array_equal(out["J_stages"], ref["J_stages"]) and np.array_equal(out["idx_stages"], ref["idx_stages"]), claim
+        bk.set_option("graph", 0)
+        out = bk.solve(50)
+        assert np.array_equal(out["J"], ref["J"]) and np.array_equal(out["idx"], ref["idx"])
+    assert np.all(np.isfinite(ref["J_stages"])) and len(np.unique(ref["idx"])) > 5
 
 
 def test_uniwin_points_outside_the_usual_shape_take_the_slow_path(env):
