@@ -49,6 +49,45 @@ int32_t hjb_solve_batch(int32_t n, const hjb_handle *hs, const hjb_solve_opts *c
         const int st = ensure_work(H[i]);
         if (st) return st;
     }
+    // Parts per column.  A handle's own choice (colsweep_split) is made for a launch that is ALONE on the device: as many parts as
+    // fill the wave slots, because such a launch is one wave's chain of round trips.  Every part primes its rows again, so that
+    // choice does up to twice the work per column - the right price for latency, the wrong one for a batch, whose launches hold n
+    // problems' columns: here the parts are what lets ALL the batch's columns fill about one round of the wave slots
+    // (profiles/r06_batch_split.log: the reference's channels, 4 x 450 columns of 20 steps, 10 parts each when alone - 2 to 4 here).
+    int old_split[kCsBatchMax];
+    bool resplit = false;
+    {
+        int64_t columns = 0;
+        for (int i = 0; i < n; ++i) {
+            const DParams &P = H[i]->hp;
+            columns += (int64_t)((P.n[0] + kCsDppLanes - 1) / kCsDppLanes) * P.n[2] * P.n[3];
+        }
+        const int64_t slots = (int64_t)(h0->cost64 ? 4 : 6) * 4 * 256;                   // waves per SIMD of the form that runs x SIMDs
+        const int s_batch = (int)std::max<int64_t>(1, slots / std::max<int64_t>(columns, 1));
+        for (int i = 0; i < n; ++i) {
+            Handle *h = H[i];
+            old_split[i] = h->cs_split;
+            if (h->cs_split == 0 && s_batch < (int)h->hcs.split) {      // (an explicit option "cs_split" stands)
+                h->cs_split = s_batch;
+                colsweep_split(h);
+                const int ust = colsweep_upload(h);
+                if (ust) return ust;
+                choose_launch(h);
+                resplit = true;
+            }
+        }
+    }
+    auto restore_split = [&]() {
+        if (!resplit) return;
+        for (int i = 0; i < n; ++i) {
+            Handle *h = H[i];
+            if (h->cs_split == old_split[i]) continue;
+            h->cs_split = old_split[i];
+            colsweep_split(h);
+            (void)colsweep_upload(h);
+            choose_launch(h);
+        }
+    };
     if (!h0->stream) HIP_TRY(h0, hipStreamCreateWithFlags(&h0->stream, hipStreamNonBlocking));
     hipStream_t stream = h0->stream;
     DCsBatch hb;
@@ -75,6 +114,8 @@ int32_t hjb_solve_batch(int32_t n, const hjb_handle *hs, const hjb_solve_opts *c
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
         if (dB) { (void)hipFree(dB); dB = nullptr; }
+        (void)hipStreamSynchronize(stream);       // (nothing of this batch is in flight when the handles get their own parts back)
+        restore_split();
     };
 #define BATCH_TRY(expr)                                                                            \
     do {                                                                                           \

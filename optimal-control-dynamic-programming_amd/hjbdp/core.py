@@ -518,48 +518,92 @@ def suggest_axis_order(spec):
         lib.hjb_problem_free(b)
 
 
-def solve_batch(specs, n_stages, device=0, monitor_period=0, monitor_tol=0.0, progress=None, monitor_single=False):
-    """Independent sweeps of ONE kernel shape side by side with ONE launch per stage for all of them (hjb_solve_batch: the four
-    channels of Solver_pos_att.simplified_run, pos-att/Solver_pos_att.m:197-242).  Every problem keeps its own monitor sums and
-    stop decision; results equal Backup.solve's bit for bit.  Raises HjbError (HJB_E_UNSUPPORTED) when the problems do not run on
-    the column-sweep kernel in its usual form - the caller then sweeps them with solve_many.  -> (outs, wall_ms, variants)"""
+def solve_batch(specs, n_stages, device=0, monitor_period=0, monitor_tol=0.0, progress=None, monitor_single=False, cs_split=None):
+    """Independent sweeps side by side with as few launch chains as the library can make of them (the four channels of
+    Solver_pos_att.simplified_run, pos-att/Solver_pos_att.m:197-242): problems that run on the column-sweep kernel with the same group
+    axis share ONE launch per stage (hjb_solve_batch); each such group, and every problem that is alone in its shape, gets a host
+    thread and a stream of its own (the device runs two launch chains at full rate: three channels + one is two chains).  Every
+    problem keeps its own monitor sums and stop decision; results equal Backup.solve's bit for bit.
+    -> (outs, wall_ms, variants, group sizes)"""
     import time
+    from concurrent.futures import ThreadPoolExecutor
     t0 = time.perf_counter()
     lib = load_library()
     n = len(specs)
-    bks = [Backup(s, device=device) for s in specs]
+    kw = dict(monitor_period=monitor_period, monitor_tol=monitor_tol, progress=progress, monitor_single=monitor_single)
+    with ThreadPoolExecutor(max_workers=max(1, n)) as ex:
+        bks = list(ex.map(lambda s: Backup(s, device=device), specs))
+    t_made = time.perf_counter()
+    t_run = t_made
     try:
-        keep, outs_np = [], []
-        hs = (C.c_void_p * n)(*[bk._h for bk in bks])
-        optp = (C.POINTER(_abi.hjb_solve_opts) * n)()
-        resp = (C.POINTER(_abi.hjb_result) * n)()
-        ress = []
-        for i, s in enumerate(specs):
-            o = _abi.hjb_solve_opts()
-            o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
-            J = np.empty(s.nS, dtype=s.j_dtype)
-            idx = np.empty(s.nS, dtype=s.idx_np_dtype)
-            o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
-            o.monitor_single = 1 if monitor_single else 0
-            if progress is not None:
-                cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
-                keep.append(cb)
-                o.progress = cb
-            r = _abi.hjb_result()
-            keep += [o, r]
-            optp[i] = C.pointer(o)
-            resp[i] = C.pointer(r)
-            outs_np.append((J, idx))
-            ress.append(r)
-        st = lib.hjb_solve_batch(n, hs, optp, resp)
-        _check(lib, None, st)
         variants = [bk.info()["kernel_variant"] for bk in bks]
+        groups = {}
+        for i, bk in enumerate(bks):
+            key = ("colsweep", bk.get_option("cs_group_axis"), bk.spec.cost_dtype is not None) if variants[i] == 7 else ("alone", i)
+            groups.setdefault(key, []).append(i)
+        outs = [None] * n
+        if cs_split is None:
+            # Parts per column of the column-sweep problems.  A handle alone picks as many parts as fill the device (it is one wave's
+            # chain of round trips), and every part primes its rows again: up to twice the work per column.  These problems are in
+            # flight TOGETHER, so the parts are what lets all their columns fill about one round of the wave slots - the library does
+            # the same inside a batch for the columns it sees; here every chain of the call is counted (profiles/r06_batch_split.log)
+            cs = [i for i in range(n) if variants[i] == 7]
+            if len(cs) > 1:
+                cols = sum(-(-specs[i].n[0] // 60) * specs[i].n[2] * specs[i].n[3] for i in cs)
+                slots = (4 if any(specs[i].cost_dtype is not None for i in cs) else 6) * 4 * 256
+                cs_split = max(1, slots // max(cols, 1))
+                cs_split = cs_split if all(cs_split < bks[i].get_option("cs_split") for i in cs) else 0
+
+        def run(members):
+            if cs_split:
+                for i in members:
+                    if variants[i] == 7:
+                        bks[i].set_option("cs_split", int(cs_split))
+            if len(members) > 1:
+                m = len(members)
+                keep, bufs, ress = [], [], []
+                hs = (C.c_void_p * m)(*[bks[i]._h for i in members])
+                optp = (C.POINTER(_abi.hjb_solve_opts) * m)()
+                resp = (C.POINTER(_abi.hjb_result) * m)()
+                for k, i in enumerate(members):
+                    s = specs[i]
+                    o = _abi.hjb_solve_opts()
+                    o.n_stages, o.monitor_period, o.monitor_tol = int(n_stages), int(monitor_period), float(monitor_tol)
+                    J = np.empty(s.nS, dtype=s.j_dtype)
+                    idx = np.empty(s.nS, dtype=s.idx_np_dtype)
+                    o.J_final, o.idx_final = J.ctypes.data, idx.ctypes.data
+                    o.monitor_single = 1 if monitor_single else 0
+                    if progress is not None:
+                        cb = _abi.hjb_progress_fn(lambda user, k_s, e, e2, sec: progress(k_s, e, e2, sec))
+                        keep.append(cb)
+                        o.progress = cb
+                    r = _abi.hjb_result()
+                    keep += [o, r]
+                    optp[k] = C.pointer(o)
+                    resp[k] = C.pointer(r)
+                    bufs.append((J, idx))
+                    ress.append(r)
+                st = lib.hjb_solve_batch(m, hs, optp, resp)
+                if st == _abi.HJB_OK:
+                    for i, (J, idx), r in zip(members, bufs, ress):
+                        outs[i] = {"J": J, "idx": idx, "J_stages": None, "idx_stages": None, "stages_done": r.stages_done,
+                                   "stopped_early": bool(r.stopped_early), "sweep_ms": r.sweep_ms, "last_e": r.last_e, "last_e2": r.last_e2,
+                                   "probe": None}
+                    return m
+                if st != _abi.HJB_E_UNSUPPORTED:
+                    _check(lib, None, st)
+            for i in members:               # alone in its shape (or a group the library did not take): the plain sweep
+                outs[i] = bks[i].solve(n_stages, **kw)
+            return 1
+        with ThreadPoolExecutor(max_workers=max(1, len(groups))) as ex:
+            sizes = list(ex.map(run, groups.values()))
+        t_run = time.perf_counter()
     finally:
         for bk in bks:
             bk.close()
-    outs = [{"J": J, "idx": idx, "J_stages": None, "idx_stages": None, "stages_done": r.stages_done, "stopped_early": bool(r.stopped_early),
-             "sweep_ms": r.sweep_ms, "last_e": r.last_e, "last_e2": r.last_e2, "probe": None} for (J, idx), r in zip(outs_np, ress)]
-    return outs, (time.perf_counter() - t0) * 1e3, variants
+    t_end = time.perf_counter()
+    solve_batch.last_phases_ms = {"create": (t_made - t0) * 1e3, "sweep": (t_run - t_made) * 1e3, "close": (t_end - t_run) * 1e3}
+    return outs, (t_end - t0) * 1e3, variants, sizes
 
 
 def solve_many(specs, n_stages, device=0, **solve_kw):

@@ -34,7 +34,7 @@ import math
 
 import numpy as np
 
-from .core import Backup, HjbError, solve_batch, solve_many
+from .core import Backup, solve_batch, solve_many
 from .matlab_compat import deg2rad, sym_linspace_pos_att
 from .problem import ProblemSpec, Term
 
@@ -104,7 +104,8 @@ class Solver_pos_att:
         self.monitor_single = True    # sum(F_gI.Values(:)) as a single-precision sum (:274)
         self.device = 0
         self.batch_channels = True    # simplified_run: the four channels as one launch per stage where the library can (hjb_solve_batch)
-        self.batched = False          # ... whether the last simplified_run did
+        self.batched = False          # ... whether the last simplified_run did (batch_groups: how many channels each launch chain carried)
+        self.batch_groups = None
         self.controllers = {}
 
     # ------------------------------------------------------------------
@@ -248,17 +249,12 @@ class Solver_pos_att:
         rel = [self._relabel(b[0]) for b in built]
         kw = dict(device=self.device, monitor_period=self.monitor_period, monitor_tol=self.monitor_tol, progress=progress,
                   monitor_single=self.monitor_single)
-        self.batched = False
+        self.batched, self.batch_groups = False, None
         if self.batch_channels:
-            # the four channels as ONE launch per stage (hjb_solve_batch); shapes it does not take run side by side on threads
-            try:
-                outs, self.wall_ms, _ = solve_batch([r[0] for r in rel], n_st, **kw)
-                self.batched = True
-            except HjbError as e:
-                from . import _abi
-                if e.status != _abi.HJB_E_UNSUPPORTED:
-                    raise
-        if not self.batched:
+            # channels of one column-sweep shape as ONE launch per stage (hjb_solve_batch), the groups side by side
+            outs, self.wall_ms, _, self.batch_groups = solve_batch([r[0] for r in rel], n_st, **kw)
+            self.batched = max(self.batch_groups) > 1
+        else:
             outs, self.wall_ms, _ = solve_many([r[0] for r in rel], n_st, **kw)
         for (args, name), (spec, combos), out, r in zip(jobs, built, outs, rel):
             self._store_controller(name, args[:4], spec.n, combos, self._map_back(out, r[1]))

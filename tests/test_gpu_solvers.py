@@ -329,18 +329,29 @@ def test_solver_pos_att_channel_reference_grid(env, form):
 
 
 @pytest.mark.order(7)
-def test_solver_pos_att_all_channels_with_monitor(env):
-    """simplified_run (4 channels incl. the thruster-failure one) on a small grid with the early-stop monitor, as the mirror runs it
-    by default: the four channels as ONE launch per stage (hjb_solve_batch), each channel with its own monitor sums and stop stage.
-    Every channel - values, labels, stop stage - equals the oracle's sweep of that channel, and the same run with the channels on
-    threads of their own (batch_channels = False: hjb_solve x 4)."""
+@pytest.mark.parametrize("grid", ["reference", "small"])
+def test_solver_pos_att_all_channels_with_monitor(env, grid):
+    """simplified_run (4 channels incl. the thruster-failure one) with the early-stop monitor, as the mirror runs it by default: on the
+    reference's own 30x30x20x15 grid the channels land on the column-sweep kernel and those that share a group axis are ONE launch per
+    stage (hjb_solve_batch), each with its own monitor sums and stop stage; on a small grid (the table kernel) every channel is a chain
+    of its own.  Every channel - values, labels, stop stage - equals the oracle's sweep of that channel, and the same run with the
+    channels on threads of their own (batch_channels = False: hjb_solve x 4)."""
     hjbdp, _abi, c_oracle = env
-    pa = hjbdp.Solver_pos_att()
-    pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 8, 8, 6, 5
-    pa.monitor_period, pa.monitor_tol = 10, 5.0
+    n_st, period, tol = (69, 10, 290000.0) if grid == "reference" else (120, 10, 5.0)
+
+    def mirror(**kw):
+        pa = hjbdp.Solver_pos_att()
+        if grid == "small":
+            pa.n_mesh_x, pa.n_mesh_v, pa.n_mesh_t, pa.n_mesh_w = 8, 8, 6, 5
+        pa.monitor_period, pa.monitor_tol = period, tol
+        for k, v in kw.items():
+            setattr(pa, k, v)
+        return pa
+    pa = mirror()
     events = []
-    pa.simplified_run(n_stages=120, progress=lambda k_s, e, e2, sec: events.append(k_s))
-    assert pa.batched                                                 # the column-sweep shape: one launch per stage for the four
+    pa.simplified_run(n_stages=n_st, progress=lambda k_s, e, e2, sec: events.append(k_s))
+    assert sorted(pa.batch_groups) == ([1, 3] if grid == "reference" else [1, 1, 1, 1]), pa.batch_groups
+    assert pa.batched == (grid == "reference")
     assert set(pa.controllers) == {"channel_x_controller_1", "channel_y_controller_1", "channel_z_controller_1",
                                    "channel_x_controller_1_failure"}
     sx, sv, st, sw = pa.grids()
@@ -352,29 +363,22 @@ def test_solver_pos_att_all_channels_with_monitor(env):
     for name, (s_t, *rest) in chan.items():
         spec, _ = pa.build_channel_spec(sx, sv, s_t, sw, *rest)
         assert pa.monitor_single and spec.table_dtype == np.float64 and spec.idx_np_dtype == np.uint8     # the mirror's defaults: the reference's typing
-        ref = _oracle_in_the_mirrors_order(c_oracle, _abi, pa, spec, 120, monitor_period=10, monitor_tol=5.0, monitor_single=True)
+        ref = _oracle_in_the_mirrors_order(c_oracle, _abi, pa, spec, n_st, monitor_period=period, monitor_tol=tol, monitor_single=True)
         c = pa.controllers[name]
-        assert c["stages_done"] == ref["stages_done"] and c["stopped_early"] == ref["stopped_early"], name
+        assert c["stages_done"] == ref["stages_done"] and c["stopped_early"] == ref["stopped_early"], (name, c["stages_done"], ref["stages_done"])
         assert np.array_equal(c["F_gI_Values"].reshape(-1, order="F"), ref["J"]), name
         assert np.array_equal(c["U_Optimal_id"].reshape(-1, order="F"), ref["idx"]), name
         stops[name] = c["stages_done"]
     assert len(pa.controllers["channel_x_controller_1_failure"]["f0_allcomb"]) == 6
-    assert len(set(stops.values())) > 1, stops                        # the channels do not stop together: the batch lost members on the way
-    assert events and all(k % 10 == 0 for k in events)
-    pt = hjbdp.Solver_pos_att()
-    pt.n_mesh_x, pt.n_mesh_v, pt.n_mesh_t, pt.n_mesh_w = 8, 8, 6, 5
-    pt.monitor_period, pt.monitor_tol, pt.batch_channels = 10, 5.0, False
-    pt.simplified_run(n_stages=120)
+    if grid == "reference":
+        assert stops["channel_x_controller_1"] == 40 and stops["channel_z_controller_1"] == 50, stops      # x leaves its batch (x, z, failure) one monitor point before the others
+    assert events and all(k % period == 0 for k in events)
+    pt = mirror(batch_channels=False)
+    pt.simplified_run(n_stages=n_st)
     assert not pt.batched
     for name in chan:
         a, b = pa.controllers[name], pt.controllers[name]
         assert a["stages_done"] == b["stages_done"] and np.array_equal(a["F_gI_Values"], b["F_gI_Values"]) and np.array_equal(a["U_Optimal_id"], b["U_Optimal_id"]), name
-    # a shape the batched launch does not take (the materialised cost table runs on the table kernel): the mirror falls back by itself
-    pe = hjbdp.Solver_pos_att()
-    pe.n_mesh_x, pe.n_mesh_v, pe.n_mesh_t, pe.n_mesh_w = 8, 8, 6, 5
-    pe.cost_mode = "exact"
-    pe.simplified_run(n_stages=12)
-    assert not pe.batched and pe.controllers["channel_x_controller_1"]["stages_done"] == 12
 
 
 @pytest.mark.order(7)
