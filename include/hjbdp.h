@@ -307,9 +307,13 @@ int32_t hjb_solve(hjb_handle h, const hjb_solve_opts *opts, hjb_result *result);
  * boundary plus one wave's chain of round trips, and of four such chains on four streams the device runs two at full rate).
  * Every problem keeps its own terminal cost, outputs, monitor sums / difference / stop decision (a stopped problem drops out of
  * the launches that follow) and progress callback; its results equal hjb_solve's bit for bit.  Conditions (else
- * HJB_E_UNSUPPORTED, and the caller sweeps the problems with hjb_solve on threads of their own): n <= 8, one device, every handle
- * on the column-sweep kernel in its usual form (float32 J, state cost terms + one control term, the one-load form), one group
- * axis and one cost typing, one n_stages and one monitor_period for all, no per-stage outputs / probe / per-stage progress. */
+ * HJB_E_UNSUPPORTED, and the caller sweeps the problems with hjb_solve on threads of their own): n <= 8, one device, one n_stages
+ * and one monitor_period for all, no per-stage outputs / probe / per-stage progress, and every handle on ONE of
+ *   - the column-sweep kernel in its usual form (float32 J, state cost terms + one control term, the one-load form), one group
+ *     axis and one cost typing; the columns are cut into parts for the whole batch unless option "cs_split" is set;
+ *   - the table kernel's 32-bit form (kernel_variant 5, every index below 2^31), one dtype and one D <= 4.  Worth it while all the
+ *     problems' states are resident at once (<= ~5e5 states in all: a launch-bound stage); larger ones overlap better as chains
+ *     of their own (profiles/r06_batch_attitude.log). */
 int32_t hjb_solve_batch(int32_t n, const hjb_handle *handles, const hjb_solve_opts *const *opts, hjb_result *const *results);
 
 /* Batched evaluation of a gridded function at nq points - what the reference does with the

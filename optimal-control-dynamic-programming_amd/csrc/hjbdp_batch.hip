@@ -1,4 +1,5 @@
-// hjbdp_batch.hip - hjb_solve_batch: several independent sweeps of ONE kernel shape side by side, ONE launch per stage for all of them.
+// hjbdp_batch.hip - hjb_solve_batch: several independent sweeps of ONE kernel shape side by side, ONE launch per stage for all of them
+// (the column-sweep kernel, kernels_colsweep.h, or the table kernel's 32-bit form, kernels_tabled.h).
 // gfx950 (MI355X) only; no CPU fallback - without a HIP device every compute entry point returns HJB_E_DEVICE.
 //
 // Solver_pos_att.simplified_run (pos-att/Solver_pos_att.m:197-242) sweeps four independent channels - x, y, z and the thruster-failure
@@ -22,25 +23,38 @@ int32_t hjb_solve_batch(int32_t n, const hjb_handle *hs, const hjb_solve_opts *c
         H[i] = (Handle *)hs[i];
         if (!H[i] || !opts[i]) return fail(nullptr, HJB_E_INVALID, "hjb_solve_batch: problem %d is null", i);
     }
-    // ---- what can run as one launch: the column-sweep kernel in its usual form, one shape, one loop -----------------------------------
+    // ---- what can run as one launch: one kernel shape and one loop --------------------------------------------------------------------
+    //   the column-sweep kernel (variant 7) in its usual form, one group axis and cost typing: Solver_pos_att's channels;
+    //   the table kernel (variant 5) in its 32-bit form, one (dtype, D <= 4): Solver_attitude.simplified_run's channels, Solver_pos_att's
+    //   channels in the reference's own axis order
     const hjb_solve_opts &o0 = *opts[0];
     if (o0.n_stages < 1) return fail(H[0], HJB_E_INVALID, "n_stages=%d", o0.n_stages);
+    const bool tabled = H[0]->variant == 5;
     int ng = 0;
     for (int i = 0; i < n; ++i) {
         Handle *h = H[i];
         const hjb_solve_opts &o = *opts[i];
-        const bool fastcost = h->hcs.ncu == 1 && h->hp.n_cost_prefix > 0;
-        if (h->variant != 7 || !h->dcs || !h->dtb || h->dtype != HJB_F32 || h->j_elems != h->n_owned || !h->hcs.dpp || !fastcost ||
-            (h->hcs.coop && h->cc_grid > 0))
-            return fail(h, HJB_E_UNSUPPORTED, "hjb_solve_batch: problem %d does not run on the column-sweep kernel in its usual form (variant %d); "
-                        "sweep the problems side by side with hjb_solve on threads of their own", i, h->variant);
-        if (h->device != H[0]->device || h->hcs.gax != H[0]->hcs.gax || h->cost64 != H[0]->cost64)
-            return fail(h, HJB_E_UNSUPPORTED, "hjb_solve_batch: problem %d has another device, group axis or cost typing than problem 0", i);
+        if (tabled) {
+            const bool i32 = h->tabled_i32 && h->tabled_i32_on && (int64_t)h->grid * h->block <= kTab32MaxThreads;
+            if (h->variant != 5 || !h->dtb || !i32 || h->j_elems != h->n_owned || h->hp.D > 4)
+                return fail(h, HJB_E_UNSUPPORTED, "hjb_solve_batch: problem %d does not run on the table kernel's 32-bit form (variant %d); "
+                            "sweep the problems side by side with hjb_solve on threads of their own", i, h->variant);
+            if (h->device != H[0]->device || h->dtype != H[0]->dtype || h->hp.D != H[0]->hp.D || h->block != H[0]->block)
+                return fail(h, HJB_E_UNSUPPORTED, "hjb_solve_batch: problem %d has another device, dtype, dimension or block size than problem 0", i);
+        } else {
+            const bool fastcost = h->hcs.ncu == 1 && h->hp.n_cost_prefix > 0;
+            if (h->variant != 7 || !h->dcs || !h->dtb || h->dtype != HJB_F32 || h->j_elems != h->n_owned || !h->hcs.dpp || !fastcost ||
+                (h->hcs.coop && h->cc_grid > 0))
+                return fail(h, HJB_E_UNSUPPORTED, "hjb_solve_batch: problem %d does not run on the column-sweep kernel in its usual form (variant %d); "
+                            "sweep the problems side by side with hjb_solve on threads of their own", i, h->variant);
+            if (h->device != H[0]->device || h->hcs.gax != H[0]->hcs.gax || h->cost64 != H[0]->cost64)
+                return fail(h, HJB_E_UNSUPPORTED, "hjb_solve_batch: problem %d has another device, group axis or cost typing than problem 0", i);
+            ng = std::max(ng, (int)h->hcs.ng);
+        }
         if (o.n_stages != o0.n_stages || o.monitor_period != o0.monitor_period)
             return fail(h, HJB_E_UNSUPPORTED, "hjb_solve_batch: one stage count and one monitor period for all problems");
         if (o.J_stages || o.idx_stages || o.probe || (o.progress && o.progress_every_stage))
             return fail(h, HJB_E_UNSUPPORTED, "hjb_solve_batch: no per-stage outputs, probe or per-stage progress (use hjb_solve)");
-        ng = std::max(ng, (int)h->hcs.ng);
     }
     Handle *h0 = H[0];
     HIP_TRY(h0, hipSetDevice(h0->device));
@@ -56,13 +70,13 @@ int32_t hjb_solve_batch(int32_t n, const hjb_handle *hs, const hjb_solve_opts *c
     // (profiles/r06_batch_split.log: the reference's channels, 4 x 450 columns of 20 steps, 10 parts each when alone - 2 to 4 here).
     int old_split[kCsBatchMax];
     bool resplit = false;
-    {
+    if (!tabled) {
         int64_t columns = 0;
         for (int i = 0; i < n; ++i) {
             const DParams &P = H[i]->hp;
             columns += (int64_t)((P.n[0] + kCsDppLanes - 1) / kCsDppLanes) * P.n[2] * P.n[3];
         }
-        const int64_t slots = (int64_t)(h0->cost64 ? 4 : 6) * 4 * 256;                   // waves per SIMD of the form that runs x SIMDs
+        const int64_t slots = (int64_t)(h0->cost64 ? 5 : 6) * 4 * 256;                   // waves per SIMD of the form that runs (82 / 80 registers) x SIMDs
         const int s_batch = (int)std::max<int64_t>(1, slots / std::max<int64_t>(columns, 1));
         for (int i = 0; i < n; ++i) {
             Handle *h = H[i];
@@ -130,13 +144,17 @@ int32_t hjb_solve_batch(int32_t n, const hjb_handle *hs, const hjb_solve_opts *c
     BATCH_TRY(sync_setup());
     StageArgs a;
     a.grid = gmax;
-    a.block = 256;
+    a.block = tabled ? (unsigned)h0->block : 256u;
     a.st = stream;
-    a.dtype = HJB_F32;
-    a.D = 4;
+    a.dtype = tabled ? h0->dtype : HJB_F32;
+    a.D = h0->hp.D;
     const int gax = h0->hcs.gax;
     const bool c64 = h0->cost64;
     auto launch = [&](uint32_t mask, int parity) -> int {
+        if (tabled) {
+            if (stage_tabled_batch(a, n, hb, mask, parity)) return fail(h0, HJB_E_DEVICE, "hjb_solve_batch: no batched instantiation (D = %d)", a.D);
+            return HJB_OK;
+        }
         if (stage_colsweep_batch(a, n, dB, mask, parity, gax, ng, c64)) return fail(h0, HJB_E_DEVICE, "hjb_solve_batch: no batched instantiation (%d groups)", ng);
         return HJB_OK;
     };

@@ -41,6 +41,7 @@ int stage_uniwin(const StageArgs &a, bool model);                               
 int stage_uniwin_occupancy(int dtype, int D, bool model, int block, size_t lds); // workgroups of `block` threads one CU holds
 int stage_uniwin_plan(int D, const DParams *dp, const DNested *dn, int32_t *plan, int n_points, int nA, int nB, int32_t *n_slow);
 int stage_tabled(const StageArgs &a);                                            // variant 5
+int stage_tabled_batch(const StageArgs &a, int n, const DCsBatch &hB, uint32_t mask, int parity);   // variant 5 (32-bit form), n problems in one launch (record by value)
 int stage_rowwise(const StageArgs &a, bool lean);                                // variant 6
 int stage_colsweep(const StageArgs &a, int gax, int ng, int costform, bool dpp);    // variant 7 (costform: 0 general, 1 fast, 2 fast in float64)
 int stage_colcoop(const StageArgs &a, int gax, int ng, bool fastcost);           // variant 7, cooperative form

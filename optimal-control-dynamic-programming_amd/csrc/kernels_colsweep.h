@@ -339,19 +339,7 @@ k_backup_colsweep(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
 }
 
 // ---- several problems, one launch (hjb_solve_batch: Solver_pos_att.simplified_run's four channels, pos-att/Solver_pos_att.m:197-242) --
-// The reference's own channels are 2.7e5 states each: a stage kernel of one of them is a launch boundary plus one wave's chain of
-// round trips (~10 us), and of four such chains on four streams the device runs two at full rate.  blockIdx.y = the problem; each
-// keeps its own plan, tables, buffers and workgroup count; `mask` drops the problems whose monitor has stopped them; `parity`
-// says which of a problem's two J buffers is the input.
-constexpr int kCsBatchMax = 8;
-struct DCsBatch {
-    const DParams *P[kCsBatchMax];
-    const DTabled *TB[kCsBatchMax];
-    const DColSweep *CS[kCsBatchMax];
-    void *J[kCsBatchMax][2];
-    void *idx[kCsBatchMax];
-    uint32_t grid[kCsBatchMax];
-};
+// blockIdx.y = the problem (DCsBatch: kernels_tabled.h); the body is the stage kernel's own.
 template <typename T, typename TJ, int GAX, int NG, bool FASTCOST, bool DPP, bool C64 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     (DPP && NG <= 5 && !C64) ? ((FASTCOST && sizeof(TJ) == 4 && (GAX == 2 || NG <= 4)) ? HJB_CS_WAVES : 5) : 1,

@@ -268,10 +268,11 @@ __device__ __forceinline__ int tab32_ctrl_off(const int32_t *stride_c, const int
     return off;
 }
 
+// The kernel's body: the states of workgroup `bx` of `gx` (the launch's own blockIdx.x / gridDim.x in k_backup_tabled32; the
+// problem's share of a batched launch in k_backup_tabled32_batch).
 template <typename T, typename TJ, int D>
-__global__ void __launch_bounds__(256)
-k_backup_tabled32(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
-                  TJ *__restrict__ Jout, void *__restrict__ idx_out) {
+__device__ __forceinline__ void tabled32_body(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
+                                              TJ *__restrict__ Jout, void *__restrict__ idx_out, unsigned bx, unsigned gx) {
     const int C = P->C;
     const int n_owned = (int)P->n_owned;
     const int nU = (int)P->nU;
@@ -293,7 +294,7 @@ k_backup_tabled32(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         poff[p] = o;
     }
     const int m1 = P->m[1], m2 = P->m[2];
-    for (int ls = (int)(blockIdx.x * blockDim.x + threadIdx.x); ls < n_owned; ls += (int)(gridDim.x * blockDim.x)) {
+    for (int ls = (int)(bx * blockDim.x + threadIdx.x); ls < n_owned; ls += (int)(gx * blockDim.x)) {
         int si[D], sl[D];
         {
             uint32_t r = (uint32_t)ls;
@@ -454,6 +455,40 @@ k_backup_tabled32(const DParams *__restrict__ P, const DTabled *__restrict__ TB,
         stj<T, TJ>(Jout, (int64_t)(in_plane + inner * (pl + (uint32_t)P->halo_lo)), best);
         if (idx_out) st_idx(idx_out, ls, (int32_t)(label + P->index_base), P->idx_bytes);
     }
+}
+
+template <typename T, typename TJ, int D>
+__global__ void __launch_bounds__(256)
+k_backup_tabled32(const DParams *__restrict__ P, const DTabled *__restrict__ TB, const TJ *__restrict__ Jn,
+                  TJ *__restrict__ Jout, void *__restrict__ idx_out) {
+    tabled32_body<T, TJ, D>(P, TB, Jn, Jout, idx_out, blockIdx.x, gridDim.x);
+}
+
+// ---- several problems, one launch (hjb_solve_batch) -------------------------------------------------------------------------------
+// The reference's simplified_run sweeps its channels one after the other (attitude-control/Solver_attitude.m:196-259: three channels of
+// 3e5 states x 5999 stages; pos-att/Solver_pos_att.m:197-242: four of 2.7e5 x 1999): a stage kernel of one of them is a launch boundary
+// plus one wave's chain of round trips, and of several such chains on streams of their own the device runs two at full rate.  Here
+// blockIdx.y = the problem; each keeps its own parameters, tables, buffers and workgroup count; `mask` drops the problems whose
+// monitor has stopped them; `parity` says which of a problem's two J buffers is the input.  The table kernel takes the record BY VALUE
+// (416 bytes of kernel arguments): pointers that arrive as kernel arguments are known to be global and unclobbered, so the body's
+// wave-uniform reads through P / TB stay scalar loads - handed over as a pointer to the record they became 61 flat loads and twice
+// the registers (108 instead of 55 for float64 D = 2), and the batch was slower than three chains.
+struct DColSweep;
+constexpr int kCsBatchMax = 8;
+struct DCsBatch {
+    const DParams *P[kCsBatchMax];
+    const DTabled *TB[kCsBatchMax];
+    const DColSweep *CS[kCsBatchMax];      // (the column-sweep kernel's plan: kernels_colsweep.h)
+    void *J[kCsBatchMax][2];
+    void *idx[kCsBatchMax];
+    uint32_t grid[kCsBatchMax];
+};
+template <typename T, typename TJ, int D>
+__global__ void __launch_bounds__(256)
+k_backup_tabled32_batch(const DCsBatch B, uint32_t mask, int parity) {
+    const unsigned ch = blockIdx.y;
+    if (!((mask >> ch) & 1u) || blockIdx.x >= B.grid[ch]) return;
+    tabled32_body<T, TJ, D>(B.P[ch], B.TB[ch], (const TJ *)B.J[ch][parity], (TJ *)B.J[ch][parity ^ 1], B.idx[ch], blockIdx.x, B.grid[ch]);
 }
 
 }  // namespace hjb

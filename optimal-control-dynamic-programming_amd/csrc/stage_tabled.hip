@@ -34,6 +34,26 @@ static int go(const StageArgs &a) {
     return 0;
 }
 
+// n problems of one (dtype, D) as one launch of the 32-bit form (blockIdx.y = the problem): hjb_solve_batch
+template <typename T, typename TJ>
+static int go_batch(const StageArgs &a, int n, const DCsBatch &hB, uint32_t mask, int parity) {
+    const dim3 g(a.grid, (unsigned)n), b(a.block);
+    switch (a.D) {
+        case 1: hipLaunchKernelGGL((k_backup_tabled32_batch<T, TJ, 1>), g, b, 0, a.st, hB, mask, parity); break;
+        case 2: hipLaunchKernelGGL((k_backup_tabled32_batch<T, TJ, 2>), g, b, 0, a.st, hB, mask, parity); break;
+        case 3: hipLaunchKernelGGL((k_backup_tabled32_batch<T, TJ, 3>), g, b, 0, a.st, hB, mask, parity); break;
+        case 4: hipLaunchKernelGGL((k_backup_tabled32_batch<T, TJ, 4>), g, b, 0, a.st, hB, mask, parity); break;
+        default: return 1;       // (5-D / 6-D grids are not launch-bound: hjb_solve on threads of their own)
+    }
+    return 0;
+}
+
+int stage_tabled_batch(const StageArgs &a, int n, const DCsBatch &hB, uint32_t mask, int parity) {
+    if (a.dtype == HJB_F16S) return go_batch<float, _Float16>(a, n, hB, mask, parity);
+    if (a.dtype == HJB_F32) return go_batch<float, float>(a, n, hB, mask, parity);
+    return go_batch<double, double>(a, n, hB, mask, parity);
+}
+
 int stage_tabled(const StageArgs &a) {
     if (a.dtype == HJB_F16S) return go<float, _Float16>(a);
     if (a.dtype == HJB_F32) return go<float, float>(a);

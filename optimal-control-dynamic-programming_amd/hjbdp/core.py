@@ -521,8 +521,8 @@ def suggest_axis_order(spec):
 def solve_batch(specs, n_stages, device=0, monitor_period=0, monitor_tol=0.0, progress=None, monitor_single=False, cs_split=None):
     """Independent sweeps side by side with as few launch chains as the library can make of them (the four channels of
     Solver_pos_att.simplified_run, pos-att/Solver_pos_att.m:197-242): problems that run on the column-sweep kernel with the same group
-    axis share ONE launch per stage (hjb_solve_batch); each such group, and every problem that is alone in its shape, gets a host
-    thread and a stream of its own (the device runs two launch chains at full rate: three channels + one is two chains).  Every
+    axis, or on the table kernel's 32-bit form with one (dtype, D), share ONE launch per stage (hjb_solve_batch); each such group, and
+    every problem that is alone in its shape, gets a host thread and a stream of its own (the device runs two launch chains at full rate: three channels + one is two chains).  Every
     problem keeps its own monitor sums and stop decision; results equal Backup.solve's bit for bit.
     -> (outs, wall_ms, variants, group sizes)"""
     import time
@@ -539,8 +539,21 @@ def solve_batch(specs, n_stages, device=0, monitor_period=0, monitor_tol=0.0, pr
         variants = [bk.info()["kernel_variant"] for bk in bks]
         groups = {}
         for i, bk in enumerate(bks):
-            key = ("colsweep", bk.get_option("cs_group_axis"), bk.spec.cost_dtype is not None) if variants[i] == 7 else ("alone", i)
+            if variants[i] == 7:
+                key = ("colsweep", bk.get_option("cs_group_axis"), bk.spec.cost_dtype is not None)
+            elif variants[i] == 5 and bk.spec.D <= 4:
+                key = ("tabled", np.dtype(bk.spec.j_dtype).str, bk.spec.D)
+            else:
+                key = ("alone", i)
             groups.setdefault(key, []).append(i)
+        # The table kernel is one state per thread: a batch pays off while ALL its states are resident at once (a launch-bound stage);
+        # beyond one round of the wave slots (256 CUs x 32 waves x 64 lanes) the launches run round after round and three chains on
+        # three streams overlap better than one launch (Solver_attitude.simplified_run's 3 x 3e5 states: 130 ms batched, 82 ms as
+        # chains - profiles/r06_batch_attitude.log)
+        for key in [k for k in groups if k[0] == "tabled"]:
+            if len(groups[key]) > 1 and sum(specs[i].nS for i in groups[key]) > 256 * 32 * 64:
+                for i in groups.pop(key):
+                    groups[("alone", i)] = [i]
         outs = [None] * n
         if cs_split is None:
             # Parts per column of the column-sweep problems.  A handle alone picks as many parts as fill the device (it is one wave's
@@ -589,14 +602,19 @@ def solve_batch(specs, n_stages, device=0, monitor_period=0, monitor_tol=0.0, pr
                         outs[i] = {"J": J, "idx": idx, "J_stages": None, "idx_stages": None, "stages_done": r.stages_done,
                                    "stopped_early": bool(r.stopped_early), "sweep_ms": r.sweep_ms, "last_e": r.last_e, "last_e2": r.last_e2,
                                    "probe": None}
-                    return m
+                    return [m]
                 if st != _abi.HJB_E_UNSUPPORTED:
                     _check(lib, None, st)
-            for i in members:               # alone in its shape (or a group the library did not take): the plain sweep
+            def one(i):                     # alone in its shape (or a group the library did not take): the plain sweep
                 outs[i] = bks[i].solve(n_stages, **kw)
-            return 1
+            if len(members) == 1:
+                one(members[0])
+            else:
+                with ThreadPoolExecutor(max_workers=len(members)) as ex2:
+                    list(ex2.map(one, members))
+            return [1] * len(members)
         with ThreadPoolExecutor(max_workers=max(1, len(groups))) as ex:
-            sizes = list(ex.map(run, groups.values()))
+            sizes = [m for ms in ex.map(run, groups.values()) for m in ms]
         t_run = time.perf_counter()
     finally:
         for bk in bks:

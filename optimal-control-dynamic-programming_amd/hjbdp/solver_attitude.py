@@ -17,7 +17,7 @@ import math
 
 import numpy as np
 
-from .core import Backup, solve_many
+from .core import Backup, solve_batch, solve_many
 from .matlab_compat import deg2rad, linspace
 from .problem import ProblemSpec, Term
 from .solver_position import NearestPolicy
@@ -51,6 +51,8 @@ class Solver_attitude:
         self.J1, self.J2, self.J3 = self.InertiaM[0, 0], self.InertiaM[1, 1], self.InertiaM[2, 2]   # InertiaM(1),(5),(9)
         self.U_vector = np.array([-0.11, 0.0, 0.11])
         self.device = 0
+        self.batch_channels = True     # simplified_run: the three channels as one launch per stage (False: three chains on threads)
+        self.batch_groups = None
         self.U1_Opt = self.U2_Opt = self.U3_Opt = None
         self.F_values = None
         self.U_idx = None
@@ -91,8 +93,12 @@ class Solver_attitude:
         self.F_values, self.U_idx, self.sweep_ms = [None] * 3, [None] * 3, [None] * 3
         self.U_Opt_stages = self.U_idx_stages = None
         built = [self.build_spec_simplified(ch) for ch in range(3)]
-        outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device,   # channels side by side
-                                           keep_idx=bool(keep_policy))
+        if keep_policy or not self.batch_channels:
+            outs, self.wall_ms, _ = solve_many([b[0] for b in built], n_st, device=self.device,   # channels side by side
+                                               keep_idx=bool(keep_policy))
+            self.batch_groups = [1, 1, 1]
+        else:                              # ... as ONE launch per stage for the three (hjb_solve_batch)
+            outs, self.wall_ms, _, self.batch_groups = solve_batch([b[0] for b in built], n_st, device=self.device)
         if keep_policy:
             self.U_idx_stages = [outs[ch]["idx_stages"].reshape(len(built[ch][1]), len(built[ch][2]), n_st, order="F") for ch in range(3)]
             self.U_Opt_stages = [self.U_vector[ix - 1] for ix in self.U_idx_stages]

@@ -182,6 +182,7 @@ def test_attitude_simplified_reference_grid_200_stages_whole_grid(env):
     sa = hjbdp.Solver_attitude()
     assert sa.n_mesh_w_simplified == 1000 and sa.n_mesh_t == 300
     sa.simplified_run(n_stages=200)
+    assert sa.batch_groups == [1, 1, 1]      # 3 x 3e5 states are more than one round of the wave slots: three chains, not one batch
     for ch in range(3):
         spec, s_w, s_t = sa.build_spec_simplified(ch)
         assert spec.n == (1000, 300) and spec.dtype == np.float64

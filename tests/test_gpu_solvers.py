@@ -54,12 +54,19 @@ def test_solver_position_value_is_monotone_in_horizon(env):
 def test_solver_attitude_simplified(env):
     hjbdp, _abi, c_oracle = env
     sa = hjbdp.Solver_attitude(n_mesh_t=70, n_mesh_w_simplified=150)
-    sa.simplified_run(n_stages=40)
+    sa.simplified_run(n_stages=70)           # (>= 64 stages: the batch's stage loop replays its graph, then runs eagerly)
+    assert sa.batch_groups == [3]            # one launch per stage for the three channels
     for ch in range(3):
         spec, s_w, s_t = sa.build_spec_simplified(ch)
-        ref = c_oracle.sweep(_abi, spec, 40)
+        ref = c_oracle.sweep(_abi, spec, 70)
         assert np.array_equal(sa.F_values[ch].reshape(-1, order="F"), ref["J"])
         assert np.array_equal(sa.U_idx[ch].reshape(-1, order="F"), ref["idx"])
+    sb = hjbdp.Solver_attitude(n_mesh_t=70, n_mesh_w_simplified=150)
+    sb.batch_channels = False                # three chains on threads of their own
+    sb.simplified_run(n_stages=70)
+    assert sb.batch_groups == [1, 1, 1]
+    for ch in range(3):
+        assert np.array_equal(sa.F_values[ch], sb.F_values[ch]) and np.array_equal(sa.U_idx[ch], sb.U_idx[ch])
 
 
 @pytest.mark.order(7)
@@ -333,8 +340,8 @@ def test_solver_pos_att_channel_reference_grid(env, form):
 def test_solver_pos_att_all_channels_with_monitor(env, grid):
     """simplified_run (4 channels incl. the thruster-failure one) with the early-stop monitor, as the mirror runs it by default: on the
     reference's own 30x30x20x15 grid the channels land on the column-sweep kernel and those that share a group axis are ONE launch per
-    stage (hjb_solve_batch), each with its own monitor sums and stop stage; on a small grid (the table kernel) every channel is a chain
-    of its own.  Every channel - values, labels, stop stage - equals the oracle's sweep of that channel, and the same run with the
+    stage (hjb_solve_batch), each with its own monitor sums and stop stage; on a small grid the four land on the table kernel and are
+    one launch per stage of that one.  Every channel - values, labels, stop stage - equals the oracle's sweep of that channel, and the same run with the
     channels on threads of their own (batch_channels = False: hjb_solve x 4)."""
     hjbdp, _abi, c_oracle = env
     n_st, period, tol = (69, 10, 290000.0) if grid == "reference" else (120, 10, 5.0)
@@ -350,8 +357,8 @@ def test_solver_pos_att_all_channels_with_monitor(env, grid):
     pa = mirror()
     events = []
     pa.simplified_run(n_stages=n_st, progress=lambda k_s, e, e2, sec: events.append(k_s))
-    assert sorted(pa.batch_groups) == ([1, 3] if grid == "reference" else [1, 1, 1, 1]), pa.batch_groups
-    assert pa.batched == (grid == "reference")
+    assert sorted(pa.batch_groups) == ([1, 3] if grid == "reference" else [4]), pa.batch_groups
+    assert pa.batched
     assert set(pa.controllers) == {"channel_x_controller_1", "channel_y_controller_1", "channel_z_controller_1",
                                    "channel_x_controller_1_failure"}
     sx, sv, st, sw = pa.grids()
