@@ -21,6 +21,7 @@ int policy_lookup_t(int32_t D, const int32_t *n, const double *const *knots, con
             if (!(kk[i + 1] > kk[i])) {
                 for (void *d : h->allocs) (void)hipFree(d);      // the axes uploaded so far
                 h->allocs.clear();
+                h->arena_left = 0;
                 g_last_error = "lookup: knots not strictly increasing";
                 return HJB_E_INVALID;
             }
@@ -62,6 +63,7 @@ int policy_lookup_t(int32_t D, const int32_t *n, const double *const *knots, con
     }
     for (void *d : h->allocs) (void)hipFree(d);
     h->allocs.clear();
+    h->arena_left = 0;
     if (st) return st;
     if (e != hipSuccess) return fail(nullptr, HJB_E_DEVICE, "hjb_policy_lookup: %s", hipGetErrorString(e));
     return HJB_OK;

@@ -66,7 +66,9 @@ struct Handle {
     int nplanes = 0, plane0 = 0;
     DParams hp{};                 // host copy of the device params
     DParams *dp = nullptr;        // device params
-    std::vector<void *> allocs;   // every device allocation (freed in destroy)
+    std::vector<void *> allocs;   // every device allocation (freed in destroy): large ones and the chunks the small ones are carved from
+    char *arena = nullptr;        // dev_alloc: the current chunk's free part
+    size_t arena_left = 0;
     int32_t *d_status = nullptr;
     // work buffers (lazy)
     void *dJ[2] = {nullptr, nullptr};
@@ -169,11 +171,12 @@ inline hipError_t sync_setup() { return hipStreamSynchronize(nullptr); }
                         __FILE__, __LINE__);                                                   \
     } while (0)
 
+int dev_alloc(Handle *h, size_t bytes, void **out);
 template <typename T>
 int upload(Handle *h, const std::vector<T> &v, void **out) {
     void *d = nullptr;
-    HIP_TRY(h, hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
-    h->allocs.push_back(d);
+    const int ast = dev_alloc(h, std::max<size_t>(v.size(), 1) * sizeof(T), &d);
+    if (ast) return ast;
     if (!v.empty()) HIP_TRY(h, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = d;
     return HJB_OK;

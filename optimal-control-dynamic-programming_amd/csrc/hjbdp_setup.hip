@@ -22,9 +22,29 @@ int fail(Handle *h, int code, const char *fmt, ...) {
     return code;
 }
 
+// Every device allocation of a handle.  Small ones (plans, tables, cost terms, records: dozens per handle) are carved out of 1 MiB
+// chunks: hipMalloc / hipFree cost 50 - 200 us each and hipFree waits for the device, which was 8 of the 64 ms of a whole
+// Solver_pos_att.simplified_run (four handles; profiles/r06_batch_split.log, block 3).  256-byte aligned (the widest access of the
+// kernels is 64 bytes: s_load_dwordx16 of a launch record).
 int dev_alloc(Handle *h, size_t bytes, void **out) {
+    constexpr size_t kChunk = (size_t)1 << 20, kSmall = (size_t)128 << 10, kAlign = 256;
+    bytes = std::max<size_t>(bytes, 16);
+    if (bytes <= kSmall) {
+        const size_t need = (bytes + kAlign - 1) & ~(kAlign - 1);
+        if (h->arena_left < need) {
+            void *c = nullptr;
+            HIP_TRY(h, hipMalloc(&c, kChunk));
+            h->allocs.push_back(c);
+            h->arena = (char *)c;
+            h->arena_left = kChunk;
+        }
+        *out = h->arena;
+        h->arena += need;
+        h->arena_left -= need;
+        return HJB_OK;
+    }
     void *d = nullptr;
-    HIP_TRY(h, hipMalloc(&d, std::max<size_t>(bytes, 16)));
+    HIP_TRY(h, hipMalloc(&d, bytes));
     h->allocs.push_back(d);
     *out = d;
     return HJB_OK;
