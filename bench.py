@@ -247,6 +247,7 @@ def run_c3(args, steps, warmup, dev, n=51):
     stream = torch.cuda.current_stream(dev).cuda_stream
     with hjbdp.Backup(spec, device=dev.index or 0) as bk:
         info = bk.info()
+        info["packed2_mode"] = bk.get_option("packed2_mode")              # 7 / 8: the rate-shared window kernel (K15) runs
         k = 0
         for _ in range(warmup):
             bk.backup_stage_device(J[k & 1], J[1 - (k & 1)], idx, stream=stream)
@@ -282,6 +283,8 @@ def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=Fal
         sw.set_option("variant", args.variant)
     info = sw.info()
     info["comm_ranks"] = sw.comm_ranks()
+    if info["kernel_variant"] == 4:
+        info["packed2_mode"] = sw.get_option("packed2_mode")
     sw.set_terminal(None)
 
     def barrier():
@@ -435,6 +438,8 @@ def main():
         tflops = f_alg(sp.D) * backups / (launch_ms * 1e-3) / 1e12
         gbs = bytes_state * res["states_rank"] / (launch_ms * 1e-3) / 1e9
         kname = KERNEL_OF_VARIANT.get(inf["kernel_variant"], "k_backup")
+        if inf["kernel_variant"] == 4 and inf.get("packed2_mode", 0) >= 7:
+            kname = "k_backup_uniwin"                              # variant 4, modes 7 / 8 (kernels_uniwin.h)
         pmc = (pmc_all or {}).get(workload)
         traffic = traffic_raw = valu_util = None
         if pmc:

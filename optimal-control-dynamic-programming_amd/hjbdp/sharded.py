@@ -182,6 +182,9 @@ class ShardedSweep:
     def set_option(self, key, value):
         self._rank.set_option(key, value)
 
+    def get_option(self, key):
+        return self._rank.get_option(key)
+
     def check_device_status(self):
         if getattr(self, "_comm_stream", None) is not None:       # a trailing exchange (post_exchange) may still be in flight
             self.torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
