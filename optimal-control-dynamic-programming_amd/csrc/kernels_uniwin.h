@@ -257,6 +257,13 @@ __device__ __forceinline__ f2 uw_fma_sel_rt(int sel, f2 s, f2 a, f2 b) {
 #ifndef HJB_UW_UNROLL_O1
 #define HJB_UW_UNROLL_O1 0
 #endif
+// 1: the running minimum is kept per TRIP (min(mA, mB) against the best so far: 5 vector instructions), and which of the trip's two
+// steps - and which control - reached it is found when the winning trip is evaluated once more per state; 0: per step (9 of a trip's
+// 73 vector instructions).  Same result: the first (step, control) in sweep order whose total equals the minimum.  Built and
+// measured (profiles/r06_k15_triptrack.log): bit-exact on the whole K15 suite, 24^6 30.27 -> 30.09 ms, C3 equal - off.
+#ifndef HJB_UW_TRIPTRACK
+#define HJB_UW_TRIPTRACK 0
+#endif
 
 // BLOCK = states per workgroup = per chunk: 256 (four waves; 27.7 KB of LDS: five workgroups = 20 waves per CU) or 64 (ONE wave per
 // workgroup: 7 KB of LDS, 23 workgroups per CU - the LDS is handed out in finer pieces - at <= 80 VGPRs: 5.75 waves per SIMD)
@@ -563,8 +570,13 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
 #undef HJB_PF
 #endif
                     const int uo = uo0 + o1;
+#if HJB_UW_TRIPTRACK
+                    const float mAB = uw_min2(mA, mB);
+                    if (uo == 0 || mAB < best) { best = mAB; best_uo = uo; }      // (the trip's FIRST step; see the label below)
+#else
                     if (uo == 0 || mA < best) { best = mA; best_uo = uo; }
                     if (mB < best) { best = mB; best_uo = uo + 1; }
+#endif
                 }
                 // ---- the last step of an odd count: one step, two CONTROLS in the halves -----------------------------------------
                 if (o1 < mo1) {
@@ -641,51 +653,61 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
             // ---- which inner control: the winning step's controls once more, in order (first-minimum rule) ----------------------
             int best_j = 0;
             {
-                const int o0 = (int)udiv_gm((uint32_t)best_uo, N->div_m_o1, N->div_s_o1), o1 = best_uo - o0 * m_o1;
+                const int o0 = (int)udiv_gm((uint32_t)best_uo, N->div_m_o1, N->div_s_o1), o1f = best_uo - o0 * m_o1;
                 const int cA = __builtin_amdgcn_ds_bpermute((kUwA + 2 * o0) * 4, rec0);
                 const float tA = __int_as_float(__builtin_amdgcn_ds_bpermute((kUwA + 2 * o0 + 1) * 4, rec0));
-                const int cB = __builtin_amdgcn_ds_bpermute((kUwB + 2 * o1) * 4, rec0);
-                const float tB = __int_as_float(__builtin_amdgcn_ds_bpermute((kUwB + 2 * o1 + 1) * 4, rec0));
-                float g = gpre;
+                float g0 = gpre;
                 if (cl0_present) {
                     const float x = s_ot[N->ot[CL0].lds_off + o0 * N->ot[CL0].c0];
-                    g = cl0_first ? x : g + x;
+                    g0 = cl0_first ? x : g0 + x;
                 }
-                if (cl1_present) {
-                    const float x = s_ot[cl1_off + o0 * cl1_c0 + o1 * cl1_c1];
-                    g = cl1_first ? x : g + x;
-                }
-                const int ra = cA - cAmin, rb = cB - cBmin;
-                float xe[2], xd[2];
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    const int q0 = w == 0 ? qa : qb;
-                    float X[2];
-#pragma unroll
-                    for (int dq = 0; dq < 2; ++dq) {
-                        float Fr[2];
-#pragma unroll
-                        for (int db = 0; db < 2; ++db) {
-                            const float f0 = my_w[((ra * 3 + rb + db) * 3 + q0 + dq) * BLOCK];
-                            const float f1 = my_w[(((ra + 1) * 3 + rb + db) * 3 + q0 + dq) * BLOCK];
-                            Fr[db] = __builtin_fmaf(tA, f1 - f0, f0);
-                        }
-                        X[dq] = __builtin_fmaf(tB, Fr[1] - Fr[0], Fr[0]);
-                    }
-                    xe[w] = X[0];
-                    xd[w] = X[1] - X[0];
-                }
+                const int ra = cA - cAmin;
                 bool found = false;
+                int best_o1 = o1f;
+                // HJB_UW_TRIPTRACK: best_uo names the winning trip's first step; its second step (if it has one: trips start at even
+                // o1, the last step of an odd count stands alone) is searched after it - first (step, control) in sweep order
 #pragma unroll
-                for (int j = 0; j < kUwIn; ++j) {
-                    if (j < m_in) {
-                        const bool second = j >= jc;
-                        const float rj = (j & 1) ? rp[j >> 1].y : rp[j >> 1].x, tj = (j & 1) ? tp[j >> 1].y : tp[j >> 1].x;
-                        const float tot = (g + rj) + __builtin_fmaf(tj, second ? xd[1] : xd[0], second ? xe[1] : xe[0]);
-                        if (!found && tot == best) { best_j = j; found = true; }
+                for (int sx = 0; sx < (HJB_UW_TRIPTRACK ? 2 : 1); ++sx) {
+                    const bool has = sx == 0 || o1f + 1 < m_o1;
+                    const int o1 = has ? o1f + sx : o1f;                              // (lane reads stay inside the record)
+                    const int cB = __builtin_amdgcn_ds_bpermute((kUwB + 2 * o1) * 4, rec0);      // (every lane takes part: a lane
+                    const float tB = __int_as_float(__builtin_amdgcn_ds_bpermute((kUwB + 2 * o1 + 1) * 4, rec0));   // read of an idle lane is 0)
+                    float g = g0;
+                    if (cl1_present) {
+                        const float x = s_ot[cl1_off + o0 * cl1_c0 + o1 * cl1_c1];
+                        g = cl1_first ? x : g + x;
+                    }
+                    const int rb = cB - cBmin;
+                    float xe[2], xd[2];
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const int q0 = w == 0 ? qa : qb;
+                        float X[2];
+#pragma unroll
+                        for (int dq = 0; dq < 2; ++dq) {
+                            float Fr[2];
+#pragma unroll
+                            for (int db = 0; db < 2; ++db) {
+                                const float f0 = my_w[((ra * 3 + rb + db) * 3 + q0 + dq) * BLOCK];
+                                const float f1 = my_w[(((ra + 1) * 3 + rb + db) * 3 + q0 + dq) * BLOCK];
+                                Fr[db] = __builtin_fmaf(tA, f1 - f0, f0);
+                            }
+                            X[dq] = __builtin_fmaf(tB, Fr[1] - Fr[0], Fr[0]);
+                        }
+                        xe[w] = X[0];
+                        xd[w] = X[1] - X[0];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kUwIn; ++j) {
+                        if (j < m_in) {
+                            const bool second = j >= jc;
+                            const float rj = (j & 1) ? rp[j >> 1].y : rp[j >> 1].x, tj = (j & 1) ? tp[j >> 1].y : tp[j >> 1].x;
+                            const float tot = (g + rj) + __builtin_fmaf(tj, second ? xd[1] : xd[0], second ? xe[1] : xe[0]);
+                            if (!found && has && tot == best) { best_j = j; best_o1 = o1; found = true; }
+                        }
                     }
                 }
-                label = o0 + P->m[0] * (o1 + P->m[1] * best_j);
+                label = o0 + P->m[0] * (best_o1 + P->m[1] * best_j);
             }
         } else {
             // ---- a point outside the usual shape: every backup on its own, from the tables (rare by the host's choice) -------------
