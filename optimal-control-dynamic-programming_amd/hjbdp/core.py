@@ -563,7 +563,7 @@ def solve_batch(specs, n_stages, device=0, monitor_period=0, monitor_tol=0.0, pr
             cs = [i for i in range(n) if variants[i] == 7]
             if len(cs) > 1:
                 cols = sum(-(-specs[i].n[0] // 60) * specs[i].n[2] * specs[i].n[3] for i in cs)
-                slots = (4 if any(specs[i].cost_dtype is not None for i in cs) else 6) * 4 * 256
+                slots = (5 if any(specs[i].cost_dtype is not None for i in cs) else 6) * 4 * 256          # waves per SIMD of the form that runs (86 / 80 registers) x SIMDs
                 cs_split = max(1, slots // max(cols, 1))
                 cs_split = cs_split if all(cs_split < bks[i].get_option("cs_split") for i in cs) else 0
 
