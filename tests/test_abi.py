@@ -307,6 +307,27 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
         ds.run()
 
 
+def test_solve_batch_checks_its_arguments_before_any_device_work(lib):
+    """hjb_solve_batch (include/hjbdp.h): a null or empty batch is HJB_E_INVALID, more than eight problems HJB_E_UNSUPPORTED - decided
+    on the host, before a device is touched (no GPU here); the Python entry point without a device fails loudly like Backup does."""
+    import ctypes as C
+    import hjbdp
+    from hjbdp import _abi
+    lib.hjb_solve_batch.restype = C.c_int32
+    assert lib.hjb_solve_batch(0, None, None, None) == _abi.HJB_E_INVALID
+    assert lib.hjb_solve_batch(2, None, None, None) == _abi.HJB_E_INVALID
+    hs = (C.c_void_p * 9)()
+    op = (C.POINTER(_abi.hjb_solve_opts) * 9)()
+    assert lib.hjb_solve_batch(9, hs, op, None) == _abi.HJB_E_UNSUPPORTED
+    assert lib.hjb_solve_batch(2, hs, op, None) == _abi.HJB_E_INVALID          # null handles
+    if hjbdp.device_count() == 0:
+        k = np.linspace(0, 1, 5)
+        spec = hjbdp.ProblemSpec([k], [3], [[hjbdp.Term((0,), k)]], [hjbdp.Term((0,), k)])
+        with pytest.raises(hjbdp.HjbError) as ei:
+            hjbdp.solve_batch([spec, spec], 3)
+        assert ei.value.status == _abi.HJB_E_DEVICE
+
+
 def test_host_without_librccl_gets_a_status_not_a_crash(built):
     """with no librccl to dlopen (here: the loader restricted to $HJBDP_RCCL_LIB, which names nothing),
     hjb_rank_comm_unique_id returns HJB_E_UNSUPPORTED and the loader's message - it used to build that message from a
