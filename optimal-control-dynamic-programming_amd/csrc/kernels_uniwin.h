@@ -494,7 +494,11 @@ k_backup_uniwin(const DParams *__restrict__ P, const DNested *__restrict__ N, co
                 f2 c2_nx = {-0.0f, -0.0f};                                          // (an absent term: g + (-0) == g bit for bit)
                 if (cl1_present && m_o1 > 1) c2_nx = (f2){cl1g[0], cl1g[cl1_c1]};
                 // ---- two (o0, o1) steps per trip, the two STEPS in the halves of every packed instruction -------------------------
+#if HJB_UW_UNROLL_O1 > 0
 #pragma unroll
+#else
+#pragma unroll 1
+#endif
                 for (; o1 + 1 < mo1; o1 += 2) {
 #if HJB_UW_SMEM
                     const i4v eb = eb_nx;                                           // (cell, t) of steps o1 and o1 + 1
