@@ -39,13 +39,14 @@
 // is regular; the host admits the form when no 60-state chunk has more than one such state.
 // (Fetching the neighbour through the LDS crossbar, ds_bpermute_b32, was measured slower: 2.90 vs 2.67 ms at the time.)
 //
-// The rest of the schedule, each step of it measured (profiles/r02_c4_experiments.log): gathers issued
-// and awaited by hand in two halves of the group sequence (counted s_waitcnt through a computed jump); results parked
-// in LDS and written out every 20 steps; the four waves of a workgroup - neighbours on the group axis - take every
-// step together (s_barrier) so that they share L1 lines; a launch with few columns (a multi-GPU slab, its boundary
-// strips, a small grid) sweeps each column in several parts, one wave each (DColSweep::split); workgroup b serves XCD
-// b % 8.  C4 (120^4 x 9, float32): 1.81 ms per stage = 1.03e12 backups/s.  Same values, same arithmetic as every
-// other variant: bit-identical results.
+// The rest of the schedule, each step of it measured (profiles/r0*_c4_experiments.log): gathers issued
+// and awaited by hand in two halves of the group sequence (counted s_waitcnt through a computed jump); results stored
+// at once by hand-issued stores (HJB_CS_DIRECT below; parked in LDS and flushed every 16 steps until round 5); the four
+// waves of a workgroup - neighbours on the group axis - take every step together (s_barrier) so that they share L1
+// lines; a launch with few columns (a multi-GPU slab, its boundary strips, a small grid) sweeps each column in several
+// parts, one wave each (DColSweep::split); workgroup b serves XCD b % 8.  C4 (120^4 x 9, float32): 1.52 - 1.60 ms per
+// stage by box = 1.17 - 1.23e12 backups/s (round 2: 1.81).  Same values, same arithmetic as every other variant:
+// bit-identical results.
 #pragma once
 #include <cstddef>
 #include "hjbdp_dev.h"
@@ -169,7 +170,7 @@ __device__ __forceinline__ void take_tie(float best, int &best_u, float tot, int
 // every wait into `vmcnt(0)` - a full drain that also waits for the rows just requested for the next half step.  Here the
 // loads are asm statements the compiler does not track; a wait is `s_waitcnt vmcnt(N)` with N = the exact number of
 // younger gathers, tied to the awaited registers by "+v" operands so that no use can move above it.  Safe because
-// loads return in order and the only stores of the loop are followed by a full drain (see the flush below).
+// loads return in order among themselves, whatever the stores of the loop do (HJB_CS_DIRECT above).
 template <int BYTES>
 __device__ __forceinline__ uint32_t gather_async(uint32_t off, gptr<char> base) {
     uint32_t r;
