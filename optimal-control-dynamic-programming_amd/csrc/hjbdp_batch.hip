@@ -70,28 +70,8 @@ int32_t hjb_solve_batch(int32_t n, const hjb_handle *hs, const hjb_solve_opts *c
     // (profiles/r06_batch_split.log: the reference's channels, 4 x 450 columns of 20 steps, 10 parts each when alone - 2 to 4 here).
     int old_split[kCsBatchMax];
     bool resplit = false;
-    if (!tabled) {
-        int64_t columns = 0;
-        for (int i = 0; i < n; ++i) {
-            const DParams &P = H[i]->hp;
-            columns += (int64_t)((P.n[0] + kCsDppLanes - 1) / kCsDppLanes) * P.n[2] * P.n[3];
-        }
-        const int64_t slots = (int64_t)(h0->cost64 ? 5 : 6) * 4 * 256;                   // waves per SIMD of the form that runs (82 / 80 registers) x SIMDs
-        const int s_batch = (int)std::max<int64_t>(1, slots / std::max<int64_t>(columns, 1));
-        for (int i = 0; i < n; ++i) {
-            Handle *h = H[i];
-            old_split[i] = h->cs_split;
-            if (h->cs_split == 0 && s_batch < (int)h->hcs.split) {      // (an explicit option "cs_split" stands)
-                h->cs_split = s_batch;
-                colsweep_split(h);
-                const int ust = colsweep_upload(h);
-                if (ust) return ust;
-                choose_launch(h);
-                resplit = true;
-            }
-        }
-    }
-    auto restore_split = [&]() {
+    for (int i = 0; i < n; ++i) old_split[i] = H[i]->cs_split;
+    auto restore_split = [&]() {              // every handle gets its own parts back, on every way out
         if (!resplit) return;
         for (int i = 0; i < n; ++i) {
             Handle *h = H[i];
@@ -102,7 +82,30 @@ int32_t hjb_solve_batch(int32_t n, const hjb_handle *hs, const hjb_solve_opts *c
             choose_launch(h);
         }
     };
-    if (!h0->stream) HIP_TRY(h0, hipStreamCreateWithFlags(&h0->stream, hipStreamNonBlocking));
+    if (!tabled) {
+        int64_t columns = 0;
+        for (int i = 0; i < n; ++i) {
+            const DParams &P = H[i]->hp;
+            columns += (int64_t)((P.n[0] + kCsDppLanes - 1) / kCsDppLanes) * P.n[2] * P.n[3];
+        }
+        const int64_t slots = (int64_t)(h0->cost64 ? 5 : 6) * 4 * 256;                   // waves per SIMD of the form that runs (82 / 80 registers) x SIMDs
+        const int s_batch = (int)std::max<int64_t>(1, slots / std::max<int64_t>(columns, 1));
+        for (int i = 0; i < n; ++i) {
+            Handle *h = H[i];
+            if (h->cs_split == 0 && s_batch < (int)h->hcs.split) {      // (an explicit option "cs_split" stands)
+                h->cs_split = s_batch;
+                resplit = true;
+                colsweep_split(h);
+                const int ust = colsweep_upload(h);
+                if (ust) { restore_split(); return ust; }
+                choose_launch(h);
+            }
+        }
+    }
+    if (!h0->stream) {
+        const hipError_t se = hipStreamCreateWithFlags(&h0->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { restore_split(); return fail(h0, HJB_E_DEVICE, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(se)); }
+    }
     hipStream_t stream = h0->stream;
     DCsBatch hb;
     memset(&hb, 0, sizeof hb);
@@ -115,8 +118,8 @@ int32_t hjb_solve_batch(int32_t n, const hjb_handle *hs, const hjb_solve_opts *c
         hb.grid[i] = (uint32_t)h->grid;
         gmax = std::max(gmax, (unsigned)h->grid);
         const size_t jb = (size_t)h->n_owned * h->esz;
-        if (opts[i]->terminal) HIP_TRY(h, hipMemcpy(h->dJ[0], opts[i]->terminal, jb, hipMemcpyHostToDevice));
-        else HIP_TRY(h, hipMemset(h->dJ[0], 0, jb));
+        const hipError_t te = opts[i]->terminal ? hipMemcpy(h->dJ[0], opts[i]->terminal, jb, hipMemcpyHostToDevice) : hipMemset(h->dJ[0], 0, jb);
+        if (te != hipSuccess) { restore_split(); return fail(h, HJB_E_DEVICE, "terminal cost of problem %d: %s", i, hipGetErrorString(te)); }
     }
     DCsBatch *dB = nullptr;
     hipGraphExec_t gexec = nullptr;
