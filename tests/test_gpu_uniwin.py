@@ -152,3 +152,15 @@ def test_uniwin_attitude_model_slab_and_float16(env, form):
         assert bk.get_option("packed2_mode") == mode
         o16 = bk.solve(2, terminal=t16, keep_J=True, keep_idx=True)
     assert np.array_equal(o16["J_stages"], r16["J_stages"]) and np.array_equal(o16["idx_stages"], r16["idx_stages"])
+
+
+@pytest.mark.order(6)
+@pytest.mark.watchdog(300)
+def test_uniwin_randomised_stress_slice(env):
+    """Ten seconds of tools/stress_uniwin.py: random rate-shared shapes (D = 4 .. 6, gains from sub-cell to several cells - the plain
+    path of points outside the two-cell windows included -, non-uniform knots, float16 storage, slabs, the walk options); every value
+    and label equals the oracle's.  (The long form: profiles/r06_stress_uniwin.txt.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_uniwin.py"), "10", "7"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
