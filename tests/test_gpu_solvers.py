@@ -553,3 +553,15 @@ def test_attitude_and_pos_att_closed_loop_rollouts(env):
     assert set(np.unique(np.abs(F))).issubset({0.0, 0.13}) and np.any(F != 0)
     assert Xp[200, 0] > Xp[0, 0]                               # from 100 m behind (-0.1 km) toward the target
     assert np.all(np.abs(FM[:200, 0:3]) <= 2 * 0.13 / pa.Mass + 1e-12) and np.all(np.abs(FM[:200, 3:6]) <= 2 * 0.13 * pa.T_dist + 1e-12)
+
+
+@pytest.mark.order(8)
+@pytest.mark.watchdog(300)
+def test_solve_batch_randomised_stress_slice(env):
+    """Ten seconds of tools/stress_batch.py: random batches (column-sweep problems of one group axis, small problems on the table kernel),
+    stage counts around the 32-stage graph, monitors that stop problems at different stages - hjb_solve_batch equals hjb_solve per
+    problem in values, labels, stages done and stop flags.  (The long form: profiles/r06_stress_batch.txt.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_batch.py"), "10", "11"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
