@@ -326,6 +326,53 @@ def run_workload(args, workload, steps, warmup, world, rank, dev, dist, weak=Fal
     return res
 
 
+class OptionalLegsWatchdog:
+    """N > 1: the headline leg is measured FIRST; what follows it - the other halo transport's leg, the weak-scaling extra - is
+    optional and has never met real multi-GPU hardware.  If those parts hang (a collective whose peers never arrive), every rank
+    leaves on its own timer and rank 0 prints the line the headline leg alone supports, instead of the run dying in the driver's
+    time limit without a line.  Disarmed before the normal print."""
+
+    def __init__(self, seconds, rank, line_fn):
+        import threading
+        self._lock = threading.Lock()
+        self._done = False
+        self._rank, self._line_fn = rank, line_fn
+        self._timer = threading.Timer(seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def _fire(self):
+        with self._lock:
+            if self._done:
+                return
+            self._done = True
+            if self._rank == 0:
+                try:
+                    print(json.dumps(self._line_fn()), flush=True)
+                except Exception as e:       # noqa: BLE001
+                    print("bench.py watchdog: could not assemble the line: %s" % e, file=sys.stderr, flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+
+    def swap(self, line_fn):
+        """The optional legs are through: what the timer would print from now on is the complete line (it stays armed across the
+        final barrier - a peer that left on its own timer a moment earlier never arrives there).  -> False if it has fired."""
+        with self._lock:
+            if self._done:
+                return False
+            self._line_fn = line_fn
+        return True
+
+    def disarm(self):
+        """-> True if the normal path may print (the timer has not fired)."""
+        with self._lock:
+            if self._done:
+                return False
+            self._done = True
+        self._timer.cancel()
+        return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,6 +391,11 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="force a stage-kernel variant (testing)")
     ap.add_argument("--grid-n", type=int, default=120, help="points per axis of the pos-att grid (config: 120; smaller = testing)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --share-gpu is a 1-GPU test mode")
+    ap.add_argument("--test-hang-optional", type=int, default=-1,
+                    help="test hook (tests/test_gpu_parity.py): rank R never leaves the optional part after the headline leg (-2: every rank)")
+    ap.add_argument("--optional-timeout", type=float, default=180.0,
+                    help="N > 1: seconds the legs AFTER the headline (other transport, weak scaling) may take before every rank leaves "
+                         "and rank 0 prints the headline-only line (at least 120 x the headline leg's own duration)")
     ap.add_argument("--transport", default="torch", choices=["torch", "lib"],
                     help="N > 1: who moves the halo planes - torch.distributed P2P from Python (default), or the RCCL transport inside "
                          "libhjbdp (hjb_rank_step: one library call per stage; needs one GPU per rank)")
@@ -406,6 +458,29 @@ def main():
     # whether the library's RCCL transport is reachable BEFORE its collective set-up).
     legs, leg_error, chosen = {args.transport: head}, None, args.transport
     other = "lib" if args.transport == "torch" else "torch"
+    watchdog = None
+    if world > 1 and not args.pmc_child:
+        def headline_only():
+            sp = head["spec"]
+            launch_ms = head["dev_ms"] / head["steps"]
+            tfl = f_alg(sp.D) * head["states_rank"] * sp.nU / (launch_ms * 1e-3) / 1e12
+            return {"metric": "bellman_backups_per_s", "value": head["total_backups"] / head["wall"], "unit": "backups/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["wall"] * 1e3 / args.steps,
+                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                    "dtype": "f32" if sp.j_dtype.itemsize == 4 else "f32 (J stored as f16)", "data": "synthetic",
+                    "config": {"workload": head["name"], "states": sp.nS, "states_per_gpu": head["states_rank"], "controls": sp.nU,
+                               "stages": args.steps, "kernel_variant": head["info"]["kernel_variant"]},
+                    "roofline": {"bound": "valu", "achieved": tfl, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_TFLOPS,
+                                 "traffic": None, "avg_launch_ms": launch_ms, "note": "rank 0's stage kernels; per-rank algorithmic flops"},
+                    "checksum_sum_J": head["checksum"],
+                    "transports": {"headline": chosen, args.transport: {"ms_per_step": head["wall"] * 1e3 / head["steps"],
+                                                                         "comm_ranks": head["info"].get("comm_ranks")}},
+                    "incomplete": "the optional legs after the headline (the other halo transport, weak scaling) did not finish within "
+                                  "%d s and were abandoned; the headline leg above was measured in full" % int(limit)}
+        limit = max(args.optional_timeout, 40.0 * head["wall"] * 3)
+        watchdog = OptionalLegsWatchdog(limit, rank, headline_only)
+        if args.test_hang_optional == rank or args.test_hang_optional == -2:
+            time.sleep(36000)
     if world > 1 and args.backend == "nccl" and not args.pmc_child:
         ok = 1
         try:
@@ -557,11 +632,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         small = build_spec(args.workload, n=32)[0] if args.workload in ("c4", "c5") else None
         out["cpu_baseline"] = cpu_baseline(spec, dataflow_spec=small)      # the GPU line's own problem, typing included
+    if watchdog is not None and not watchdog.swap(lambda: out):
+        return                               # (the timer fired and is printing / leaving)
     if world > 1:
         dist.barrier()
+    if watchdog is not None and not watchdog.disarm():
+        return
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        OptionalLegsWatchdog(20.0, 1, lambda: None)      # (tearing the group down must not outlive the line by more than this)
         dist.destroy_process_group()
 
 
