@@ -331,6 +331,11 @@ k_backup_packed2(const DParams *__restrict__ P, const DNested *__restrict__ N, c
         n_v = ac * nw;
     } else {
         n_v = n_chunks;
+        // the same locality rule without a window: workgroup b runs on XCD b % 8, so with chunk = b every XCD's L2 fetched nearly
+        // the whole J (C2: 24 MB through the fabric for a 4 MB array).  XCD x takes the x-th contiguous share of every grid-sized span
+        // (its workgroups b = x, x + 8, ...: G / 8 of them, one more for x < G % 8)
+        const unsigned int G = gridDim.x, x = blockIdx.x & 7u, q = G >> 3, r = G & 7u;
+        first_v = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
     }
     for (unsigned int v = first_v; v < n_v; v += gridDim.x) {
         unsigned int chunk = v;
