@@ -1403,6 +1403,12 @@ void choose_launch(Handle *h) {
     const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass (variant 4: 256)
     int64_t blocks = (h->n_owned + per_block - 1) / per_block;
     h->grid = (int)std::min<int64_t>(blocks, h->variant == 3 ? 1024 : 256 * 16);
+    if ((h->variant == 4 || h->variant == 5) && blocks > h->grid) {
+        // these kernels give XCD x the x-th contiguous share of every grid-sized span of chunks (kernels_packed2.h, kernels_tabled.h):
+        // equally long spans, so that no short last span falls to the first XCDs alone
+        const int64_t spans = (blocks + h->grid - 1) / h->grid;
+        h->grid = (int)(((blocks + spans - 1) / spans + 7) / 8 * 8);      // (a multiple of 8: the window modes' walk asks for it)
+    }
     if (h->variant == 6) {       // one wave per (64-state chunk of a) grid row, four waves per workgroup
         const int64_t n0 = h->hp.n[0];
         const int64_t items = (h->n_owned / n0) * ((n0 + 63) / 64);

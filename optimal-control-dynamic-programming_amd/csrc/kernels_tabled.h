@@ -34,6 +34,15 @@ __device__ __forceinline__ void tab_load_pair(const double *__restrict__ Jn, int
     a = p.x; b = p.y;
 }
 
+// Workgroup b runs on XCD b % 8 (each XCD has its own L2).  With "workgroup b takes states [256 b, 256 b + 256)" every XCD walks the
+// whole grid and its L2 holds all of J; here XCD x takes the x-th CONTIGUOUS share of every grid-sized span of workgroups instead
+// (its workgroups b = x, x + 8, ...: G / 8 of them, one more for x < G % 8), so an L2 holds one region of J and its halo.  The host
+// sizes the launch so that the spans are equally long (choose_launch): a short last span would fall to the first XCDs alone.
+__device__ __forceinline__ unsigned xcd_share(unsigned b, unsigned G) {
+    const unsigned x = b & 7u, q = G >> 3, r = G & 7u;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 struct DTabled {
     struct Axis {
         const void *tab;
@@ -90,7 +99,7 @@ k_backup_tabled(const DParams *__restrict__ P, const DTabled *__restrict__ TB, c
     const int64_t n_owned = P->n_owned;
     const int64_t nU = P->nU;
     const int plane0 = P->plane0, nplanes = P->nplanes;
-    for (int64_t ls = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ls < n_owned;
+    for (int64_t ls = xcd_share(blockIdx.x, gridDim.x) * (int64_t)blockDim.x + threadIdx.x; ls < n_owned;
          ls += (int64_t)gridDim.x * blockDim.x) {
         int si[D];          // global indices (cost term tables)
         int sl[D];          // local index along the last axis (axis tables cover owned planes)
@@ -294,7 +303,7 @@ __device__ __forceinline__ void tabled32_body(const DParams *__restrict__ P, con
         poff[p] = o;
     }
     const int m1 = P->m[1], m2 = P->m[2];
-    for (int ls = (int)(bx * blockDim.x + threadIdx.x); ls < n_owned; ls += (int)(gx * blockDim.x)) {
+    for (int ls = (int)(xcd_share(bx, gx) * blockDim.x + threadIdx.x); ls < n_owned; ls += (int)(gx * blockDim.x)) {
         int si[D], sl[D];
         {
             uint32_t r = (uint32_t)ls;
