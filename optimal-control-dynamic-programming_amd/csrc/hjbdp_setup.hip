@@ -1402,17 +1402,21 @@ void choose_launch(Handle *h) {
     h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
     const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass (variant 4: 256)
     int64_t blocks = (h->n_owned + per_block - 1) / per_block;
-    h->grid = (int)std::min<int64_t>(blocks, h->variant == 3 ? 1024 : 256 * 16);
-    if ((h->variant == 4 || h->variant == 5) && blocks > h->grid) {
-        // these kernels give XCD x the x-th contiguous share of every grid-sized span of chunks (kernels_packed2.h, kernels_tabled.h):
-        // equally long spans, so that no short last span falls to the first XCDs alone
-        const int64_t spans = (blocks + h->grid - 1) / h->grid;
-        h->grid = (int)(((blocks + spans - 1) / spans + 7) / 8 * 8);      // (a multiple of 8: the window modes' walk asks for it)
-    }
+    // A launch smaller than the work walks it in grid-sized spans.  Equally long spans: a short last span runs on part of the chip
+    // (Solver_attitude.run's 5199 chunks as 4096 + 1103: 3.63 ms per 19 stages; as 2 x 2600: 2.53), and the kernels that give XCD x
+    // the x-th contiguous share of every span (kernels_packed2.h, kernels_tabled.h) would hand a short one to the first XCDs alone.
+    auto spans_of = [](int64_t work, int64_t cap) {
+        if (work <= cap) return work;
+        const int64_t spans = (work + cap - 1) / cap;
+        return std::min<int64_t>(cap, ((work + spans - 1) / spans + 7) / 8 * 8);      // (a multiple of 8: the window modes' walk asks for it)
+    };
+    // (the control-split kernel keeps its 1024 workgroups: one wave per state and few states - Kirk's 2500 blocks as 3 x 840 ran 19.3 ms
+    // per 199 stages against 16.3 with a short last span that overlaps the tail of the one before)
+    h->grid = h->variant == 3 ? (int)std::min<int64_t>(blocks, 1024) : (int)spans_of(blocks, 256 * 16);
     if (h->variant == 6) {       // one wave per (64-state chunk of a) grid row, four waves per workgroup
         const int64_t n0 = h->hp.n[0];
         const int64_t items = (h->n_owned / n0) * ((n0 + 63) / 64);
-        h->grid = (int)std::min<int64_t>((items + 3) / 4, 256 * 16);
+        h->grid = (int)spans_of((items + 3) / 4, 256 * 16);
     }
     if (h->variant == 7) {       // one wave per (chunk of axis 0, i2, i3) column; workgroup b serves XCD b % 8
         const DParams &P = h->hp;
