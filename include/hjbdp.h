@@ -268,7 +268,9 @@ int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
  * a column is swept in - each by a wave of its own, priming where it starts; 0 = automatic: more parts for launches with
  * few columns, e.g. the boundary strips of a multi-GPU slab; reads back the value in effect).  Variant 5: "tabled_i32"
  * (1 [default where every index of the problem fits 31 bits]: the table kernel's 32-bit form, 0: its general 64-bit form;
- * reads back the form a launch would take). */
+ * reads back the form a launch would take).  "grid" (get: workgroups per launch; set, timing experiments on the grid-stride
+ * kernels only: the library's own choice walks a grid larger than the launch in equally long spans - until the next option that
+ * re-chooses the launch). */
 int32_t hjb_get_option(hjb_handle h, const char *key, int64_t *value);
 
 /* ONE backup, host buffers (exactly the MATLAB statement above):

@@ -392,6 +392,14 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         }
         return HJB_OK;
     }
+    if (!strcmp(key, "grid")) {                                      // workgroups per launch of the grid-stride stage kernels (timing experiments)
+        if (value < 1 || value > (1 << 20)) return fail(h, HJB_E_INVALID, "%s out of range", key);
+        if (h->variant == 7 || (h->variant == 4 && uniwin_active(h)) || h->variant == 1)
+            return fail(h, HJB_E_UNSUPPORTED, "the launch size of kernel variant %d is part of its plan", h->variant);
+        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        h->grid = (int)value;                                        // (until the next option that re-chooses the launch)
+        return HJB_OK;
+    }
     if (!strcmp(key, "cs_split")) {                                  // variant 7: parts a column is swept in (0 = automatic)
         if (value < 0 || value > 64) return fail(h, HJB_E_INVALID, "%s out of range", key);
         h->cs_split = (int)value;
