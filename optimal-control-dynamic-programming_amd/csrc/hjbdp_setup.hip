@@ -1412,7 +1412,10 @@ void choose_launch(Handle *h) {
     };
     // (the control-split kernel keeps its 1024 workgroups: one wave per state and few states - Kirk's 2500 blocks as 3 x 840 ran 19.3 ms
     // per 199 stages against 16.3 with a short last span that overlaps the tail of the one before)
-    h->grid = h->variant == 3 ? (int)std::min<int64_t>(blocks, 1024) : (int)spans_of(blocks, 256 * 16);
+    // The table kernel takes its whole grid as ONE span where its 32-bit form allows (XCD x then sweeps one contiguous eighth of the
+    // grid: 13M states 0.671 -> 0.630 ms, Solver_attitude.run in the reference's order 13.7 -> 12.9 ms per 19 stages; 2e8 states: equal)
+    const int64_t cap = h->variant == 5 ? kTab32MaxThreads / 256 : 256 * 16;
+    h->grid = h->variant == 3 ? (int)std::min<int64_t>(blocks, 1024) : (int)spans_of(blocks, cap);
     if (h->variant == 6) {       // one wave per (64-state chunk of a) grid row, four waves per workgroup
         const int64_t n0 = h->hp.n[0];
         const int64_t items = (h->n_owned / n0) * ((n0 + 63) / 64);
