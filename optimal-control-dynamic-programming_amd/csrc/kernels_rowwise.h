@@ -58,7 +58,7 @@ k_backup_rowwise(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
     for (int a = 0; a < D; ++a) js[a] = P->jstride[a];
     const bool hasc0 = TB->ax[0].has_ctrl != 0;
 
-    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < items; item += wstride) {
+    for (int64_t item = (int64_t)xcd_share(blockIdx.x, gridDim.x) * 4 + wave; item < items; item += wstride) {      // (XCD-aware: kernels_tabled.h)
         // ---- the row (uniform) and this lane's axis-0 index -------------------------------------
         int sl[D], si[D];
         {
@@ -269,7 +269,7 @@ k_backup_rowlean(const DParams *__restrict__ P, const DTabled *__restrict__ TB, 
     }
     const int my_cj[3] = {lane < nU ? s_cj[3 * lane] : 0, lane < nU ? s_cj[3 * lane + 1] : 0, lane < nU ? s_cj[3 * lane + 2] : 0};
 
-    for (uint32_t item = blockIdx.x * 4u + wave; item < items; item += wstride) {
+    for (uint32_t item = xcd_share(blockIdx.x, gridDim.x) * 4u + wave; item < items; item += wstride) {      // (XCD-aware: kernels_tabled.h)
         int sl[D], si[D];
         {
             uint32_t r = item;

@@ -41,6 +41,8 @@ for v in variants:
                 bk.set_option("cs_dpp", int(os.environ["CS_DPP"]))
             if os.environ.get("CS_XCD_AXIS"):
                 bk.set_option("cs_xcd_axis", int(os.environ["CS_XCD_AXIS"]))
+            if os.environ.get("GRID"):
+                bk.set_option("grid", int(os.environ["GRID"]))
             if os.environ.get("CS_SPLIT"):
                 bk.set_option("cs_split", int(os.environ["CS_SPLIT"]))
             if os.environ.get("TABLED_I32"):
