@@ -270,7 +270,8 @@ int32_t hjb_set_option(hjb_handle h, const char *key, int64_t value);
  * (1 [default where every index of the problem fits 31 bits]: the table kernel's 32-bit form, 0: its general 64-bit form;
  * reads back the form a launch would take).  "grid" (get: workgroups per launch; set, timing experiments on the grid-stride
  * kernels only: the library's own choice walks a grid larger than the launch in equally long spans - until the next option that
- * re-chooses the launch). */
+ * re-chooses the launch).  "block" (set, variant 3 only: 256 / 512 / 1024 threads per workgroup = 64 x the states it sweeps side by
+ * side; 512 by default where J is staged in LDS). */
 int32_t hjb_get_option(hjb_handle h, const char *key, int64_t *value);
 
 /* ONE backup, host buffers (exactly the MATLAB statement above):

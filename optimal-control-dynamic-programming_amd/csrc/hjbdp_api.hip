@@ -392,6 +392,12 @@ int32_t hjb_set_option(hjb_handle hh, const char *key, int64_t value) {
         }
         return HJB_OK;
     }
+    if (!strcmp(key, "block")) {                                     // variant 3: threads per workgroup = 64 x the states a workgroup sweeps side by side
+        if (h->variant != 3 || (value != 256 && value != 512 && value != 1024)) return fail(h, HJB_E_UNSUPPORTED, "block: 256, 512 or 1024 on kernel variant 3");
+        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        h->block = (int)value;
+        return HJB_OK;
+    }
     if (!strcmp(key, "grid")) {                                      // workgroups per launch of the grid-stride stage kernels (timing experiments)
         if (value < 1 || value > (1 << 20)) return fail(h, HJB_E_INVALID, "%s out of range", key);
         if (h->variant == 7 || (h->variant == 4 && uniwin_active(h)) || h->variant == 1)

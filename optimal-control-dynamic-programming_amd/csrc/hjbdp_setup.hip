@@ -1400,7 +1400,10 @@ void choose_launch(Handle *h) {
     }
     h->block = 256;
     h->split_j_in_lds = (size_t)h->j_elems * h->esz <= 64 * 1024;
-    const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? 4 : 256);   // states per workgroup pass (variant 4: 256)
+    // the control-split kernel with J staged in LDS: eight waves share one copy of J (Kirk: 40 KB), so four workgroups fill a CU's 32
+    // wave slots instead of half of them (Kirk's default problem 16.1 -> 13.4 ms per 199 stages: profiles/r06_xcd_shares_and_spans.log)
+    if (h->variant == 3 && h->split_j_in_lds) h->block = 512;
+    const int per_block = h->variant == 2 ? 512 : (h->variant == 3 ? h->block / 64 : 256);   // states per workgroup pass (variant 4: 256)
     int64_t blocks = (h->n_owned + per_block - 1) / per_block;
     // A launch smaller than the work walks it in grid-sized spans.  Equally long spans: a short last span runs on part of the chip
     // (Solver_attitude.run's 5199 chunks as 4096 + 1103: 3.63 ms per 19 stages; as 2 x 2600: 2.53), and the kernels that give XCD x
@@ -1415,7 +1418,7 @@ void choose_launch(Handle *h) {
     // The table kernel takes its whole grid as ONE span where its 32-bit form allows (XCD x then sweeps one contiguous eighth of the
     // grid: 13M states 0.671 -> 0.630 ms, Solver_attitude.run in the reference's order 13.7 -> 12.9 ms per 19 stages; 2e8 states: equal)
     const int64_t cap = h->variant == 5 ? kTab32MaxThreads / 256 : 256 * 16;
-    h->grid = h->variant == 3 ? (int)std::min<int64_t>(blocks, 1024) : (int)spans_of(blocks, cap);
+    h->grid = h->variant == 3 ? (int)std::min<int64_t>(blocks, h->block == 512 ? 2048 : 1024) : (int)spans_of(blocks, cap);
     if (h->variant == 6) {       // one wave per (64-state chunk of a) grid row, four waves per workgroup
         const int64_t n0 = h->hp.n[0];
         const int64_t items = (h->n_owned / n0) * ((n0 + 63) / 64);

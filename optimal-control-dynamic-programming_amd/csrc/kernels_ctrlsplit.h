@@ -18,7 +18,7 @@
 namespace hjb {
 
 template <typename T, int D, bool J_IN_LDS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_backup_ctrlsplit(const DParams *__restrict__ P, const T *__restrict__ Jn, T *__restrict__ Jout,
                    void *__restrict__ idx_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
