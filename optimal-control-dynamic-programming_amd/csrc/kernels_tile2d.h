@@ -18,8 +18,22 @@
 
 namespace hjb {
 
-constexpr int kTileX = 16, kTileY = 16;     // owned states per workgroup
-constexpr int kTileK = 8;                    // stages per launch (halo width)
+// 16 x 8 owned states and 8 stages per launch (patch 32 x 24 = three states per thread).  Solver_position's channel (201 x 201 x 3),
+// 5999 stages alone: 16x16x8 11.63 ms, 8x8x8 11.19, 12x12x8 11.04, 16x8x8 10.32, 16x8x4 10.54, 8x4x4 11.11, 8x8x2 13.77, 16x16x4 12.83,
+// 8x8x4 9.82 - but four stages per launch double the launches, and the three channels of simplified_run side by side then take 24.4 ms
+// instead of 21 - 22 (the device runs two launch chains at full rate): 16 x 8 x 8 is the form that helps both
+// (profiles/r06_xcd_shares_and_spans.log; A/B builds: tools/mkab.sh with -DHJB_TILE_X/Y/K on every unit that includes this header).
+#ifndef HJB_TILE_X
+#define HJB_TILE_X 16
+#endif
+#ifndef HJB_TILE_Y
+#define HJB_TILE_Y 8
+#endif
+#ifndef HJB_TILE_K
+#define HJB_TILE_K 8
+#endif
+constexpr int kTileX = HJB_TILE_X, kTileY = HJB_TILE_Y;     // owned states per workgroup
+constexpr int kTileK = HJB_TILE_K;                           // stages per launch (halo width)
 constexpr int kPatchX = kTileX + 2 * kTileK, kPatchY = kTileY + 2 * kTileK;
 
 // CACHED variant (nU <= kTileMaxU): a thread keeps its <= 4 patch states for the whole launch, so everything that
